@@ -1,0 +1,1110 @@
+/*
+ * demc_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).  See demc_oracle.h.
+ *
+ * Every function cites the reference file:line (relative to /root/reference) it restates.
+ * Arithmetic is IEEE double, compiled with -ffp-contract=off so that the proposal algebra
+ * (crossover.jl:168) is a fixed sequence of correctly-rounded +,-,* that the HIP kernel can
+ * reproduce bit for bit.
+ */
+#include "demc_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_OK 0
+#define ORC_EINVAL 1
+#define ORC_ENOMEM 3
+#define ORC_EUNSUPPORTED 5
+
+#define LOG_2PI 1.8378770664093454835606594728112
+#define LOG_PI 1.1447298858494001741434273513531
+#define PI_D 3.14159265358979323846264338327950288
+
+/* ------------------------------------------------------------------ RNG ------- */
+/* Philox4x32-10 (Salmon et al., SC'11).  Own copy: the oracle shares no code with csrc/. */
+static inline void philox_round(uint32_t c[4], const uint32_t k[2]) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
+    uint32_t k[2] = {key[0], key[1]};
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k);
+        k[0] += 0x9E3779B9u;
+        k[1] += 0xBB67AE85u;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+/* 53-bit uniform in [0,1) from two words, like Julia's rand(Float64) resolution */
+double orc_u53(uint32_t lo, uint32_t hi) {
+    const uint64_t x = ((uint64_t)hi << 32) | lo;
+    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+static inline uint32_t mulhi32(uint32_t x, uint32_t m) { return (uint32_t)(((uint64_t)x * m) >> 32); }
+static inline uint64_t mulhi64(uint64_t x, uint64_t m) { return (uint64_t)(((unsigned __int128)x * m) >> 64); }
+
+enum { S_STEP = 1, S_GROUP = 2, S_PART = 3, S_NOISE = 4, S_RECOMB = 5, S_MIG = 6 };
+
+static inline void draw_block(uint64_t seed, uint32_t stream, uint32_t sweep, uint64_t iter, uint32_t entity,
+                              uint32_t block, uint32_t out[4]) {
+    const uint32_t ctr[4] = {block, entity, (uint32_t)iter, (stream << 24) | (sweep & 0xFFFFu)};
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    orc_philox4x32_10(ctr, key, out);
+}
+
+/* ------------------------------------------------------------------ handle ---- */
+struct orc_handle {
+    orc_config c;
+    int64_t P;
+    double *theta, *weight;
+    int64_t* id;
+    double *lo, *hi;
+    uint8_t* blocks;
+    int32_t* pk;
+    double *pa, *pb;
+    int32_t* pref;
+    int family;
+    double* data;
+    int64_t ndata;
+    int64_t dims[4];
+    double* hyper;
+    int nhyper;
+    /* derived model constants */
+    double* Z;      /* MVN_FULL: whitened data L^-1 x_i, [N][d] */
+    double* L;      /* Cholesky factor (lower), [d][d] */
+    double logdet;  /* log det Sigma */
+    double* lgc;    /* log binomial coefficients */
+    /* history (utilities.jl:161-180).  Stored by SLOT together with the id that sat in the slot at that
+     * row; the host re-keys by particle id on export (the reference writes samples[iter,:,p.id]). */
+    double* hist;
+    uint8_t* acc_hist;
+    double* lp_hist;
+    int64_t* id_hist;
+    /* trace of last sweep */
+    double *tr_prop, *tr_w, *tr_adj;
+    int32_t* tr_idx;
+    uint8_t* tr_acc;
+    char err[256];
+};
+
+static int fail(orc_handle* h, int code, const char* msg) {
+    if (h) snprintf(h->err, sizeof h->err, "%s", msg);
+    return code;
+}
+const char* orc_last_error(orc_handle* h) { return h ? h->err : "null handle"; }
+
+int orc_create(const orc_config* cfg, orc_handle** out) {
+    if (!cfg || !out) return ORC_EINVAL;
+    if (cfg->n_groups < 1 || cfg->Np < 1 || cfg->D < 1 || cfg->n_rows < 0) return ORC_EINVAL;
+    orc_handle* h = (orc_handle*)calloc(1, sizeof *h);
+    if (!h) return ORC_ENOMEM;
+    h->c = *cfg;
+    /* structs.jl:102-105: alpha forced to 0 when there is a single group */
+    if (h->c.n_groups_total <= 0) h->c.n_groups_total = h->c.n_groups;
+    if (h->c.n_groups_total == 1) h->c.alpha = 0.0;
+    h->P = (int64_t)cfg->n_groups * cfg->Np;
+    const int64_t P = h->P, D = cfg->D;
+    h->theta = (double*)calloc((size_t)(P * D), sizeof(double));
+    h->weight = (double*)calloc((size_t)P, sizeof(double));
+    h->id = (int64_t*)calloc((size_t)P, sizeof(int64_t));
+    h->lo = (double*)malloc(sizeof(double) * (size_t)D);
+    h->hi = (double*)malloc(sizeof(double) * (size_t)D);
+    h->pk = (int32_t*)calloc((size_t)D, sizeof(int32_t));
+    h->pa = (double*)calloc((size_t)D, sizeof(double));
+    h->pb = (double*)calloc((size_t)D, sizeof(double));
+    h->pref = (int32_t*)calloc((size_t)D, sizeof(int32_t));
+    h->tr_prop = (double*)calloc((size_t)(P * D), sizeof(double));
+    h->tr_w = (double*)calloc((size_t)P, sizeof(double));
+    h->tr_adj = (double*)calloc((size_t)P, sizeof(double));
+    h->tr_idx = (int32_t*)calloc((size_t)P * 4, sizeof(int32_t));
+    h->tr_acc = (uint8_t*)calloc((size_t)P, 1);
+    for (int64_t j = 0; j < D; ++j) { h->lo[j] = -INFINITY; h->hi[j] = INFINITY; }
+    for (int64_t s = 0; s < P; ++s) h->id[s] = (int64_t)cfg->group_offset * cfg->Np + s;
+    if (cfg->store_history && cfg->n_rows > 0) {
+        h->hist = (double*)calloc((size_t)(cfg->n_rows * P * D), sizeof(double));
+        h->acc_hist = (uint8_t*)calloc((size_t)(cfg->n_rows * P), 1);
+        h->lp_hist = (double*)calloc((size_t)(cfg->n_rows * P), sizeof(double));
+        h->id_hist = (int64_t*)calloc((size_t)(cfg->n_rows * P), sizeof(int64_t));
+        if (!h->hist || !h->acc_hist || !h->lp_hist || !h->id_hist) { orc_destroy(h); return ORC_ENOMEM; }
+        for (int64_t r = 0; r < cfg->n_rows; ++r)
+            for (int64_t s = 0; s < P; ++s) h->id_hist[r * P + s] = (int64_t)cfg->group_offset * cfg->Np + s;
+    }
+    h->family = -1;
+    *out = h;
+    return ORC_OK;
+}
+
+void orc_destroy(orc_handle* h) {
+    if (!h) return;
+    free(h->theta); free(h->weight); free(h->id); free(h->lo); free(h->hi); free(h->blocks);
+    free(h->pk); free(h->pa); free(h->pb); free(h->pref); free(h->data); free(h->hyper);
+    free(h->Z); free(h->L); free(h->lgc); free(h->hist); free(h->acc_hist); free(h->lp_hist); free(h->id_hist);
+    free(h->tr_prop); free(h->tr_w); free(h->tr_adj); free(h->tr_idx); free(h->tr_acc);
+    free(h);
+}
+
+/* ------------------------------------------------------------------ model ----- */
+static int cholesky_lower(const double* S, int d, double* L) {
+    memset(L, 0, sizeof(double) * (size_t)d * d);
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = S[i * d + j];
+            for (int k = 0; k < j; ++k) s -= L[i * d + k] * L[j * d + k];
+            if (i == j) {
+                if (!(s > 0.0)) return 1;
+                L[i * d + i] = sqrt(s);
+            } else
+                L[i * d + j] = s / L[j * d + j];
+        }
+    return 0;
+}
+static void forward_solve(const double* L, int d, const double* b, double* z) {
+    for (int i = 0; i < d; ++i) {
+        double s = b[i];
+        for (int k = 0; k < i; ++k) s -= L[i * d + k] * z[k];
+        z[i] = s / L[i * d + i];
+    }
+}
+
+int orc_set_model(orc_handle* h, int32_t family, const double* data, const int64_t* dims, int32_t ndims,
+                  const double* hyper, int32_t nhyper) {
+    if (!h) return ORC_EINVAL;
+    if (ndims < 0 || ndims > 4) return fail(h, ORC_EINVAL, "ndims out of range");
+    free(h->data); free(h->hyper); free(h->Z); free(h->L); free(h->lgc);
+    h->data = h->hyper = h->Z = h->L = h->lgc = NULL;
+    memset(h->dims, 0, sizeof h->dims);
+    for (int i = 0; i < ndims; ++i) h->dims[i] = dims[i];
+    h->family = family;
+    const int D = h->c.D;
+    int64_t nd = 0;
+    switch (family) {
+        case ORC_FAM_GAUSSIAN:
+            if (D != 2) return fail(h, ORC_EINVAL, "GAUSSIAN needs D=2");
+            nd = h->dims[0];
+            break;
+        case ORC_FAM_MVN_ISO:
+            if (D != h->dims[1] + 1) return fail(h, ORC_EINVAL, "MVN_ISO needs D=d+1");
+            nd = h->dims[0] * h->dims[1];
+            break;
+        case ORC_FAM_MVN_FULL:
+            if (D != h->dims[1] || nhyper != D * D) return fail(h, ORC_EINVAL, "MVN_FULL needs D=d, hyper=Sigma");
+            nd = h->dims[0] * h->dims[1];
+            break;
+        case ORC_FAM_BINOMIAL:
+            if (D != 1) return fail(h, ORC_EINVAL, "BINOMIAL needs D=1");
+            nd = 2 * h->dims[0];
+            break;
+        case ORC_FAM_HIER_BINOMIAL:
+            if (D != h->dims[0] + 2 || nhyper < 1) return fail(h, ORC_EINVAL, "HIER_BINOMIAL needs D=S+2, hyper=n");
+            nd = h->dims[0];
+            break;
+        case ORC_FAM_HIER_GAUSSIAN:
+            if (D != h->dims[0] + 3) return fail(h, ORC_EINVAL, "HIER_GAUSSIAN needs D=S+3");
+            nd = h->dims[0] * h->dims[1];
+            break;
+        case ORC_FAM_LBA:
+            if (D != h->dims[1] + 3) return fail(h, ORC_EINVAL, "LBA needs D=n_acc+3");
+            nd = 2 * h->dims[0];
+            break;
+        case ORC_FAM_LNR:
+            if (D != h->dims[1] + 1) return fail(h, ORC_EINVAL, "LNR needs D=n_acc+1");
+            nd = 2 * h->dims[0];
+            break;
+        case ORC_FAM_RASTRIGIN:
+            nd = 0;
+            break;
+        default:
+            return fail(h, ORC_EUNSUPPORTED, "unknown model family");
+    }
+    h->ndata = nd;
+    if (nd > 0) {
+        if (!data) return fail(h, ORC_EINVAL, "data is NULL");
+        h->data = (double*)malloc(sizeof(double) * (size_t)nd);
+        memcpy(h->data, data, sizeof(double) * (size_t)nd);
+    }
+    h->nhyper = nhyper;
+    if (nhyper > 0) {
+        h->hyper = (double*)malloc(sizeof(double) * (size_t)nhyper);
+        memcpy(h->hyper, hyper, sizeof(double) * (size_t)nhyper);
+    }
+    if (family == ORC_FAM_MVN_FULL) {
+        const int d = D;
+        const int64_t N = h->dims[0];
+        h->L = (double*)malloc(sizeof(double) * (size_t)d * d);
+        if (cholesky_lower(h->hyper, d, h->L)) return fail(h, ORC_EINVAL, "Sigma is not positive definite");
+        h->logdet = 0.0;
+        for (int i = 0; i < d; ++i) h->logdet += 2.0 * log(h->L[i * d + i]);
+        h->Z = (double*)malloc(sizeof(double) * (size_t)N * d);
+        for (int64_t i = 0; i < N; ++i) forward_solve(h->L, d, h->data + i * d, h->Z + i * d);
+    }
+    if (family == ORC_FAM_BINOMIAL) {
+        const int64_t N = h->dims[0];
+        h->lgc = (double*)malloc(sizeof(double) * (size_t)N);
+        for (int64_t i = 0; i < N; ++i) {
+            const double n = h->data[i], k = h->data[N + i];
+            h->lgc[i] = lgamma(n + 1.0) - lgamma(k + 1.0) - lgamma(n - k + 1.0);
+        }
+    }
+    if (family == ORC_FAM_HIER_BINOMIAL) {
+        const int64_t S = h->dims[0];
+        const double n = h->hyper[0];
+        h->lgc = (double*)malloc(sizeof(double) * (size_t)S);
+        for (int64_t s = 0; s < S; ++s) {
+            const double k = h->data[s];
+            h->lgc[s] = lgamma(n + 1.0) - lgamma(k + 1.0) - lgamma(n - k + 1.0);
+        }
+    }
+    return ORC_OK;
+}
+
+int orc_set_priors(orc_handle* h, const int32_t* kind, const double* a, const double* b, const int32_t* ref) {
+    if (!h || !kind) return ORC_EINVAL;
+    for (int j = 0; j < h->c.D; ++j) {
+        h->pk[j] = kind[j];
+        h->pa[j] = a ? a[j] : 0.0;
+        h->pb[j] = b ? b[j] : 1.0;
+        h->pref[j] = ref ? ref[j] : 0;
+        if (kind[j] == ORC_PRIOR_NORMAL_REF && (h->pref[j] < 0 || h->pref[j] >= h->c.D))
+            return fail(h, ORC_EINVAL, "prior ref index out of range");
+    }
+    return ORC_OK;
+}
+int orc_set_bounds(orc_handle* h, const double* lo, const double* hi) {
+    if (!h || !lo || !hi) return ORC_EINVAL;
+    memcpy(h->lo, lo, sizeof(double) * (size_t)h->c.D);
+    memcpy(h->hi, hi, sizeof(double) * (size_t)h->c.D);
+    return ORC_OK;
+}
+int orc_set_blocks(orc_handle* h, const uint8_t* masks, int32_t n_blocks) {
+    if (!h) return ORC_EINVAL;
+    free(h->blocks);
+    h->blocks = NULL;
+    h->c.n_blocks = n_blocks;
+    if (n_blocks > 0) {
+        if (!masks) return fail(h, ORC_EINVAL, "masks is NULL");
+        h->blocks = (uint8_t*)malloc((size_t)n_blocks * h->c.D);
+        memcpy(h->blocks, masks, (size_t)n_blocks * h->c.D);
+    }
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------ densities -- */
+static inline double norm_logpdf(double x, double m, double s) {
+    /* Distributions.jl Normal: -(z^2 + log2pi)/2 - log(sigma) */
+    const double z = (x - m) / s;
+    return -(z * z + LOG_2PI) / 2.0 - log(s);
+}
+static inline double Phi(double x) { return 0.5 * erfc(-x * 0.70710678118654752440); }
+static inline double phi(double x) { return exp(-0.5 * x * x) * 0.39894228040143267794; }
+static inline double softplus(double x) { return x > 0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
+
+static double prior_scalar(int kind, double a, double b, double sref, double x) {
+    switch (kind) {
+        case ORC_PRIOR_FLAT:
+            return 0.0;
+        case ORC_PRIOR_NORMAL:
+            return norm_logpdf(x, a, b);
+        case ORC_PRIOR_NORMAL_REF:
+            return norm_logpdf(x, a, sref);
+        case ORC_PRIOR_HALFCAUCHY: {
+            /* truncated(Cauchy(a,b),0,Inf): logpdf_cauchy(x) - log(1 - cdf(0))  (Gaussian_Example.jl:14) */
+            if (x < 0.0) return -INFINITY;
+            const double z = (x - a) / b;
+            const double tp = 1.0 - (atan((0.0 - a) / b) / PI_D + 0.5);
+            return -LOG_PI - log(b) - log1p(z * z) - log(tp);
+        }
+        case ORC_PRIOR_UNIFORM:
+            return (x >= a && x <= b) ? -log(b - a) : -INFINITY;
+        case ORC_PRIOR_BETA: {
+            if (x < 0.0 || x > 1.0) return -INFINITY;
+            const double lbeta = lgamma(a) + lgamma(b) - lgamma(a + b);
+            const double t1 = (a == 1.0) ? 0.0 : (a - 1.0) * log(x);
+            const double t2 = (b == 1.0) ? 0.0 : (b - 1.0) * log1p(-x);
+            return t1 + t2 - lbeta;
+        }
+    }
+    return NAN;
+}
+
+static double prior_loglike(const orc_handle* h, const double* th) {
+    double ll = 0.0;
+    for (int j = 0; j < h->c.D; ++j) {
+        const double sref = (h->pk[j] == ORC_PRIOR_NORMAL_REF) ? th[h->pref[j]] : 0.0;
+        ll += prior_scalar(h->pk[j], h->pa[j], h->pb[j], sref, th[j]);
+    }
+    return ll;
+}
+
+/* LBA single-trial log density, SequentialSamplingModels.jl conventions (package not in tree:
+ * recalled; Brown & Heathcote 2008): b = A + k, sigma = 1, normalised by 1 - P(all drifts <= 0),
+ * density floored at 1e-10.  Examples/Run_LBA.jl:33-37. */
+static double lba_dens(double v, double s, double b, double A, double t) {
+    const double n1 = (b - A - t * v) / (t * s), n2 = (b - t * v) / (t * s);
+    return (1.0 / A) * (-v * Phi(n1) + s * phi(n1) + v * Phi(n2) - s * phi(n2));
+}
+static double lba_cdf(double v, double s, double b, double A, double t) {
+    const double n1 = (b - A - t * v) / (t * s), n2 = (b - t * v) / (t * s);
+    return 1.0 + ((b - A - t * v) / A) * Phi(n1) - ((b - t * v) / A) * Phi(n2) + ((t * s) / A) * phi(n1) -
+           ((t * s) / A) * phi(n2);
+}
+double orc_lba_logpdf(const double* nu, int32_t n_acc, double A, double k, double tau, int32_t choice, double rt) {
+    if (rt < tau) return -INFINITY;
+    const double b = A + k, t = rt - tau;
+    double den = 1.0, pneg = 1.0;
+    for (int i = 0; i < n_acc; ++i) {
+        if (i + 1 == choice)
+            den *= lba_dens(nu[i], 1.0, b, A, t);
+        else
+            den *= (1.0 - lba_cdf(nu[i], 1.0, b, A, t));
+        pneg *= Phi(-nu[i]);
+    }
+    den = den / (1.0 - pneg);
+    if (isnan(den)) return -INFINITY;
+    if (den < 1e-10) den = 1e-10;
+    return log(den);
+}
+/* LNR: winner LogNormal(nu_c, sigma) density at t - tau times the others' survival.
+ * test/lognormal_race_tests.jl:9-12. */
+double orc_lnr_logpdf(const double* nu, int32_t n_acc, double sigma, double tau, int32_t choice, double rt) {
+    const double t = rt - tau;
+    if (!(t > 0.0)) return -INFINITY;
+    const double lt = log(t);
+    double ll = 0.0;
+    for (int i = 0; i < n_acc; ++i) {
+        const double z = (lt - nu[i]) / sigma;
+        if (i + 1 == choice)
+            ll += -(z * z + LOG_2PI) / 2.0 - log(sigma) - lt;
+        else
+            ll += log(0.5 * erfc(z * 0.70710678118654752440));
+    }
+    return ll;
+}
+
+static double model_loglike(const orc_handle* h, const double* th) {
+    switch (h->family) {
+        case ORC_FAM_GAUSSIAN: { /* sum(logpdf.(Normal(mu,sigma), data)) Gaussian_Example.jl:26-28 */
+            const int64_t N = h->dims[0];
+            double ll = 0.0;
+            for (int64_t i = 0; i < N; ++i) ll += norm_logpdf(h->data[i], th[0], th[1]);
+            return ll;
+        }
+        case ORC_FAM_MVN_ISO: { /* sum(logpdf(MvNormal(mu, sigma^2 I), data)) multivariate_normal_tests.jl:31-33 */
+            const int64_t N = h->dims[0];
+            const int d = (int)h->dims[1];
+            const double s = th[d];
+            double ll = 0.0;
+            for (int64_t i = 0; i < N; ++i) {
+                double q = 0.0;
+                for (int j = 0; j < d; ++j) {
+                    const double r = h->data[i * d + j] - th[j];
+                    q += r * r;
+                }
+                ll += -0.5 * (d * LOG_2PI + d * log(s * s)) - 0.5 * q / (s * s);
+            }
+            return ll;
+        }
+        case ORC_FAM_MVN_FULL: { /* -1/2 (d log2pi + logdet) - 1/2 |L^-1 (x - mu)|^2, whitened */
+            const int64_t N = h->dims[0];
+            const int d = (int)h->dims[1];
+            double m[1024];
+            if (d > 1024) return NAN;
+            forward_solve(h->L, d, th, m);
+            double q = 0.0;
+            for (int64_t i = 0; i < N; ++i) {
+                double qi = 0.0;
+                for (int j = 0; j < d; ++j) {
+                    const double r = h->Z[i * d + j] - m[j];
+                    qi += r * r;
+                }
+                q += qi;
+            }
+            return -0.5 * (double)N * (d * LOG_2PI + h->logdet) - 0.5 * q;
+        }
+        case ORC_FAM_BINOMIAL: { /* logpdf(Binomial(N,theta), k) binomial_tests.jl:15-17 */
+            const int64_t N = h->dims[0];
+            const double p = th[0];
+            double ll = 0.0;
+            for (int64_t i = 0; i < N; ++i) {
+                const double n = h->data[i], k = h->data[N + i];
+                const double t1 = (k == 0.0) ? 0.0 : k * log(p);
+                const double t2 = (n - k == 0.0) ? 0.0 : (n - k) * log1p(-p);
+                ll += h->lgc[i] + t1 + t2;
+            }
+            return ll;
+        }
+        case ORC_FAM_HIER_BINOMIAL: { /* k_s ~ Binomial(n, logistic(mu_b0 + b0_s)) */
+            const int64_t S = h->dims[0];
+            const double n = h->hyper[0];
+            double ll = 0.0;
+            for (int64_t s = 0; s < S; ++s) {
+                const double eta = th[0] + th[2 + s];
+                const double k = h->data[s];
+                ll += h->lgc[s] - k * softplus(-eta) - (n - k) * softplus(eta);
+            }
+            return ll;
+        }
+        case ORC_FAM_HIER_GAUSSIAN: { /* Hierarchical_Example.jl:36-44 */
+            const int64_t S = h->dims[0], n = h->dims[1];
+            const double sg = th[2 + S];
+            double ll = 0.0;
+            for (int64_t s = 0; s < S; ++s) {
+                const double mu = th[0] + th[2 + s];
+                double l = 0.0;
+                for (int64_t i = 0; i < n; ++i) l += norm_logpdf(h->data[s * n + i] - mu, 0.0, sg);
+                ll += l;
+            }
+            return ll;
+        }
+        case ORC_FAM_LBA: {
+            const int64_t N = h->dims[0];
+            const int na = (int)h->dims[1];
+            double ll = 0.0;
+            for (int64_t i = 0; i < N; ++i)
+                ll += orc_lba_logpdf(th, na, th[na], th[na + 1], th[na + 2], (int)h->data[i], h->data[N + i]);
+            return ll;
+        }
+        case ORC_FAM_LNR: {
+            const int64_t N = h->dims[0];
+            const int na = (int)h->dims[1];
+            const double sg = h->nhyper > 0 ? h->hyper[0] : 1.0;
+            double ll = 0.0;
+            for (int64_t i = 0; i < N; ++i)
+                ll += orc_lnr_logpdf(th, na, sg, th[na], (int)h->data[i], h->data[N + i]);
+            return ll;
+        }
+        case ORC_FAM_RASTRIGIN: { /* optimization_tests.jl:15-23 */
+            const int n = h->c.D;
+            double y = 10.0 * n;
+            for (int i = 0; i < n; ++i) y += th[i] * th[i] - 10.0 * cos(2.0 * PI_D * th[i]);
+            return y;
+        }
+    }
+    return NAN;
+}
+
+double orc_mvn_full_direct(const double* X, int64_t N, int32_t d, const double* Sigma, const double* mu) {
+    double* L = (double*)malloc(sizeof(double) * (size_t)d * d);
+    double* r = (double*)malloc(sizeof(double) * (size_t)d);
+    double* z = (double*)malloc(sizeof(double) * (size_t)d);
+    double ll = NAN;
+    if (!cholesky_lower(Sigma, d, L)) {
+        double logdet = 0.0;
+        for (int i = 0; i < d; ++i) logdet += 2.0 * log(L[i * d + i]);
+        ll = 0.0;
+        for (int64_t i = 0; i < N; ++i) {
+            for (int j = 0; j < d; ++j) r[j] = X[i * d + j] - mu[j];
+            forward_solve(L, d, r, z);
+            double q = 0.0;
+            for (int j = 0; j < d; ++j) q += z[j] * z[j];
+            ll += -0.5 * (d * LOG_2PI + logdet) - 0.5 * q;
+        }
+    }
+    free(L); free(r); free(z);
+    return ll;
+}
+
+/* in_bounds, utilities.jl:70-78: inclusive; NaN fails */
+static int in_bounds(const orc_handle* h, const double* th) {
+    for (int j = 0; j < h->c.D; ++j)
+        if (!(th[j] >= h->lo[j] && th[j] <= h->hi[j])) return 0;
+    return 1;
+}
+/* compute_posterior! utilities.jl:92-99 / evaluate_fun! utilities.jl:113-120 */
+static double fitness(const orc_handle* h, const double* th) {
+    if (!in_bounds(h, th)) {
+        if (h->c.fitness_kind == ORC_FITNESS_FUN) return h->c.update_kind == ORC_UPDATE_MAXIMIZE ? -INFINITY : INFINITY;
+        return -INFINITY;
+    }
+    if (h->c.fitness_kind == ORC_FITNESS_FUN) return model_loglike(h, th);
+    return prior_loglike(h, th) + model_loglike(h, th);
+}
+
+int orc_logpost(orc_handle* h, const double* theta, int64_t n, double* out) {
+    if (!h || h->family < 0) return ORC_EINVAL;
+    const int D = h->c.D;
+#pragma omp parallel for schedule(dynamic) num_threads(h->c.n_threads > 0 ? h->c.n_threads : 1)
+    for (int64_t i = 0; i < n; ++i) out[i] = fitness(h, theta + i * D);
+    return ORC_OK;
+}
+int orc_loglike(orc_handle* h, const double* theta, int64_t n, double* out) {
+    if (!h || h->family < 0) return ORC_EINVAL;
+    for (int64_t i = 0; i < n; ++i) out[i] = model_loglike(h, theta + i * h->c.D);
+    return ORC_OK;
+}
+int orc_prior(orc_handle* h, const double* theta, int64_t n, double* out) {
+    if (!h) return ORC_EINVAL;
+    for (int64_t i = 0; i < n; ++i) out[i] = prior_loglike(h, theta + i * h->c.D);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------ state ----- */
+int orc_set_state(orc_handle* h, const double* theta, const double* weight, const int64_t* id) {
+    if (!h || !theta) return ORC_EINVAL;
+    memcpy(h->theta, theta, sizeof(double) * (size_t)(h->P * h->c.D));
+    if (id) memcpy(h->id, id, sizeof(int64_t) * (size_t)h->P);
+    if (weight)
+        memcpy(h->weight, weight, sizeof(double) * (size_t)h->P);
+    else {
+        if (h->family < 0) return fail(h, ORC_EINVAL, "set_model before set_state(weight=NULL)");
+        orc_logpost(h, h->theta, h->P, h->weight);
+    }
+    return ORC_OK;
+}
+int orc_get_state(orc_handle* h, double* theta, double* weight, int64_t* id) {
+    if (!h) return ORC_EINVAL;
+    if (theta) memcpy(theta, h->theta, sizeof(double) * (size_t)(h->P * h->c.D));
+    if (weight) memcpy(weight, h->weight, sizeof(double) * (size_t)h->P);
+    if (id) memcpy(id, h->id, sizeof(int64_t) * (size_t)h->P);
+    return ORC_OK;
+}
+int orc_set_history_rows(orc_handle* h, int64_t row0, int64_t nrows, const double* rows) {
+    if (!h || !h->hist) return ORC_EINVAL;
+    if (row0 < 0 || row0 + nrows > h->c.n_rows) return fail(h, ORC_EINVAL, "history rows out of range");
+    memcpy(h->hist + row0 * h->P * h->c.D, rows, sizeof(double) * (size_t)(nrows * h->P * h->c.D));
+    return ORC_OK;
+}
+int orc_get_history(orc_handle* h, int64_t row0, int64_t row1, double* th, uint8_t* acc, double* lp, int64_t* idh) {
+    if (!h || !h->hist) return ORC_EINVAL;
+    if (row0 < 0 || row1 > h->c.n_rows || row1 < row0) return fail(h, ORC_EINVAL, "history rows out of range");
+    const int64_t n = row1 - row0;
+    if (th) memcpy(th, h->hist + row0 * h->P * h->c.D, sizeof(double) * (size_t)(n * h->P * h->c.D));
+    if (acc) memcpy(acc, h->acc_hist + row0 * h->P, (size_t)(n * h->P));
+    if (lp) memcpy(lp, h->lp_hist + row0 * h->P, sizeof(double) * (size_t)(n * h->P));
+    if (idh) memcpy(idh, h->id_hist + row0 * h->P, sizeof(int64_t) * (size_t)(n * h->P));
+    return ORC_OK;
+}
+int orc_get_trace(orc_handle* h, double* proposal, double* w_prop, double* log_adj, int32_t* idx, uint8_t* accepted) {
+    if (!h) return ORC_EINVAL;
+    if (proposal) memcpy(proposal, h->tr_prop, sizeof(double) * (size_t)(h->P * h->c.D));
+    if (w_prop) memcpy(w_prop, h->tr_w, sizeof(double) * (size_t)h->P);
+    if (log_adj) memcpy(log_adj, h->tr_adj, sizeof(double) * (size_t)h->P);
+    if (idx) memcpy(idx, h->tr_idx, sizeof(int32_t) * (size_t)h->P * 4);
+    if (accepted) memcpy(accepted, h->tr_acc, (size_t)h->P);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------ KAT helpers */
+/* project(p1,p2) = p2 * (<p1,p2>/<p2,p2>)  utilities.jl:239-246 */
+void orc_project(const double* p1, const double* p2, int32_t D, double* out) {
+    double v1 = 0.0, v2 = 0.0;
+    for (int j = 0; j < D; ++j) {
+        v1 += p1[j] * p2[j];
+        v2 += p2[j] * p2[j];
+    }
+    const double r = v1 / v2;
+    for (int j = 0; j < D; ++j) out[j] = p2[j] * r;
+}
+/* reset!: where the block mask is false the proposal takes the previous value  crossover.jl:336-352 */
+void orc_reset(double* proposal, const double* previous, const uint8_t* mask, int32_t D) {
+    for (int j = 0; j < D; ++j)
+        if (!mask[j]) proposal[j] = previous[j];
+}
+/* Particle +,-,* (utilities.jl:271-357) folded into one helper: out = a*x + b*y, evaluated as (x*a) + (y*b) */
+void orc_axpby(const double* x, const double* y, double a, double b, int32_t D, double* out) {
+    for (int j = 0; j < D; ++j) out[j] = x[j] * a + y[j] * b;
+}
+/* shift_particles!: circshift(particles, 1): selected group i receives the particle of i-1  migration.jl:84-91 */
+void orc_shift_particles(double* cand, int32_t n_sel, int32_t D) {
+    if (n_sel < 2) return;
+    double* last = (double*)malloc(sizeof(double) * (size_t)D);
+    memcpy(last, cand + (size_t)(n_sel - 1) * D, sizeof(double) * (size_t)D);
+    for (int i = n_sel - 1; i > 0; --i) memcpy(cand + (size_t)i * D, cand + (size_t)(i - 1) * D, sizeof(double) * (size_t)D);
+    memcpy(cand, last, sizeof(double) * (size_t)D);
+    free(last);
+}
+/* adjust_loglike crossover.jl:268-273.  faithful=1: log(|a|^(d-1) / |b|^(d-1)) as written (over/underflows for
+ * large d); faithful=0: (d-1)(log|a| - log|b|), the form both engines use. */
+double orc_adjust_loglike(const double* pt, const double* prop, const double* pz, int32_t D, int32_t faithful) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int j = 0; j < D; ++j) {
+        const double a = prop[j] - pz[j], b = pt[j] - pz[j];
+        s1 += a * a;
+        s2 += b * b;
+    }
+    if (faithful) return log(pow(sqrt(s1), D - 1) / pow(sqrt(s2), D - 1));
+    return (double)(D - 1) * (0.5 * log(s1) - 0.5 * log(s2));
+}
+/* StatsBase.sample(Weights) walk: t = u*sum; first i with cumsum >= t (recalled; package not in tree) */
+static int32_t weighted_pick(const double* e, int32_t n, double total, double u) {
+    const double t = u * total;
+    int32_t i = 0;
+    double cw = e[0];
+    while (cw < t && i < n - 1) {
+        ++i;
+        cw += e[i];
+    }
+    return i;
+}
+/* select_base exactly as written, including the NaN -> raw-weights fallback  crossover.jl:282-289 */
+int32_t orc_select_base_ref(const double* w, int32_t n, double u) {
+    double* e = (double*)malloc(sizeof(double) * (size_t)n);
+    double tot = 0.0;
+    for (int i = 0; i < n; ++i) tot += exp(w[i]);
+    int anynan = 0;
+    for (int i = 0; i < n; ++i) {
+        e[i] = exp(w[i]) / tot;
+        if (isnan(e[i])) anynan = 1;
+    }
+    double total = 0.0;
+    if (anynan)
+        for (int i = 0; i < n; ++i) e[i] = w[i];
+    for (int i = 0; i < n; ++i) total += e[i];
+    const int32_t r = weighted_pick(e, n, total, u);
+    free(e);
+    return r;
+}
+/* select_particle exactly as written: softmax(-w), NaN -> findmin(w)  migration.jl:64-70 */
+int32_t orc_select_particle_ref(const double* w, int32_t n, double u) {
+    double* e = (double*)malloc(sizeof(double) * (size_t)n);
+    double tot = 0.0;
+    for (int i = 0; i < n; ++i) tot += exp(-w[i]);
+    int anynan = 0;
+    for (int i = 0; i < n; ++i) {
+        e[i] = exp(-w[i]) / tot;
+        if (isnan(e[i])) anynan = 1;
+    }
+    int32_t r;
+    if (anynan) {
+        r = 0;
+        for (int i = 1; i < n; ++i)
+            if (w[i] < w[r]) r = i;
+    } else {
+        double total = 0.0;
+        for (int i = 0; i < n; ++i) total += e[i];
+        r = weighted_pick(e, n, total, u);
+    }
+    free(e);
+    return r;
+}
+
+/* ------------------------------------------------------------------ selection -- */
+/* Stabilised select_base (SURVEY H5 deviation): softmax(w - max) over the whole group. */
+static int32_t select_base_stable(const double* w, int32_t n, double u) {
+    double wmax = -INFINITY;
+    for (int i = 0; i < n; ++i)
+        if (w[i] > wmax) wmax = w[i];
+    double total = 0.0;
+    for (int i = 0; i < n; ++i) total += exp(w[i] - wmax);
+    if (!(total > 0.0) || !(total < INFINITY)) { /* all -Inf or NaN present: uniform pick */
+        int32_t r = (int32_t)(u * n);
+        return r < n ? r : n - 1;
+    }
+    const double t = u * total;
+    int32_t i = 0;
+    double cw = exp(w[0] - wmax);
+    while (cw < t && i < n - 1) {
+        ++i;
+        cw += exp(w[i] - wmax);
+    }
+    return i;
+}
+/* Stabilised select_particle: P(j) ~ exp(-(w_j - wmin)); non-finite weights -> argmin (first), like findmin. */
+static int32_t select_particle_stable(const double* w, int32_t n, double u) {
+    double wmin = INFINITY;
+    int32_t amin = 0;
+    int bad = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!(w[i] > -INFINITY && w[i] < INFINITY)) bad = 1;
+        if (w[i] < wmin) { wmin = w[i]; amin = i; }
+    }
+    if (bad) return amin;
+    double total = 0.0;
+    for (int i = 0; i < n; ++i) total += exp(wmin - w[i]);
+    const double t = u * total;
+    int32_t i = 0;
+    double cw = exp(wmin - w[0]);
+    while (cw < t && i < n - 1) {
+        ++i;
+        cw += exp(wmin - w[i]);
+    }
+    return i;
+}
+
+/* samplepair (StatsBase, recalled): i1 = rand(1:m); i2 = rand(1:m-1); i2 == i1 ? m : i2    */
+static inline void pick_pair(uint32_t r0, uint32_t r1, uint32_t m, uint32_t* i1, uint32_t* i2) {
+    *i1 = mulhi32(r0, m);
+    uint32_t b = mulhi32(r1, m - 1);
+    if (b == *i1) b = m - 1;
+    *i2 = b;
+}
+/* ordered 3-of-m without replacement (self-avoiding by rank shift) */
+static inline void pick_triple(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t m, uint32_t* i1, uint32_t* i2, uint32_t* i3) {
+    const uint32_t a = mulhi32(r0, m);
+    uint32_t b = mulhi32(r1, m - 1);
+    if (b >= a) ++b;
+    uint32_t c = mulhi32(r2, m - 2);
+    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+    if (c >= lo) ++c;
+    if (c >= hi) ++c;
+    *i1 = a; *i2 = b; *i3 = c;
+}
+static inline void pick_cells(const uint64_t hdraw[3], int n, uint64_t M, uint64_t cell[3]) {
+    /* n distinct cells of M (resample: CartesianIndices without replacement, crossover.jl:123-124) */
+    uint64_t a = mulhi64(hdraw[0], M), b = 0, c = 0;
+    if (n > 1) {
+        b = mulhi64(hdraw[1], M - 1);
+        if (b >= a) ++b;
+    }
+    if (n > 2) {
+        c = mulhi64(hdraw[2], M - 2);
+        const uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
+        if (c >= lo) ++c;
+        if (c >= hi) ++c;
+    }
+    cell[0] = a; cell[1] = b; cell[2] = c;
+}
+
+/* ------------------------------------------------------------------ one particle */
+typedef struct {
+    const double* rows;   /* group base: row j at rows + j*D (live or snapshot) */
+    const double* w;      /* group weights (same view) */
+    int32_t pool_lo, pool_n; /* partner pool within the group */
+    int exclude_self;     /* DE pool = pool minus self (setdiff, crossover.jl:158) */
+} group_view;
+
+static void propose(orc_handle* h, int64_t iter, uint32_t sweep, int32_t g_glob, int32_t p, const group_view* gv,
+                    const double* pt, int is_mutation, const uint8_t* mask, double* prop, double* log_adj,
+                    int32_t idx[4]) {
+    const int D = h->c.D, Np = h->c.Np;
+    const uint32_t slot = (uint32_t)g_glob * (uint32_t)Np + (uint32_t)p;
+    const uint64_t seed = h->c.seed;
+    uint32_t r[4];
+    *log_adj = 0.0;
+    idx[0] = idx[1] = idx[2] = idx[3] = -1;
+    if (is_mutation) {
+        /* mutation! mutation.jl:13-25: theta + Normal(0, sigma) per scalar; block mask ignored (main.jl:205) */
+        idx[0] = 2;
+        for (int k = 0; 2 * k < D; ++k) {
+            draw_block(seed, S_NOISE, sweep, (uint64_t)iter, slot, (uint32_t)k, r);
+            const double u1 = orc_u53(r[0], r[1]), u2 = orc_u53(r[2], r[3]);
+            const double rad = sqrt(-2.0 * log(1.0 - u1));
+            const double z0 = rad * cos(2.0 * PI_D * u2), z1 = rad * sin(2.0 * PI_D * u2);
+            prop[2 * k] = pt[2 * k] + h->c.sigma * z0;
+            if (2 * k + 1 < D) prop[2 * k + 1] = pt[2 * k + 1] + h->c.sigma * z1;
+        }
+        return;
+    }
+    draw_block(seed, S_PART, sweep, (uint64_t)iter, slot, 0, r);
+    const double u_snk = orc_u53(r[0], r[1]), u_base = orc_u53(r[2], r[3]);
+    uint32_t ri[4];
+    draw_block(seed, S_PART, sweep, (uint64_t)iter, slot, 1, ri);
+    draw_block(seed, S_PART, sweep, (uint64_t)iter, slot, 2, r);
+    const double u_g1 = orc_u53(r[0], r[1]), u_g2 = orc_u53(r[2], r[3]);
+    const int snooker = (u_snk <= h->c.theta_snooker); /* crossover.jl:31 */
+    const int from_hist = (h->c.partner_kind == ORC_PARTNER_HISTORY);
+    const double *P1 = NULL, *P2 = NULL, *P3 = NULL;
+    uint64_t cell[3] = {0, 0, 0};
+    if (from_hist) {
+        /* resample crossover.jl:113-121: rows 1:(iter-1) x all local particles (a cell is (row, slot);
+         * per row the slots are a permutation of the ids, so a uniform cell is a uniform (row, id)) */
+        uint32_t h4[4], h5[4];
+        draw_block(seed, S_PART, sweep, (uint64_t)iter, slot, 4, h4);
+        draw_block(seed, S_PART, sweep, (uint64_t)iter, slot, 5, h5);
+        const uint64_t hd[3] = {((uint64_t)h4[1] << 32) | h4[0], ((uint64_t)h4[3] << 32) | h4[2], ((uint64_t)h5[1] << 32) | h5[0]};
+        const uint64_t ub = (uint64_t)(iter - 1), M = ub * (uint64_t)h->P;
+        pick_cells(hd, snooker ? 3 : 2, M, cell);
+        const double* rows[3];
+        for (int q = 0; q < 3; ++q) {
+            const uint64_t row = cell[q] % ub, pid = cell[q] / ub;
+            rows[q] = h->hist + ((int64_t)row * h->P + (int64_t)pid) * D;
+        }
+        P1 = rows[0]; P2 = rows[1]; P3 = rows[2];
+        idx[1] = (int32_t)(cell[0] & 0x7fffffff); idx[2] = (int32_t)(cell[1] & 0x7fffffff);
+        idx[3] = snooker ? (int32_t)(cell[2] & 0x7fffffff) : -1;
+    }
+    const double eps = h->c.eps;
+    if (snooker) {
+        /* snooker_update! crossover.jl:239-257 */
+        idx[0] = 1;
+        if (!from_hist) {
+            uint32_t a, b, c;
+            pick_triple(ri[0], ri[1], ri[2], (uint32_t)gv->pool_n, &a, &b, &c);
+            a += gv->pool_lo; b += gv->pool_lo; c += gv->pool_lo;
+            P1 = gv->rows + (int64_t)a * D; P2 = gv->rows + (int64_t)b * D; P3 = gv->rows + (int64_t)c * D;
+            idx[1] = (int32_t)a; idx[2] = (int32_t)b; idx[3] = (int32_t)c;
+        }
+        const double *Pz = P1, *Pm = P2, *Pn = P3;
+        double vm = 0.0, vn = 0.0, vd = 0.0;
+        for (int j = 0; j < D; ++j) { /* project: sum over all scalars, utilities.jl:240-244 */
+            const double d = pt[j] - Pz[j];
+            vm += Pm[j] * d;
+            vn += Pn[j] * d;
+            vd += d * d;
+        }
+        const double cm = vm / vd, cn = vn / vd;
+        const double gam = 1.2 + (2.2 - 1.2) * u_g1; /* rand(Uniform(1.2,2.2)) crossover.jl:249 */
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; 2 * k < D; ++k) {
+            draw_block(seed, S_NOISE, sweep, (uint64_t)iter, slot, (uint32_t)k, r);
+            const double uu[2] = {orc_u53(r[0], r[1]), orc_u53(r[2], r[3])};
+            for (int q = 0; q < 2 && 2 * k + q < D; ++q) {
+                const int j = 2 * k + q;
+                const double d = pt[j] - Pz[j];
+                const double pr1 = d * cm, pr2 = d * cn;
+                const double t1 = pr1 - pr2;
+                const double t2 = t1 * gam;
+                const double t3 = pt[j] + t2;
+                const double bj = -eps + (eps - (-eps)) * uu[q];
+                prop[j] = t3 + bj;
+            }
+        }
+        /* recombination! then reset! then adjust_loglike (crossover.jl:255, :84-85) */
+        if (h->c.kappa != 1.0)
+            for (int k = 0; 2 * k < D; ++k) {
+                draw_block(seed, S_RECOMB, sweep, (uint64_t)iter, slot, (uint32_t)k, r);
+                const double uu[2] = {orc_u53(r[0], r[1]), orc_u53(r[2], r[3])};
+                for (int q = 0; q < 2 && 2 * k + q < D; ++q)
+                    if (uu[q] <= 1.0 - h->c.kappa) prop[2 * k + q] = pt[2 * k + q];
+            }
+        if (mask) orc_reset(prop, pt, mask, D);
+        for (int j = 0; j < D; ++j) {
+            const double a = prop[j] - Pz[j], b = pt[j] - Pz[j];
+            s1 += a * a;
+            s2 += b * b;
+        }
+        *log_adj = (double)(D - 1) * (0.5 * log(s1) - 0.5 * log(s2));
+        return;
+    }
+    /* DE branch: random_gamma / fixed_gamma / variable_gamma  crossover.jl:154-226 */
+    idx[0] = 0;
+    const int kind = h->c.proposal_kind;
+    const int use_base = (kind == ORC_PROPOSAL_RANDOM_GAMMA) && (iter <= h->c.burnin); /* crossover.jl:164 */
+    const double* Pb = NULL;
+    if (use_base) {
+        const int32_t b = select_base_stable(gv->w, Np, u_base); /* crossover.jl:156, whole group */
+        Pb = gv->rows + (int64_t)b * D;
+        idx[3] = b;
+    }
+    if (!from_hist) {
+        uint32_t a, b;
+        if (gv->exclude_self) {
+            pick_pair(ri[0], ri[1], (uint32_t)gv->pool_n - 1, &a, &b);
+            /* group_diff[j] = group[j + (j >= t)]  (setdiff, crossover.jl:158) */
+            const uint32_t t = (uint32_t)(p - gv->pool_lo);
+            a += (a >= t); b += (b >= t);
+        } else
+            pick_pair(ri[0], ri[1], (uint32_t)gv->pool_n, &a, &b);
+        a += gv->pool_lo; b += gv->pool_lo;
+        P1 = gv->rows + (int64_t)a * D; P2 = gv->rows + (int64_t)b * D;
+        idx[1] = (int32_t)a; idx[2] = (int32_t)b;
+    }
+    const double *Pm = P1, *Pn = P2;
+    double g1, g2 = 0.0;
+    if (kind == ORC_PROPOSAL_RANDOM_GAMMA) {
+        g1 = 0.5 + (1.0 - 0.5) * u_g1; /* rand(Uniform(.5,1)) crossover.jl:162 */
+        if (use_base) g2 = 0.5 + (1.0 - 0.5) * u_g2;
+    } else if (kind == ORC_PROPOSAL_FIXED_GAMMA)
+        g1 = 2.38; /* crossover.jl:191 */
+    else
+        g1 = 2.38 / sqrt(2.0 * (double)D); /* crossover.jl:218 */
+    for (int k = 0; 2 * k < D; ++k) {
+        draw_block(seed, S_NOISE, sweep, (uint64_t)iter, slot, (uint32_t)k, r);
+        const double uu[2] = {orc_u53(r[0], r[1]), orc_u53(r[2], r[3])};
+        for (int q = 0; q < 2 && 2 * k + q < D; ++q) {
+            const int j = 2 * k + q;
+            /* ((Pt + g1*(Pm-Pn)) + g2*(Pb-Pt)) + b  crossover.jl:168, operand order per utilities.jl:319-325 */
+            const double t1 = Pm[j] - Pn[j];
+            const double t2 = t1 * g1;
+            double t6 = pt[j] + t2;
+            if (use_base) {
+                const double t4 = Pb[j] - pt[j];
+                const double t5 = t4 * g2;
+                t6 = t6 + t5;
+            }
+            const double bj = -eps + (eps - (-eps)) * uu[q];
+            prop[j] = t6 + bj;
+        }
+    }
+    if (h->c.kappa != 1.0) /* recombination! crossover.jl:301-312 */
+        for (int k = 0; 2 * k < D; ++k) {
+            draw_block(seed, S_RECOMB, sweep, (uint64_t)iter, slot, (uint32_t)k, r);
+            const double uu[2] = {orc_u53(r[0], r[1]), orc_u53(r[2], r[3])};
+            for (int q = 0; q < 2 && 2 * k + q < D; ++q)
+                if (uu[q] <= 1.0 - h->c.kappa) prop[2 * k + q] = pt[2 * k + q];
+        }
+    if (mask) orc_reset(prop, pt, mask, D); /* crossover.jl:93 */
+}
+
+/* accept / mh_update! / maximize! / minimize!  utilities.jl:55-58, :201-226 */
+static int decide(const orc_handle* h, int64_t iter, uint32_t sweep, uint32_t slot, double w_prop, double w_cur, double adj) {
+    if (h->c.update_kind == ORC_UPDATE_MAXIMIZE) return w_prop > w_cur;
+    if (h->c.update_kind == ORC_UPDATE_MINIMIZE) return w_prop < w_cur;
+    uint32_t r[4];
+    draw_block(h->c.seed, S_PART, sweep, (uint64_t)iter, slot, 3, r);
+    const double u = orc_u53(r[0], r[1]);
+    const double pr = fmin(1.0, exp(w_prop - w_cur + adj)); /* NaN propagates -> reject */
+    return u <= pr;
+}
+
+static void sweep_group(orc_handle* h, int64_t iter, uint32_t sweep, int32_t g, const uint8_t* mask, double* snap_rows,
+                        double* snap_w, double* prop) {
+    const int D = h->c.D, Np = h->c.Np;
+    const int32_t g_glob = h->c.group_offset + g;
+    double* rows = h->theta + (int64_t)g * Np * D;
+    double* w = h->weight + (int64_t)g * Np;
+    const int64_t row = iter - 1;
+    uint32_t r[4];
+    draw_block(h->c.seed, S_GROUP, sweep, (uint64_t)iter, (uint32_t)g_glob, 0, r);
+    const int is_mut = (orc_u53(r[0], r[1]) <= h->c.beta); /* mutate_or_crossover! main.jl:199-207 */
+    const int sched = h->c.schedule;
+    const int half = Np / 2;
+    const int n_phase = (sched == ORC_SCHED_TWO_COLOUR) ? 2 : 1;
+    for (int ph = 0; ph < n_phase; ++ph) {
+        int a_lo = 0, a_hi = Np;
+        group_view gv;
+        gv.rows = rows; gv.w = w; gv.pool_lo = 0; gv.pool_n = Np; gv.exclude_self = 1;
+        if (sched == ORC_SCHED_TWO_COLOUR) {
+            a_lo = ph == 0 ? 0 : half; a_hi = ph == 0 ? half : Np;
+            gv.pool_lo = ph == 0 ? half : 0; gv.pool_n = ph == 0 ? Np - half : half; gv.exclude_self = 0;
+        }
+        if (sched != ORC_SCHED_SEQUENTIAL) {
+            /* the GPU schedules read partners, base weights and the current particle from the phase-start state */
+            memcpy(snap_rows, rows, sizeof(double) * (size_t)Np * D);
+            memcpy(snap_w, w, sizeof(double) * (size_t)Np);
+            gv.rows = snap_rows; gv.w = snap_w;
+        }
+        for (int p = a_lo; p < a_hi; ++p) { /* crossover.jl:13-15 / mutation.jl:16 sweep */
+            const int64_t s = (int64_t)g * Np + p;
+            const uint32_t slot = (uint32_t)g_glob * (uint32_t)Np + (uint32_t)p;
+            const double* pt = gv.rows + (int64_t)p * D;
+            const double w_cur = gv.w[p];
+            double adj;
+            int32_t idx[4];
+            /* snooker draws from the whole pool incl. Pt in the reference schedules (crossover.jl:241) */
+            propose(h, iter, sweep, g_glob, p, &gv, pt, is_mut, is_mut ? NULL : mask, prop, &adj, idx);
+            const double w_prop = fitness(h, prop);
+            const int acc = decide(h, iter, sweep, slot, w_prop, w_cur, adj);
+            memcpy(h->tr_prop + s * D, prop, sizeof(double) * (size_t)D);
+            h->tr_w[s] = w_prop; h->tr_adj[s] = adj; h->tr_acc[s] = (uint8_t)acc;
+            memcpy(h->tr_idx + s * 4, idx, sizeof idx);
+            if (acc) {
+                memcpy(rows + (int64_t)p * D, prop, sizeof(double) * (size_t)D);
+                w[p] = w_prop;
+            }
+            if (h->c.update_kind == ORC_UPDATE_MH && h->hist && row >= 0 && row < h->c.n_rows) {
+                /* utilities.jl:207-208: per particle object; keyed by slot here, re-keyed by id_hist on export */
+                h->acc_hist[row * h->P + s] = (uint8_t)acc;
+                h->lp_hist[row * h->P + s] = w[p];
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ migration -- */
+int orc_migration_due(const orc_config* c, int64_t iter) {
+    uint32_t r[4];
+    draw_block(c->seed, S_STEP, 0, (uint64_t)iter, 0, 0, r);
+    const int ngt = c->n_groups_total > 0 ? c->n_groups_total : c->n_groups;
+    const double alpha = ngt == 1 ? 0.0 : c->alpha;
+    return orc_u53(r[0], r[1]) <= alpha; /* main.jl:85 */
+}
+/* select_groups migration.jl:31-35: N = rand(2:n_groups); ordered sample without replacement (Fisher-Yates) */
+int orc_migration_plan(const orc_config* c, int64_t iter, int32_t* sel, int32_t* n_sel) {
+    const int ng = c->n_groups_total > 0 ? c->n_groups_total : c->n_groups;
+    if (ng < 2) { *n_sel = 0; return ORC_OK; }
+    uint32_t r[4];
+    draw_block(c->seed, S_STEP, 0, (uint64_t)iter, 0, 0, r);
+    const int ns = 2 + (int)mulhi32(r[2], (uint32_t)(ng - 1));
+    int32_t* perm = (int32_t*)malloc(sizeof(int32_t) * (size_t)ng);
+    for (int i = 0; i < ng; ++i) perm[i] = i;
+    for (int i = 0; i < ns; ++i) {
+        if ((i & 3) == 0) draw_block(c->seed, S_STEP, 0, (uint64_t)iter, 0, 1 + (uint32_t)(i >> 2), r);
+        const int j = i + (int)mulhi32(r[i & 3], (uint32_t)(ng - i));
+        const int32_t t = perm[i]; perm[i] = perm[j]; perm[j] = t;
+    }
+    for (int i = 0; i < ns; ++i) sel[i] = perm[i];
+    *n_sel = ns;
+    free(perm);
+    return ORC_OK;
+}
+/* select_particle for every local group; row = (slot, theta[D], weight, id) */
+int orc_migration_pack(orc_handle* h, int64_t iter, double* rows) {
+    const int D = h->c.D, Np = h->c.Np;
+    for (int g = 0; g < h->c.n_groups; ++g) {
+        uint32_t r[4];
+        draw_block(h->c.seed, S_MIG, 0, (uint64_t)iter, (uint32_t)(h->c.group_offset + g), 0, r);
+        const int32_t j = select_particle_stable(h->weight + (int64_t)g * Np, Np, orc_u53(r[0], r[1]));
+        const int64_t s = (int64_t)g * Np + j;
+        double* o = rows + (int64_t)g * (D + 3);
+        o[0] = (double)j;
+        memcpy(o + 1, h->theta + s * D, sizeof(double) * (size_t)D);
+        o[D + 1] = h->weight[s];
+        o[D + 2] = (double)h->id[s];
+    }
+    return ORC_OK;
+}
+int orc_migration_apply(orc_handle* h, int64_t iter, const double* all_rows) {
+    const int D = h->c.D, Np = h->c.Np;
+    const int ng = h->c.n_groups_total;
+    int32_t* sel = (int32_t*)malloc(sizeof(int32_t) * (size_t)ng);
+    int32_t ns = 0;
+    orc_migration_plan(&h->c, iter, sel, &ns);
+    for (int i = 0; i < ns; ++i) {
+        const int gd = sel[i], gs = sel[(i + ns - 1) % ns]; /* circshift(particles, 1) migration.jl:86 */
+        const int gl = gd - h->c.group_offset;
+        if (gl < 0 || gl >= h->c.n_groups) continue;
+        const double* dst = all_rows + (int64_t)gd * (D + 3);
+        const double* src = all_rows + (int64_t)gs * (D + 3);
+        const int64_t s = (int64_t)gl * Np + (int64_t)dst[0];
+        memcpy(h->theta + s * D, src + 1, sizeof(double) * (size_t)D);
+        h->weight[s] = src[D + 1];
+        h->id[s] = (int64_t)src[D + 2];
+    }
+    free(sel);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------ step ------ */
+/* step!/pstep! main.jl:84-107 */
+int orc_step(orc_handle* h, int64_t iter0, int32_t n_iters) {
+    if (!h || h->family < 0) return ORC_EINVAL;
+    const int D = h->c.D, Np = h->c.Np;
+    const int nthreads = h->c.n_threads > 0 ? h->c.n_threads : 1;
+    if (h->c.schedule == ORC_SCHED_TWO_COLOUR && Np < 4) return fail(h, ORC_EINVAL, "two_colour needs Np >= 4");
+    if (Np < 3) return fail(h, ORC_EINVAL, "Np >= 3 required (structs.jl:43)");
+    for (int64_t iter = iter0; iter < iter0 + n_iters; ++iter) {
+        if (h->c.partner_kind == ORC_PARTNER_HISTORY && (iter < 2 || !h->hist))
+            return fail(h, ORC_EINVAL, "history partners need n_initial > 0 and stored history");
+        if (orc_migration_due(&h->c, iter)) { /* main.jl:85 */
+            if (h->c.n_groups_total != h->c.n_groups)
+                return fail(h, ORC_EINVAL, "sharded handle: drive migration with pack/apply");
+            double* rows = (double*)malloc(sizeof(double) * (size_t)h->c.n_groups * (D + 3));
+            orc_migration_pack(h, iter, rows);
+            orc_migration_apply(h, iter, rows);
+            free(rows);
+        }
+        const int n_sweeps = h->c.n_blocks > 0 ? h->c.n_blocks : 1; /* block_update! main.jl:174-179 */
+        for (int b = 0; b < n_sweeps; ++b) {
+            const uint8_t* mask = h->c.n_blocks > 0 ? h->blocks + (size_t)b * D : NULL;
+#pragma omp parallel num_threads(nthreads)
+            {
+                double* snap_rows = (double*)malloc(sizeof(double) * (size_t)Np * D);
+                double* snap_w = (double*)malloc(sizeof(double) * (size_t)Np);
+                double* prop = (double*)malloc(sizeof(double) * (size_t)D);
+#pragma omp for schedule(dynamic)
+                for (int g = 0; g < h->c.n_groups; ++g) /* p_update! main.jl:135-148: one task per group */
+                    sweep_group(h, iter, (uint32_t)b, g, mask, snap_rows, snap_w, prop);
+                free(snap_rows); free(snap_w); free(prop);
+            }
+        }
+        /* store_samples! utilities.jl:161-180: samples[iter, :, p.id] = p.theta */
+        const int64_t row = iter - 1;
+        if (h->hist && row >= 0 && row < h->c.n_rows)
+            for (int64_t s = 0; s < h->P; ++s) {
+                memcpy(h->hist + (row * h->P + s) * D, h->theta + s * D, sizeof(double) * (size_t)D);
+                h->id_hist[row * h->P + s] = h->id[s];
+            }
+    }
+    return ORC_OK;
+}

@@ -1,0 +1,249 @@
+"""ctypes wrapper around oracle/libdemc_oracle.so -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (differentialevolutionmcmc.jl_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libdemc_oracle.so")
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("demc_oracle.c", "demc_oracle.h", "Makefile")]
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libdemc_oracle.so"])
+    return _LIB
+
+
+class OrcConfig(C.Structure):
+    _fields_ = [
+        ("n_groups", C.c_int32), ("Np", C.c_int32), ("D", C.c_int32), ("n_blocks", C.c_int32),
+        ("burnin", C.c_int64), ("n_initial", C.c_int64), ("n_rows", C.c_int64),
+        ("alpha", C.c_double), ("beta", C.c_double), ("eps", C.c_double), ("sigma", C.c_double),
+        ("kappa", C.c_double), ("theta_snooker", C.c_double),
+        ("proposal_kind", C.c_int32), ("partner_kind", C.c_int32), ("update_kind", C.c_int32),
+        ("fitness_kind", C.c_int32), ("schedule", C.c_int32), ("store_history", C.c_int32),
+        ("group_offset", C.c_int32), ("n_groups_total", C.c_int32),
+        ("seed", C.c_uint64), ("n_threads", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+_bp = C.POINTER(C.c_uint8)
+_up = C.POINTER(C.c_uint32)
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        L.orc_create.argtypes = [C.POINTER(OrcConfig), C.POINTER(C.c_void_p)]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_last_error.argtypes = [C.c_void_p]
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_set_model.argtypes = [C.c_void_p, C.c_int32, _dp, _lp, C.c_int32, _dp, C.c_int32]
+        L.orc_set_priors.argtypes = [C.c_void_p, _ip, _dp, _dp, _ip]
+        L.orc_set_bounds.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_set_blocks.argtypes = [C.c_void_p, _bp, C.c_int32]
+        L.orc_set_state.argtypes = [C.c_void_p, _dp, _dp, _lp]
+        L.orc_get_state.argtypes = [C.c_void_p, _dp, _dp, _lp]
+        L.orc_set_history_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int64, _dp]
+        L.orc_get_history.argtypes = [C.c_void_p, C.c_int64, C.c_int64, _dp, _bp, _dp, _lp]
+        L.orc_step.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
+        L.orc_logpost.argtypes = [C.c_void_p, _dp, C.c_int64, _dp]
+        L.orc_loglike.argtypes = [C.c_void_p, _dp, C.c_int64, _dp]
+        L.orc_prior.argtypes = [C.c_void_p, _dp, C.c_int64, _dp]
+        L.orc_get_trace.argtypes = [C.c_void_p, _dp, _dp, _dp, _ip, _bp]
+        L.orc_migration_due.argtypes = [C.POINTER(OrcConfig), C.c_int64]
+        L.orc_migration_pack.argtypes = [C.c_void_p, C.c_int64, _dp]
+        L.orc_migration_apply.argtypes = [C.c_void_p, C.c_int64, _dp]
+        L.orc_migration_plan.argtypes = [C.POINTER(OrcConfig), C.c_int64, _ip, _ip]
+        L.orc_project.argtypes = [_dp, _dp, C.c_int32, _dp]
+        L.orc_reset.argtypes = [_dp, _dp, _bp, C.c_int32]
+        L.orc_axpby.argtypes = [_dp, _dp, C.c_double, C.c_double, C.c_int32, _dp]
+        L.orc_shift_particles.argtypes = [_dp, C.c_int32, C.c_int32]
+        L.orc_adjust_loglike.argtypes = [_dp, _dp, _dp, C.c_int32, C.c_int32]
+        L.orc_adjust_loglike.restype = C.c_double
+        L.orc_select_base_ref.argtypes = [_dp, C.c_int32, C.c_double]
+        L.orc_select_particle_ref.argtypes = [_dp, C.c_int32, C.c_double]
+        L.orc_philox4x32_10.argtypes = [_up, _up, _up]
+        L.orc_u53.argtypes = [C.c_uint32, C.c_uint32]
+        L.orc_u53.restype = C.c_double
+        L.orc_mvn_full_direct.argtypes = [_dp, C.c_int64, C.c_int32, _dp, _dp]
+        L.orc_mvn_full_direct.restype = C.c_double
+        L.orc_lba_logpdf.argtypes = [_dp, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_double]
+        L.orc_lba_logpdf.restype = C.c_double
+        L.orc_lnr_logpdf.argtypes = [_dp, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_double]
+        L.orc_lnr_logpdf.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+CFG_KEYS = [f[0] for f in OrcConfig._fields_]
+
+
+def make_config(**kw):
+    c = OrcConfig()
+    defaults = dict(n_groups=4, Np=4, D=1, n_blocks=0, burnin=1000, n_initial=0, n_rows=0, alpha=0.1, beta=0.1,
+                    eps=0.001, sigma=0.05, kappa=1.0, theta_snooker=0.0, proposal_kind=0, partner_kind=0,
+                    update_kind=0, fitness_kind=0, schedule=0, store_history=1, group_offset=0, n_groups_total=0,
+                    seed=1, n_threads=1, reserved=0)
+    defaults.update(kw)
+    for k, v in defaults.items():
+        if k not in CFG_KEYS:
+            continue
+        setattr(c, k, v)
+    if c.n_groups_total == 0:
+        c.n_groups_total = c.n_groups
+    return c
+
+
+class Oracle:
+    """Engine interface shared (by convention) with the HIP engine: same method names and array shapes."""
+
+    def __init__(self, **cfg):
+        self.L = lib()
+        self.cfg = make_config(**cfg)
+        self.h = C.c_void_p()
+        rc = self.L.orc_create(C.byref(self.cfg), C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError(f"orc_create failed rc={rc}")
+        self.P = self.cfg.n_groups * self.cfg.Np
+        self.D = self.cfg.D
+
+    def close(self):
+        if self.h:
+            self.L.orc_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"oracle error rc={rc}: {self.L.orc_last_error(self.h).decode()}")
+
+    def set_model(self, family, data, dims, hyper=None):
+        data = np.ascontiguousarray(np.asarray(data, dtype=np.float64).ravel()) if data is not None else None
+        dims = np.ascontiguousarray(np.asarray(dims, dtype=np.int64))
+        hyper = np.ascontiguousarray(np.asarray(hyper, dtype=np.float64).ravel()) if hyper is not None else None
+        self._ck(self.L.orc_set_model(self.h, family, _d(data), dims.ctypes.data_as(_lp), len(dims), _d(hyper),
+                                      0 if hyper is None else hyper.size))
+
+    def set_priors(self, kind, a, b, ref=None):
+        kind = np.ascontiguousarray(kind, dtype=np.int32)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        ref = np.zeros(self.D, np.int32) if ref is None else np.ascontiguousarray(ref, dtype=np.int32)
+        self._ck(self.L.orc_set_priors(self.h, kind.ctypes.data_as(_ip), _d(a), _d(b), ref.ctypes.data_as(_ip)))
+
+    def set_bounds(self, lo, hi):
+        lo = np.ascontiguousarray(lo, dtype=np.float64)
+        hi = np.ascontiguousarray(hi, dtype=np.float64)
+        self._ck(self.L.orc_set_bounds(self.h, _d(lo), _d(hi)))
+
+    def set_blocks(self, masks):
+        masks = np.ascontiguousarray(masks, dtype=np.uint8).reshape(-1, self.D)
+        self._ck(self.L.orc_set_blocks(self.h, masks.ctypes.data_as(_bp), masks.shape[0]))
+
+    def set_state(self, theta, weight=None, ids=None):
+        theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(self.P, self.D)
+        w = None if weight is None else np.ascontiguousarray(weight, dtype=np.float64)
+        i = None if ids is None else np.ascontiguousarray(ids, dtype=np.int64)
+        self._ck(self.L.orc_set_state(self.h, _d(theta), _d(w), None if i is None else i.ctypes.data_as(_lp)))
+
+    def get_state(self):
+        th = np.empty((self.P, self.D))
+        w = np.empty(self.P)
+        i = np.empty(self.P, np.int64)
+        self._ck(self.L.orc_get_state(self.h, _d(th), _d(w), i.ctypes.data_as(_lp)))
+        return th, w, i
+
+    def set_history_rows(self, row0, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.float64).reshape(-1, self.P, self.D)
+        self._ck(self.L.orc_set_history_rows(self.h, row0, rows.shape[0], _d(rows)))
+
+    def get_history(self, row0, row1):
+        n = row1 - row0
+        th = np.empty((n, self.P, self.D))
+        acc = np.empty((n, self.P), np.uint8)
+        lp = np.empty((n, self.P))
+        idh = np.empty((n, self.P), np.int64)
+        self._ck(self.L.orc_get_history(self.h, row0, row1, _d(th), acc.ctypes.data_as(_bp), _d(lp),
+                                        idh.ctypes.data_as(_lp)))
+        return th, acc, lp, idh
+
+    def step(self, iter0, n_iters=1):
+        self._ck(self.L.orc_step(self.h, iter0, n_iters))
+
+    def logpost(self, theta):
+        theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(-1, self.D)
+        out = np.empty(theta.shape[0])
+        self._ck(self.L.orc_logpost(self.h, _d(theta), theta.shape[0], _d(out)))
+        return out
+
+    def loglike(self, theta):
+        theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(-1, self.D)
+        out = np.empty(theta.shape[0])
+        self._ck(self.L.orc_loglike(self.h, _d(theta), theta.shape[0], _d(out)))
+        return out
+
+    def prior(self, theta):
+        theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(-1, self.D)
+        out = np.empty(theta.shape[0])
+        self._ck(self.L.orc_prior(self.h, _d(theta), theta.shape[0], _d(out)))
+        return out
+
+    def get_trace(self):
+        prop = np.empty((self.P, self.D))
+        w = np.empty(self.P)
+        adj = np.empty(self.P)
+        idx = np.empty((self.P, 4), np.int32)
+        acc = np.empty(self.P, np.uint8)
+        self._ck(self.L.orc_get_trace(self.h, _d(prop), _d(w), _d(adj), idx.ctypes.data_as(_ip),
+                                      acc.ctypes.data_as(_bp)))
+        return dict(proposal=prop, w_prop=w, log_adj=adj, idx=idx, accepted=acc)
+
+    def migration_due(self, it):
+        return bool(self.L.orc_migration_due(C.byref(self.cfg), it))
+
+    def migration_plan(self, it):
+        sel = np.empty(self.cfg.n_groups_total, np.int32)
+        n = C.c_int32()
+        self.L.orc_migration_plan(C.byref(self.cfg), it, sel.ctypes.data_as(_ip), C.byref(n))
+        return sel[: n.value].copy()
+
+    def migration_pack(self, it):
+        rows = np.empty((self.cfg.n_groups, self.D + 3))
+        self._ck(self.L.orc_migration_pack(self.h, it, _d(rows)))
+        return rows
+
+    def migration_apply(self, it, all_rows):
+        all_rows = np.ascontiguousarray(all_rows, dtype=np.float64).reshape(self.cfg.n_groups_total, self.D + 3)
+        self._ck(self.L.orc_migration_apply(self.h, it, _d(all_rows)))
+
+
+def philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().orc_philox4x32_10(c, k, o)
+    return [int(x) for x in o]
