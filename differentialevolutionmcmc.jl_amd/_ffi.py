@@ -1,0 +1,242 @@
+"""ctypes binding of libdemc_hip.so (include/demc.h).
+
+This is the only compute backend of the package: if the shared library is missing or no HIP
+device is visible, every entry point raises -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdemc_hip.so")
+
+OK, EINVAL, EHIP, ENOMEM, ERCCL, EUNSUPPORTED = 0, 1, 2, 3, 4, 5
+_CODE = {1: "DEMC_EINVAL", 2: "DEMC_EHIP", 3: "DEMC_ENOMEM", 4: "DEMC_ERCCL", 5: "DEMC_EUNSUPPORTED"}
+
+EXPORTS = [
+    "demc_version", "demc_create", "demc_destroy", "demc_last_error", "demc_set_stream", "demc_set_model",
+    "demc_set_priors", "demc_set_bounds", "demc_set_blocks", "demc_set_state", "demc_get_state",
+    "demc_set_history_rows", "demc_get_history", "demc_step", "demc_update", "demc_migration_due",
+    "demc_migration_pack", "demc_migration_apply", "demc_logpost", "demc_get_trace", "demc_timing_enable",
+    "demc_timing_read",
+]
+
+
+class DemcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{_CODE.get(code, code)}: {msg}")
+        self.code = code
+
+
+class DemcConfig(C.Structure):
+    """POD mirror of demc_config (include/demc.h) = the DE keyword constructor (structs.jl:80-131)."""
+    _fields_ = [
+        ("n_groups", C.c_int32), ("Np", C.c_int32), ("D", C.c_int32), ("n_blocks", C.c_int32),
+        ("burnin", C.c_int64), ("n_initial", C.c_int64), ("n_rows", C.c_int64),
+        ("alpha", C.c_double), ("beta", C.c_double), ("eps", C.c_double), ("sigma", C.c_double),
+        ("kappa", C.c_double), ("theta_snooker", C.c_double),
+        ("proposal_kind", C.c_int32), ("partner_kind", C.c_int32), ("update_kind", C.c_int32),
+        ("fitness_kind", C.c_int32), ("schedule", C.c_int32), ("store_history", C.c_int32),
+        ("group_offset", C.c_int32), ("n_groups_total", C.c_int32),
+        ("seed", C.c_uint64), ("device_id", C.c_int32), ("loglike_mode", C.c_int32),
+    ]
+
+
+CFG_KEYS = [f[0] for f in DemcConfig._fields_]
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+_bp = C.POINTER(C.c_uint8)
+_lib = None
+
+
+def load():
+    """Load libdemc_hip.so; raises if it has not been built (python __graft_entry__.py / make -C csrc)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    H = C.c_void_p
+    L.demc_version.restype = C.c_int32
+    L.demc_create.argtypes = [C.POINTER(DemcConfig), C.POINTER(H)]
+    L.demc_destroy.argtypes = [H]
+    L.demc_last_error.argtypes = [H]
+    L.demc_last_error.restype = C.c_char_p
+    L.demc_set_stream.argtypes = [H, C.c_void_p]
+    L.demc_set_model.argtypes = [H, C.c_int32, _dp, _lp, C.c_int32, _dp, C.c_int32]
+    L.demc_set_priors.argtypes = [H, _ip, _dp, _dp, _ip]
+    L.demc_set_bounds.argtypes = [H, _dp, _dp]
+    L.demc_set_blocks.argtypes = [H, _bp, C.c_int32]
+    L.demc_set_state.argtypes = [H, _dp, _dp, _lp]
+    L.demc_get_state.argtypes = [H, _dp, _dp, _lp]
+    L.demc_set_history_rows.argtypes = [H, C.c_int64, C.c_int64, _dp]
+    L.demc_get_history.argtypes = [H, C.c_int64, C.c_int64, _dp, _bp, _dp, _lp]
+    L.demc_step.argtypes = [H, C.c_int64, C.c_int32]
+    L.demc_update.argtypes = [H, C.c_int64, C.c_int32]
+    L.demc_migration_due.argtypes = [C.POINTER(DemcConfig), C.c_int64]
+    L.demc_migration_pack.argtypes = [H, C.c_int64, C.c_void_p]
+    L.demc_migration_apply.argtypes = [H, C.c_int64, C.c_void_p]
+    L.demc_logpost.argtypes = [H, _dp, C.c_int64, _dp]
+    L.demc_get_trace.argtypes = [H, _dp, _dp, _dp, _ip, _bp]
+    L.demc_timing_enable.argtypes = [H, C.c_int32]
+    L.demc_timing_read.argtypes = [H, _dp, C.c_int32]
+    for name in EXPORTS:
+        if name not in ("demc_last_error",):
+            getattr(L, name).restype = C.c_int32 if name != "demc_last_error" else C.c_char_p
+    L.demc_last_error.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def make_config(**kw):
+    d = dict(n_groups=4, Np=4, D=1, n_blocks=0, burnin=1000, n_initial=0, n_rows=0, alpha=0.1, beta=0.1, eps=0.001,
+             sigma=0.05, kappa=1.0, theta_snooker=0.0, proposal_kind=0, partner_kind=0, update_kind=0,
+             fitness_kind=0, schedule=2, store_history=1, group_offset=0, n_groups_total=0, seed=1, device_id=0,
+             loglike_mode=0)
+    for k, v in kw.items():
+        if k in d:
+            d[k] = v
+    c = DemcConfig()
+    for k, v in d.items():
+        setattr(c, k, v)
+    if c.n_groups_total == 0:
+        c.n_groups_total = c.n_groups
+    return c
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+class HipEngine:
+    """One demc_handle (one GPU, one shard of groups).  Method names and array shapes are the engine interface
+    the host driver (sampler.py / distributed.py) is written against."""
+
+    def __init__(self, **cfg):
+        self.L = load()
+        self.cfg = make_config(**cfg)
+        self.h = C.c_void_p()
+        rc = self.L.demc_create(C.byref(self.cfg), C.byref(self.h))
+        if rc != OK:
+            msg = self.L.demc_last_error(self.h).decode() if self.h else "demc_create failed"
+            if self.h:
+                self.L.demc_destroy(self.h)
+                self.h = C.c_void_p()
+            raise DemcError(rc, msg)
+        self.P = self.cfg.n_groups * self.cfg.Np
+        self.D = self.cfg.D
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.demc_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != OK:
+            raise DemcError(rc, self.L.demc_last_error(self.h).decode())
+
+    def set_stream(self, hip_stream):
+        self._ck(self.L.demc_set_stream(self.h, C.c_void_p(hip_stream)))
+
+    def set_model(self, family, data, dims, hyper=None):
+        data = None if data is None else np.ascontiguousarray(np.asarray(data, dtype=np.float64).ravel())
+        dims = np.ascontiguousarray(np.asarray(dims, dtype=np.int64).ravel())
+        hyper = None if hyper is None else np.ascontiguousarray(np.asarray(hyper, dtype=np.float64).ravel())
+        self._ck(self.L.demc_set_model(self.h, family, _d(data), dims.ctypes.data_as(_lp), dims.size, _d(hyper),
+                                       0 if hyper is None else hyper.size))
+
+    def set_priors(self, kind, a, b, ref=None):
+        kind = np.ascontiguousarray(kind, dtype=np.int32)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        ref = np.zeros(self.D, np.int32) if ref is None else np.ascontiguousarray(ref, dtype=np.int32)
+        self._ck(self.L.demc_set_priors(self.h, kind.ctypes.data_as(_ip), _d(a), _d(b), ref.ctypes.data_as(_ip)))
+
+    def set_bounds(self, lo, hi):
+        lo = np.ascontiguousarray(lo, dtype=np.float64)
+        hi = np.ascontiguousarray(hi, dtype=np.float64)
+        self._ck(self.L.demc_set_bounds(self.h, _d(lo), _d(hi)))
+
+    def set_blocks(self, masks):
+        masks = np.ascontiguousarray(masks, dtype=np.uint8).reshape(-1, self.D)
+        self._ck(self.L.demc_set_blocks(self.h, masks.ctypes.data_as(_bp), masks.shape[0]))
+
+    def set_state(self, theta, weight=None, ids=None):
+        theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(self.P, self.D)
+        w = None if weight is None else np.ascontiguousarray(weight, dtype=np.float64)
+        i = None if ids is None else np.ascontiguousarray(ids, dtype=np.int64)
+        self._ck(self.L.demc_set_state(self.h, _d(theta), _d(w), None if i is None else i.ctypes.data_as(_lp)))
+
+    def get_state(self):
+        th = np.empty((self.P, self.D))
+        w = np.empty(self.P)
+        i = np.empty(self.P, np.int64)
+        self._ck(self.L.demc_get_state(self.h, _d(th), _d(w), i.ctypes.data_as(_lp)))
+        return th, w, i
+
+    def set_history_rows(self, row0, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.float64).reshape(-1, self.P, self.D)
+        self._ck(self.L.demc_set_history_rows(self.h, row0, rows.shape[0], _d(rows)))
+
+    def get_history(self, row0, row1):
+        n = row1 - row0
+        th = np.empty((n, self.P, self.D))
+        acc = np.empty((n, self.P), np.uint8)
+        lp = np.empty((n, self.P))
+        idh = np.empty((n, self.P), np.int64)
+        self._ck(self.L.demc_get_history(self.h, row0, row1, _d(th), acc.ctypes.data_as(_bp), _d(lp),
+                                         idh.ctypes.data_as(_lp)))
+        return th, acc, lp, idh
+
+    def step(self, iter0, n_iters=1):
+        self._ck(self.L.demc_step(self.h, iter0, n_iters))
+
+    def update(self, iter0, n_iters=1):
+        self._ck(self.L.demc_update(self.h, iter0, n_iters))
+
+    def logpost(self, theta):
+        theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(-1, self.D)
+        out = np.empty(theta.shape[0])
+        self._ck(self.L.demc_logpost(self.h, _d(theta), theta.shape[0], _d(out)))
+        return out
+
+    def get_trace(self):
+        prop = np.empty((self.P, self.D))
+        w = np.empty(self.P)
+        adj = np.empty(self.P)
+        idx = np.empty((self.P, 4), np.int32)
+        acc = np.empty(self.P, np.uint8)
+        self._ck(self.L.demc_get_trace(self.h, _d(prop), _d(w), _d(adj), idx.ctypes.data_as(_ip),
+                                       acc.ctypes.data_as(_bp)))
+        return dict(proposal=prop, w_prop=w, log_adj=adj, idx=idx, accepted=acc)
+
+    def migration_due(self, it):
+        return bool(self.L.demc_migration_due(C.byref(self.cfg), it))
+
+    def migration_pack_dev(self, it, dev_ptr):
+        """select_particle for every local group; rows [n_groups][D+3] written to the device address dev_ptr."""
+        self._ck(self.L.demc_migration_pack(self.h, it, C.c_void_p(dev_ptr)))
+
+    def migration_apply_dev(self, it, dev_ptr):
+        """shift_particles! given the all-gathered rows [n_groups_total][D+3] at the device address dev_ptr."""
+        self._ck(self.L.demc_migration_apply(self.h, it, C.c_void_p(dev_ptr)))
+
+    def timing_enable(self, on=True):
+        self._ck(self.L.demc_timing_enable(self.h, 1 if on else 0))
+
+    def timing_read(self, reset=True):
+        out = np.zeros(10)
+        self._ck(self.L.demc_timing_read(self.h, _d(out), 1 if reset else 0))
+        names = ("propose", "loglike_prep", "loglike", "accept_store", "migration")
+        return {n: dict(ms=out[i], launches=int(out[5 + i])) for i, n in enumerate(names)}

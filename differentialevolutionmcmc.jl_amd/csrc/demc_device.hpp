@@ -1,0 +1,134 @@
+// demc_device.hpp -- device-side building blocks of the gfx950 DE-MCMC path:
+// counter-based Philox4x32-10, draw addressing, and the registered log-densities.
+//
+// RNG contract (DESIGN.md "Randomness"): the reference consumes Julia's task-local Xoshiro
+// stream in a fixed order.  A fused kernel cannot share one sequential
+// stream, so every draw is addressed instead:
+//     Philox4x32-10( key = seed,
+//                    ctr = (block, entity, iteration, stream<<24 | sweep) )
+// entity = global group index or global slot index, so results do not depend on how groups
+// are sharded over GPUs.  One block = 4 x u32 = two 53-bit uniforms.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace demc {
+
+constexpr double kLog2Pi = 1.8378770664093454835606594728112;
+constexpr double kLogPi = 1.1447298858494001741434273513531;
+constexpr double kPi = 3.14159265358979323846264338327950288;
+constexpr double kInvSqrt2 = 0.70710678118654752440;
+constexpr double kInvSqrt2Pi = 0.39894228040143267794;
+
+enum Stream : uint32_t { S_STEP = 1, S_GROUP = 2, S_PART = 3, S_NOISE = 4, S_RECOMB = 5, S_MIG = 6 };
+
+struct U4 {
+    uint32_t x, y, z, w;
+};
+
+__host__ __device__ inline U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
+        U4 n;
+        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+        n.y = (uint32_t)p1;
+        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+        n.w = (uint32_t)p0;
+        c = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+__host__ __device__ inline U4 draw_block(uint64_t seed, uint32_t stream, uint32_t sweep, uint64_t iter, uint32_t entity,
+                                         uint32_t block) {
+    U4 c;
+    c.x = block;
+    c.y = entity;
+    c.z = (uint32_t)iter;
+    c.w = (stream << 24) | (sweep & 0xFFFFu);
+    return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// 53-bit uniform in [0,1), the resolution of Julia's rand(Float64)
+__host__ __device__ inline double u53(uint32_t lo, uint32_t hi) {
+    const uint64_t x = ((uint64_t)hi << 32) | lo;
+    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+__host__ __device__ inline uint32_t mulhi32(uint32_t x, uint32_t m) { return (uint32_t)(((uint64_t)x * m) >> 32); }
+__device__ inline uint64_t mulhi64(uint64_t x, uint64_t m) { return __umul64hi(x, m); }
+
+// StatsBase.samplepair: i1 = rand(1:m); i2 = rand(1:m-1); i2 == i1 ? m : i2
+__host__ __device__ inline void pick_pair(uint32_t r0, uint32_t r1, uint32_t m, uint32_t& i1, uint32_t& i2) {
+    i1 = mulhi32(r0, m);
+    uint32_t b = mulhi32(r1, m - 1);
+    if (b == i1) b = m - 1;
+    i2 = b;
+}
+// ordered 3-of-m without replacement (rank shift)
+__host__ __device__ inline void pick_triple(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t m, uint32_t& i1, uint32_t& i2,
+                                            uint32_t& i3) {
+    const uint32_t a = mulhi32(r0, m);
+    uint32_t b = mulhi32(r1, m - 1);
+    if (b >= a) ++b;
+    uint32_t c = mulhi32(r2, m - 2);
+    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+    if (c >= lo) ++c;
+    if (c >= hi) ++c;
+    i1 = a;
+    i2 = b;
+    i3 = c;
+}
+
+// ---- log-densities of the registered family (Distributions.jl forms) ----
+__device__ inline double norm_logpdf(double x, double m, double s) {
+    const double z = (x - m) / s;
+    return -(z * z + kLog2Pi) / 2.0 - log(s);
+}
+__device__ inline double Phi(double x) { return 0.5 * erfc(-x * kInvSqrt2); }
+__device__ inline double phi(double x) { return exp(-0.5 * x * x) * kInvSqrt2Pi; }
+__device__ inline double softplus(double x) { return x > 0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
+
+enum Prior : int { PR_FLAT = 0, PR_NORMAL = 1, PR_HALFCAUCHY = 2, PR_UNIFORM = 3, PR_BETA = 4, PR_NORMAL_REF = 5 };
+
+__device__ inline double prior_scalar(int kind, double a, double b, double sref, double x) {
+    switch (kind) {
+        case PR_NORMAL:
+            return norm_logpdf(x, a, b);
+        case PR_NORMAL_REF:
+            return norm_logpdf(x, a, sref);
+        case PR_HALFCAUCHY: {  // truncated(Cauchy(a,b),0,Inf)  Examples/Gaussian_Example.jl:14
+            if (x < 0.0) return -INFINITY;
+            const double z = (x - a) / b;
+            const double tp = 1.0 - (atan((0.0 - a) / b) / kPi + 0.5);
+            return -kLogPi - log(b) - log1p(z * z) - log(tp);
+        }
+        case PR_UNIFORM:
+            return (x >= a && x <= b) ? -log(b - a) : -INFINITY;
+        case PR_BETA: {
+            if (x < 0.0 || x > 1.0) return -INFINITY;
+            const double lbeta = lgamma(a) + lgamma(b) - lgamma(a + b);
+            const double t1 = (a == 1.0) ? 0.0 : (a - 1.0) * log(x);
+            const double t2 = (b == 1.0) ? 0.0 : (b - 1.0) * log1p(-x);
+            return t1 + t2 - lbeta;
+        }
+        default:
+            return 0.0;
+    }
+}
+
+// LBA (Examples/Run_LBA.jl:33-37; SequentialSamplingModels conventions: b = A + k, sigma = 1,
+// normalised by 1 - P(all drifts <= 0), density floored at 1e-10)
+__device__ inline double lba_dens(double v, double b, double A, double t) {
+    const double n1 = (b - A - t * v) / t, n2 = (b - t * v) / t;
+    return (1.0 / A) * (-v * Phi(n1) + phi(n1) + v * Phi(n2) - phi(n2));
+}
+__device__ inline double lba_cdf(double v, double b, double A, double t) {
+    const double n1 = (b - A - t * v) / t, n2 = (b - t * v) / t;
+    return 1.0 + ((b - A - t * v) / A) * Phi(n1) - ((b - t * v) / A) * Phi(n2) + (t / A) * phi(n1) - (t / A) * phi(n2);
+}
+
+}  // namespace demc

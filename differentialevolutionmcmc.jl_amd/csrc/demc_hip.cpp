@@ -1,0 +1,763 @@
+// demc_hip.cpp -- host runtime and C-ABI (include/demc.h) of libdemc_hip.so.
+//
+// The handle owns every device buffer (particles, proposals, partial sums, history, model data laid out
+// for the kernels) and one HIP stream; demc_step() enqueues, per iteration, the launch schedule that
+// step!/update!/block_update!/mutate_or_crossover! (main.jl:84-207) imply:
+//     [migration pack + apply]  then per sweep (block) and per colour phase:  K1 propose -> K2 loglike -> K3 accept/store
+// All per-iteration randomness is addressed by (seed, iteration, entity) inside the kernels, so the host
+// loop needs no device->host traffic: the only host-side draw is the alpha coin (pure function of seed, iter).
+//
+// There is NO CPU fallback in this file: every compute entry point launches HIP kernels or fails.
+#include "../../include/demc.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "demc_kernels.hpp"
+
+using namespace demc;
+
+namespace {
+
+struct Timed {
+    hipEvent_t a, b;
+    int cls;
+};
+
+}  // namespace
+
+struct demc_handle {
+    demc_config c{};
+    long long P = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // state
+    double *theta = nullptr, *weight = nullptr, *prop = nullptr, *prop_prior = nullptr, *prop_adj = nullptr;
+    double *tr_w = nullptr, *partial = nullptr, *aux = nullptr, *lo = nullptr, *hi = nullptr, *pa = nullptr, *pb = nullptr;
+    double *hist = nullptr, *lp_hist = nullptr, *mig_rows = nullptr, *scratch_theta = nullptr, *scratch_w = nullptr;
+    long long* id = nullptr;
+    unsigned char *prop_oob = nullptr, *tr_acc = nullptr, *masks = nullptr, *acc_hist = nullptr;
+    int *tr_idx = nullptr, *pk = nullptr, *pref = nullptr, *id_hist = nullptr;
+    // model
+    int family = -1;
+    long long N = 0;
+    int d = 0, n_acc = 0, dpad = 0;
+    int n_tiles = 0;
+    int ks_t = 0, n_kpass = 0;  // MFMA k-steps per pass (template) and passes over the dimensions
+    double *data = nullptr, *Ainv = nullptr, *Ypad = nullptr, *Xf = nullptr, *sx = nullptr;
+    size_t data2_off = 0;
+    double c0 = 0, c1 = 0, c2 = 0;
+    int partial_cap = 64;
+    int lpp = 1;
+    int tile_in_lds = 0;
+    size_t k1_lds = 0;
+    bool bounds_set = false, priors_set = false;
+    std::string err;
+    // timing
+    bool timing = false;
+    std::vector<Timed> events;
+    double t_ms[5] = {0, 0, 0, 0, 0};
+    long long t_n[5] = {0, 0, 0, 0, 0};
+};
+
+namespace {
+
+int fail(demc_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return fail(h, DEMC_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+    } while (0)
+
+template <typename T>
+int dev_alloc(demc_handle* h, T** p, size_t n) {
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+    if (e != hipSuccess) return fail(h, DEMC_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    e = hipMemset(*p, 0, n * sizeof(T));
+    if (e != hipSuccess) return fail(h, DEMC_EHIP, std::string("hipMemset: ") + hipGetErrorString(e));
+    return DEMC_OK;
+}
+#define ALLOC(ptr, n)                          \
+    do {                                       \
+        int rc_ = dev_alloc(h, &(ptr), (n));   \
+        if (rc_ != DEMC_OK) return rc_;        \
+    } while (0)
+
+void tick(demc_handle* h, int cls, bool begin) {
+    if (!h->timing) return;
+    if (begin) {
+        Timed t;
+        hipEventCreate(&t.a);
+        hipEventCreate(&t.b);
+        t.cls = cls;
+        hipEventRecord(t.a, h->stream);
+        h->events.push_back(t);
+    } else
+        hipEventRecord(h->events.back().b, h->stream);
+}
+
+void drain_events(demc_handle* h) {
+    for (auto& t : h->events) {
+        hipEventSynchronize(t.b);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, t.a, t.b);
+        h->t_ms[t.cls] += ms;
+        h->t_n[t.cls] += 1;
+        hipEventDestroy(t.a);
+        hipEventDestroy(t.b);
+    }
+    h->events.clear();
+}
+
+int pow2_ceil(int x) {
+    int p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+KParams base_params(demc_handle* h) {
+    KParams k;
+    std::memset(&k, 0, sizeof k);
+    const demc_config& c = h->c;
+    k.n_groups = c.n_groups; k.Np = c.Np; k.D = c.D; k.group_offset = c.group_offset;
+    k.a_lo = 0; k.n_act = c.Np; k.pool_lo = 0; k.pool_n = c.Np; k.exclude_self = 1;
+    k.lpp = h->lpp; k.mode = MODE_STEP;
+    k.iter = 0; k.burnin = c.burnin; k.sweep = 0; k.seed = c.seed;
+    k.beta = c.beta; k.eps = c.eps; k.sigma = c.sigma; k.kappa = c.kappa; k.theta_snooker = c.theta_snooker;
+    k.proposal_kind = c.proposal_kind; k.partner_kind = c.partner_kind; k.update_kind = c.update_kind;
+    k.fitness_kind = c.fitness_kind;
+    k.theta = h->theta; k.weight = h->weight; k.id = h->id; k.prop = h->prop; k.prop_prior = h->prop_prior;
+    k.prop_adj = h->prop_adj; k.prop_oob = h->prop_oob; k.tr_idx = h->tr_idx; k.tr_w = h->tr_w; k.tr_acc = h->tr_acc;
+    k.lo = h->lo; k.hi = h->hi; k.mask = nullptr; k.pk = h->pk; k.pa = h->pa; k.pb = h->pb; k.pref = h->pref;
+    k.hist = h->hist; k.acc_hist = h->acc_hist; k.lp_hist = h->lp_hist; k.id_hist = h->id_hist;
+    k.P = h->P; k.store_row = -1; k.tile_in_lds = h->tile_in_lds;
+    k.family = h->family; k.N = h->N; k.d = h->d; k.n_acc = h->n_acc; k.n_partials = 1;
+    k.partial = h->partial; k.aux = h->aux; k.data = h->data; k.data2 = h->data ? h->data + h->data2_off : nullptr;
+    k.c0 = h->c0; k.c1 = h->c1; k.c2 = h->c2;
+    return k;
+}
+
+template <int KS>
+void launch_cross(demc_handle* h, const KParams& k, int grid, int k0, int n_chunks, int part0) {
+    hipLaunchKernelGGL((k_cross_mfma<KS, 4>), dim3(grid), dim3(256), 0, h->stream, k, h->Ypad, h->dpad, k0, h->Xf,
+                       h->n_tiles, n_chunks, part0);
+}
+
+template <int DMAX>
+void launch_prep(demc_handle* h, const KParams& k, int grid, const double* Ainv, const double* sx) {
+    hipLaunchKernelGGL((k_mvn_prep<DMAX>), dim3(grid), dim3(256), 0, h->stream, k, Ainv, h->Ypad, h->dpad, sx);
+}
+
+// K2 dispatch for the active set described by k.  Sets k.n_partials.
+int launch_loglike(demc_handle* h, KParams& k) {
+    const long long n_prop = (long long)k.n_groups * k.n_act;
+    if (n_prop == 0) return DEMC_OK;
+    switch (h->family) {
+        case FAM_MVN_FULL:
+        case FAM_MVN_ISO: {
+            const bool suff = h->c.loglike_mode == DEMC_LOGLIKE_SUFFSTAT;
+            const double* Ainv = (h->family == FAM_MVN_FULL) ? h->Ainv : nullptr;
+            const double* sx = suff ? h->sx : nullptr;
+            const int grid = (int)((n_prop + 255) / 256);
+            const int dm = pow2_ceil(h->d < 4 ? 4 : h->d);
+            tick(h, 1, true);
+            if (dm <= 4) launch_prep<4>(h, k, grid, Ainv, sx);
+            else if (dm <= 8) launch_prep<8>(h, k, grid, Ainv, sx);
+            else if (dm <= 16) launch_prep<16>(h, k, grid, Ainv, sx);
+            else if (dm <= 32) launch_prep<32>(h, k, grid, Ainv, sx);
+            else launch_prep<64>(h, k, grid, Ainv, sx);
+            tick(h, 1, false);
+            k.n_partials = 1;
+            if (!suff) {
+                tick(h, 2, true);
+                // particle tiles of 256 (4 waves x MT=4 x 16) x observation chunks; chunks in multiples of 8 so that
+                // blockIdx % 8 (the XCD a block lands on) selects the chunk it streams
+                const long long n_ptiles = (n_prop + 255) / 256;
+                int n_chunks = 8;
+                while (n_ptiles * n_chunks < 1024 && n_chunks * 2 <= 32 && h->n_tiles / (n_chunks * 2) >= 16) n_chunks *= 2;
+                if (h->n_tiles < n_chunks) n_chunks = (int)(h->n_tiles > 0 ? h->n_tiles : 1);
+                const int n_kpass = h->n_kpass;
+                if (n_chunks * n_kpass > h->partial_cap) n_chunks = h->partial_cap / n_kpass;
+                if (n_chunks < 1) return fail(h, DEMC_EINVAL, "data dimension too large for the partial-sum workspace");
+                const int grid2 = (int)(n_ptiles * n_chunks);
+                for (int kp = 0; kp < n_kpass; ++kp) {
+                    const int ks_here = h->ks_t;
+                    const int k0 = kp * 4 * h->ks_t, part0 = kp * n_chunks;
+                    if (ks_here <= 1) launch_cross<1>(h, k, grid2, k0, n_chunks, part0);
+                    else if (ks_here <= 2) launch_cross<2>(h, k, grid2, k0, n_chunks, part0);
+                    else if (ks_here <= 4) launch_cross<4>(h, k, grid2, k0, n_chunks, part0);
+                    else if (ks_here <= 8) launch_cross<8>(h, k, grid2, k0, n_chunks, part0);
+                    else launch_cross<16>(h, k, grid2, k0, n_chunks, part0);
+                }
+                tick(h, 2, false);
+                k.n_partials = n_chunks * n_kpass;
+            }
+        } break;
+        case FAM_GAUSSIAN:
+        case FAM_BINOMIAL:
+        case FAM_LBA:
+        case FAM_LNR:
+        case FAM_RASTRIGIN: {
+            long long want = (262144 + n_prop - 1) / n_prop;
+            long long cap = h->N / 32;
+            if (cap < 1) cap = 1;
+            if (want > cap) want = cap;
+            if (want > h->partial_cap) want = h->partial_cap;
+            if (want < 1 || h->family == FAM_RASTRIGIN) want = 1;
+            const int n_chunks = (int)want;
+            tick(h, 2, true);
+            hipLaunchKernelGGL(k_obs_loglike, dim3((unsigned)((n_prop + 255) / 256), (unsigned)n_chunks), dim3(256), 0,
+                               h->stream, k, n_chunks);
+            tick(h, 2, false);
+            k.n_partials = n_chunks;
+        } break;
+        case FAM_HIER_BINOMIAL:
+        case FAM_HIER_GAUSSIAN: {
+            tick(h, 2, true);
+            hipLaunchKernelGGL(k_hier_loglike, dim3((unsigned)((n_prop + 3) / 4)), dim3(256), 0, h->stream, k);
+            tick(h, 2, false);
+            k.n_partials = 1;
+        } break;
+        default:
+            return fail(h, DEMC_EUNSUPPORTED, "model family not set or not registered");
+    }
+    return DEMC_OK;
+}
+
+int launch_phase(demc_handle* h, KParams& k) {
+    const long long n_prop = (long long)k.n_groups * k.n_act;
+    if (n_prop == 0) return DEMC_OK;
+    tick(h, 0, true);
+    hipLaunchKernelGGL(k_propose, dim3(k.n_groups), dim3(256), h->k1_lds, h->stream, k);
+    tick(h, 0, false);
+    int rc = launch_loglike(h, k);
+    if (rc != DEMC_OK) return rc;
+    tick(h, 3, true);
+    const int ppp = 256 / k.lpp;
+    hipLaunchKernelGGL(k_accept_store, dim3((unsigned)((n_prop + ppp - 1) / ppp)), dim3(256), 0, h->stream, k);
+    tick(h, 3, false);
+    return DEMC_OK;
+}
+
+// one sweep of every group: mutate_or_crossover! for all groups (main.jl:161-167, 199-207)
+int run_sweep(demc_handle* h, long long iter, unsigned sweep, const unsigned char* mask, long long store_row) {
+    const int Np = h->c.Np;
+    KParams k = base_params(h);
+    k.iter = iter; k.sweep = sweep; k.mask = mask; k.store_row = store_row;
+    if (h->c.schedule == DEMC_SCHED_TWO_COLOUR) {
+        const int half = Np / 2;
+        k.a_lo = 0; k.n_act = half; k.pool_lo = half; k.pool_n = Np - half; k.exclude_self = 0;
+        int rc = launch_phase(h, k);
+        if (rc != DEMC_OK) return rc;
+        k.a_lo = half; k.n_act = Np - half; k.pool_lo = 0; k.pool_n = half;
+        return launch_phase(h, k);
+    }
+    return launch_phase(h, k);
+}
+
+int migration_enqueue(demc_handle* h, long long iter, double* dev_rows, const double* dev_all_rows, bool pack, bool apply) {
+    KParams k = base_params(h);
+    k.iter = iter;
+    tick(h, 4, true);
+    if (pack)
+        hipLaunchKernelGGL(k_mig_pack, dim3(h->c.n_groups), dim3(256), 0, h->stream, k, dev_rows);
+    if (apply) {
+        const int ngt = h->c.n_groups_total;
+        const int grid = ngt < 64 ? ngt : 64;
+        hipLaunchKernelGGL(k_mig_apply, dim3(grid), dim3(256), sizeof(int) * (size_t)ngt, h->stream, k, dev_all_rows, ngt);
+    }
+    tick(h, 4, false);
+    return DEMC_OK;
+}
+
+int evaluate_rows(demc_handle* h, double* theta_dev, double* weight_dev) {
+    // init_particle: evaluate_fitness! on the current rows (utilities.jl:13-22) -- identity proposal, forced accept
+    KParams k = base_params(h);
+    k.mode = MODE_IDENT; k.theta = theta_dev; k.weight = weight_dev; k.store_row = -1; k.iter = 0;
+    k.tile_in_lds = 0;
+    return launch_phase(h, k);
+}
+
+bool chol_inv(const double* S, int d, std::vector<double>& Ainv, double& logdet) {
+    std::vector<double> L((size_t)d * d, 0.0), Li((size_t)d * d, 0.0);
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = S[i * d + j];
+            for (int k = 0; k < j; ++k) s -= L[i * d + k] * L[j * d + k];
+            if (i == j) {
+                if (!(s > 0.0)) return false;
+                L[i * d + i] = std::sqrt(s);
+            } else
+                L[i * d + j] = s / L[j * d + j];
+        }
+    logdet = 0.0;
+    for (int i = 0; i < d; ++i) logdet += 2.0 * std::log(L[i * d + i]);
+    for (int c = 0; c < d; ++c)  // Li = L^-1 by forward substitution on unit vectors
+        for (int i = 0; i < d; ++i) {
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int k = 0; k < i; ++k) s -= L[i * d + k] * Li[k * d + c];
+            Li[i * d + c] = s / L[i * d + i];
+        }
+    Ainv.assign((size_t)d * d, 0.0);
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < d; ++k) s += Li[k * d + i] * Li[k * d + j];
+            Ainv[i * d + j] = s;
+        }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t demc_version(void) { return DEMC_VERSION; }
+
+const char* demc_last_error(demc_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int32_t demc_create(const demc_config* cfg, demc_handle** out) {
+    if (!cfg || !out) return DEMC_EINVAL;
+    *out = nullptr;
+    demc_handle* h = new (std::nothrow) demc_handle();
+    if (!h) return DEMC_ENOMEM;
+    *out = h;  // returned even on failure so that demc_last_error() can be read; caller destroys it
+    h->c = *cfg;
+    demc_config& c = h->c;
+    if (c.n_groups < 1 || c.Np < 3 || c.D < 1 || c.n_rows < 0)
+        return fail(h, DEMC_EINVAL, "need n_groups >= 1, Np >= 3 (structs.jl:43), D >= 1, n_rows >= 0");
+    if (c.n_groups_total <= 0) c.n_groups_total = c.n_groups;
+    if (c.n_groups_total == 1) c.alpha = 0.0;  // structs.jl:102-105
+    if (c.schedule == DEMC_SCHED_SEQUENTIAL)
+        return fail(h, DEMC_EUNSUPPORTED, "sequential in-place sweep is the CPU reference schedule; use synchronous or two_colour");
+    if (c.schedule != DEMC_SCHED_SYNCHRONOUS && c.schedule != DEMC_SCHED_TWO_COLOUR)
+        return fail(h, DEMC_EINVAL, "unknown schedule");
+    if (c.schedule == DEMC_SCHED_TWO_COLOUR && c.partner_kind == DEMC_PARTNER_CURRENT) {
+        const int need = c.theta_snooker > 0.0 ? 6 : 4;
+        if (c.Np < need) return fail(h, DEMC_EINVAL, "two_colour needs Np >= 4 (>= 6 with snooker)");
+    }
+    if (c.proposal_kind < 0 || c.proposal_kind > 2 || c.partner_kind < 0 || c.partner_kind > 1 || c.update_kind < 0 ||
+        c.update_kind > 2 || c.fitness_kind < 0 || c.fitness_kind > 1)
+        return fail(h, DEMC_EUNSUPPORTED, "hook outside the registered set (structs.jl:71-74): no fallback");
+    if (c.partner_kind == DEMC_PARTNER_HISTORY && (!c.store_history || c.n_initial < 1))
+        return fail(h, DEMC_EINVAL, "history partners (resample) need store_history and n_initial > 0");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(h, DEMC_EHIP, "no HIP device visible");
+    HIPCHK(hipSetDevice(c.device_id));
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+    h->P = (long long)c.n_groups * c.Np;
+    const size_t P = (size_t)h->P, D = (size_t)c.D;
+    ALLOC(h->theta, P * D); ALLOC(h->weight, P); ALLOC(h->id, P); ALLOC(h->prop, P * D);
+    ALLOC(h->prop_prior, P); ALLOC(h->prop_adj, P); ALLOC(h->prop_oob, P);
+    ALLOC(h->tr_idx, P * 4); ALLOC(h->tr_w, P); ALLOC(h->tr_acc, P);
+    ALLOC(h->partial, (size_t)h->partial_cap * P); ALLOC(h->aux, P);
+    ALLOC(h->lo, D); ALLOC(h->hi, D); ALLOC(h->pk, D); ALLOC(h->pa, D); ALLOC(h->pb, D); ALLOC(h->pref, D);
+    ALLOC(h->mig_rows, (size_t)c.n_groups_total * (D + 3));
+    ALLOC(h->scratch_theta, P * D); ALLOC(h->scratch_w, P);
+    if (c.store_history && c.n_rows > 0) {
+        ALLOC(h->hist, (size_t)c.n_rows * P * D);
+        ALLOC(h->acc_hist, (size_t)c.n_rows * P);
+        ALLOC(h->lp_hist, (size_t)c.n_rows * P);
+        ALLOC(h->id_hist, (size_t)c.n_rows * P);
+    }
+    {
+        std::vector<double> lo(D, -INFINITY), hi(D, INFINITY);
+        HIPCHK(hipMemcpy(h->lo, lo.data(), D * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->hi, hi.data(), D * sizeof(double), hipMemcpyHostToDevice));
+        std::vector<long long> id(P);
+        for (size_t s = 0; s < P; ++s) id[s] = (long long)c.group_offset * c.Np + (long long)s;
+        HIPCHK(hipMemcpy(h->id, id.data(), P * sizeof(long long), hipMemcpyHostToDevice));
+        if (h->id_hist) {
+            std::vector<int> row(P);
+            for (size_t s = 0; s < P; ++s) row[s] = (int)id[s];
+            for (long long r = 0; r < c.n_rows; ++r)
+                HIPCHK(hipMemcpy(h->id_hist + (size_t)r * P, row.data(), P * sizeof(int), hipMemcpyHostToDevice));
+        }
+    }
+    // lanes per particle: every lane owns dim pairs {2k,2k+1}
+    h->lpp = pow2_ceil((c.D + 1) / 2);
+    if (h->lpp > 64) h->lpp = 64;
+    // K1 LDS: group tile (if it fits) + Np doubles for the select_base prefix sums
+    const size_t tile = (size_t)c.Np * D * sizeof(double), cdf = (size_t)c.Np * sizeof(double);
+    h->tile_in_lds = (tile + cdf <= 128 * 1024) ? 1 : 0;
+    h->k1_lds = (h->tile_in_lds ? tile : 0) + cdf;
+    HIPCHK(hipFuncSetAttribute((const void*)k_propose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k1_lds));
+    if ((size_t)c.n_groups_total * sizeof(int) > 48 * 1024) return fail(h, DEMC_EINVAL, "n_groups_total too large");
+    return DEMC_OK;
+}
+
+int32_t demc_destroy(demc_handle* h) {
+    if (!h) return DEMC_OK;
+    if (h->stream) hipStreamSynchronize(h->stream);
+    drain_events(h);
+    void* ptrs[] = {h->theta, h->weight, h->prop, h->prop_prior, h->prop_adj, h->tr_w, h->partial, h->aux, h->lo, h->hi,
+                    h->pa, h->pb, h->hist, h->lp_hist, h->mig_rows, h->scratch_theta, h->scratch_w, h->id, h->prop_oob,
+                    h->tr_acc, h->masks, h->acc_hist, h->tr_idx, h->pk, h->pref, h->id_hist, h->data, h->Ainv, h->Ypad,
+                    h->Xf, h->sx};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return DEMC_OK;
+}
+
+int32_t demc_set_stream(demc_handle* h, void* hip_stream) {
+    if (!h) return DEMC_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    h->own_stream = false;
+    if (hip_stream)
+        h->stream = (hipStream_t)hip_stream;
+    else {
+        HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->own_stream = true;
+    }
+    return DEMC_OK;
+}
+
+int32_t demc_set_model(demc_handle* h, int32_t family, const double* data, const int64_t* dims, int32_t ndims,
+                       const double* hyper, int32_t nhyper) {
+    if (!h) return DEMC_EINVAL;
+    if (ndims < 0 || ndims > 4 || (ndims > 0 && !dims)) return fail(h, DEMC_EINVAL, "bad dims");
+    long long dm[4] = {0, 0, 0, 0};
+    for (int i = 0; i < ndims; ++i) dm[i] = dims[i];
+    const int D = h->c.D;
+    for (double** p : {&h->data, &h->Ainv, &h->Ypad, &h->Xf, &h->sx})
+        if (*p) { hipFree(*p); *p = nullptr; }
+    h->family = -1; h->N = 0; h->d = 0; h->n_acc = 0; h->dpad = 0; h->n_tiles = 0; h->c0 = h->c1 = h->c2 = 0; h->data2_off = 0;
+    std::vector<double> dev;  // what goes to h->data
+    switch (family) {
+        case DEMC_FAM_GAUSSIAN:
+            if (D != 2 || dm[0] < 1) return fail(h, DEMC_EINVAL, "GAUSSIAN: theta=(mu,sigma), dims=[N]");
+            h->N = dm[0];
+            dev.assign(data, data + dm[0]);
+            break;
+        case DEMC_FAM_BINOMIAL: {
+            if (D != 1 || dm[0] < 1) return fail(h, DEMC_EINVAL, "BINOMIAL: theta=p, dims=[N], data=[n[N],k[N]]");
+            const long long N = dm[0];
+            h->N = N;
+            dev.assign(data, data + 2 * N);
+            dev.resize(3 * N);
+            for (long long i = 0; i < N; ++i) {
+                const double n = data[i], k = data[N + i];
+                dev[2 * N + i] = std::lgamma(n + 1.0) - std::lgamma(k + 1.0) - std::lgamma(n - k + 1.0);
+            }
+            h->data2_off = (size_t)N;
+        } break;
+        case DEMC_FAM_HIER_BINOMIAL: {
+            if (D != dm[0] + 2 || nhyper < 1) return fail(h, DEMC_EINVAL, "HIER_BINOMIAL: D=S+2, dims=[S], hyper=[n]");
+            const long long S = dm[0];
+            h->N = S;
+            h->c0 = hyper[0];
+            dev.assign(data, data + S);
+            dev.resize(2 * S);
+            for (long long s = 0; s < S; ++s) {
+                const double n = hyper[0], k = data[s];
+                dev[S + s] = std::lgamma(n + 1.0) - std::lgamma(k + 1.0) - std::lgamma(n - k + 1.0);
+            }
+        } break;
+        case DEMC_FAM_HIER_GAUSSIAN:
+            if (D != dm[0] + 3 || dm[1] < 1) return fail(h, DEMC_EINVAL, "HIER_GAUSSIAN: D=S+3, dims=[S,n]");
+            h->N = dm[0];
+            h->d = (int)dm[1];
+            dev.assign(data, data + dm[0] * dm[1]);
+            break;
+        case DEMC_FAM_LBA:
+        case DEMC_FAM_LNR: {
+            const int extra = (family == DEMC_FAM_LBA) ? 3 : 1;
+            if (dm[1] < 1 || dm[1] > 8 || D != dm[1] + extra) return fail(h, DEMC_EINVAL, "LBA/LNR: dims=[N,n_acc<=8]");
+            h->N = dm[0];
+            h->n_acc = (int)dm[1];
+            h->c0 = (family == DEMC_FAM_LNR) ? (nhyper > 0 ? hyper[0] : 1.0) : 0.0;
+            dev.assign(data, data + 2 * dm[0]);
+            h->data2_off = (size_t)dm[0];
+        } break;
+        case DEMC_FAM_RASTRIGIN:
+            h->N = 1;
+            break;
+        case DEMC_FAM_MVN_ISO:
+        case DEMC_FAM_MVN_FULL: {
+            const long long N = dm[0];
+            const int d = (int)dm[1];
+            if (N < 1 || d < 1) return fail(h, DEMC_EINVAL, "MVN: dims=[N,d]");
+            if (d > 64) return fail(h, DEMC_EUNSUPPORTED, "MVN families: data dimension d <= 64");
+            if (family == DEMC_FAM_MVN_ISO && D != d + 1) return fail(h, DEMC_EINVAL, "MVN_ISO: D=d+1");
+            if (family == DEMC_FAM_MVN_FULL && (D != d || nhyper != d * d)) return fail(h, DEMC_EINVAL, "MVN_FULL: D=d, hyper=Sigma[d][d]");
+            h->N = N;
+            h->d = d;
+            // k-steps of 4 dims: one pass of KS in {1,2,4,8,16} steps for d <= 64, else passes of 16 steps
+            if (d <= 64) { h->ks_t = pow2_ceil((d + 3) / 4); h->n_kpass = 1; }
+            else { h->ks_t = 16; h->n_kpass = (d + 63) / 64; }
+            h->dpad = 4 * h->ks_t * h->n_kpass;
+            if ((N + 15) / 16 > 0x3fffffff) return fail(h, DEMC_EINVAL, "too many observations");
+            h->n_tiles = (int)((N + 15) / 16);
+            std::vector<double> Ainv;
+            double logdet = 0.0;
+            if (family == DEMC_FAM_MVN_FULL) {
+                if (!chol_inv(hyper, d, Ainv, logdet)) return fail(h, DEMC_EINVAL, "Sigma is not positive definite");
+                h->c0 = -0.5 * (double)N * (d * kLog2Pi + logdet);
+                ALLOC(h->Ainv, (size_t)d * d);
+                HIPCHK(hipMemcpy(h->Ainv, Ainv.data(), sizeof(double) * d * d, hipMemcpyHostToDevice));
+            }
+            // data-only constants: c1 = sum_i x_i' A^-1 x_i (A = I for ISO), sx = sum_i x_i
+            std::vector<double> sx(d, 0.0), t(d);
+            double c1 = 0.0;
+            for (long long i = 0; i < N; ++i) {
+                const double* x = data + i * d;
+                double q = 0.0;
+                if (family == DEMC_FAM_MVN_FULL) {
+                    for (int r = 0; r < d; ++r) {
+                        double s = 0.0;
+                        for (int k = 0; k < d; ++k) s += Ainv[r * d + k] * x[k];
+                        q += x[r] * s;
+                    }
+                } else
+                    for (int k = 0; k < d; ++k) q += x[k] * x[k];
+                c1 += q;
+                for (int k = 0; k < d; ++k) sx[k] += x[k];
+            }
+            h->c1 = c1;
+            ALLOC(h->sx, (size_t)d);
+            HIPCHK(hipMemcpy(h->sx, sx.data(), sizeof(double) * d, hipMemcpyHostToDevice));
+            ALLOC(h->Ypad, (size_t)h->P * h->dpad);
+            // fragment-ordered copy of X for v_mfma_f64_16x16x4_f64's B operand:
+            //   Xf[tile][kstep][lane] = X[16*tile + (lane&15)][4*kstep + (lane>>4)], zero padded
+            const int ksx = h->dpad / 4;
+            std::vector<double> xf(((size_t)h->n_tiles + 1) * ksx * 64, 0.0);  // +1: the all-zero tail tile
+            for (long long tI = 0; tI < h->n_tiles; ++tI)
+                for (int ks = 0; ks < ksx; ++ks)
+                    for (int l = 0; l < 64; ++l) {
+                        const long long i = 16 * tI + (l & 15);
+                        const int k = 4 * ks + (l >> 4);
+                        if (i < N && k < d) xf[((size_t)tI * ksx + ks) * 64 + l] = data[i * d + k];
+                    }
+            ALLOC(h->Xf, xf.size());
+            HIPCHK(hipMemcpy(h->Xf, xf.data(), sizeof(double) * xf.size(), hipMemcpyHostToDevice));
+        } break;
+        default:
+            return fail(h, DEMC_EUNSUPPORTED, "model family is not registered; arbitrary closures cannot run on the device");
+    }
+    if (!dev.empty()) {
+        ALLOC(h->data, dev.size());
+        HIPCHK(hipMemcpy(h->data, dev.data(), sizeof(double) * dev.size(), hipMemcpyHostToDevice));
+    }
+    h->family = family;
+    return DEMC_OK;
+}
+
+int32_t demc_set_priors(demc_handle* h, const int32_t* kind, const double* a, const double* b, const int32_t* ref) {
+    if (!h || !kind) return DEMC_EINVAL;
+    const size_t D = (size_t)h->c.D;
+    std::vector<double> va(D, 0.0), vb(D, 1.0);
+    std::vector<int> vr(D, 0), vk(kind, kind + D);
+    for (size_t j = 0; j < D; ++j) {
+        if (vk[j] < 0 || vk[j] > DEMC_PRIOR_NORMAL_REF) return fail(h, DEMC_EUNSUPPORTED, "prior kind not registered");
+        if (a) va[j] = a[j];
+        if (b) vb[j] = b[j];
+        if (ref) vr[j] = ref[j];
+        if (vk[j] == DEMC_PRIOR_NORMAL_REF && (vr[j] < 0 || vr[j] >= (int)D)) return fail(h, DEMC_EINVAL, "prior ref out of range");
+    }
+    HIPCHK(hipMemcpy(h->pk, vk.data(), D * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->pa, va.data(), D * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->pb, vb.data(), D * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->pref, vr.data(), D * sizeof(int), hipMemcpyHostToDevice));
+    return DEMC_OK;
+}
+
+int32_t demc_set_bounds(demc_handle* h, const double* lo, const double* hi) {
+    if (!h || !lo || !hi) return DEMC_EINVAL;
+    const size_t D = (size_t)h->c.D;
+    HIPCHK(hipMemcpy(h->lo, lo, D * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->hi, hi, D * sizeof(double), hipMemcpyHostToDevice));
+    return DEMC_OK;
+}
+
+int32_t demc_set_blocks(demc_handle* h, const uint8_t* masks, int32_t n_blocks) {
+    if (!h || n_blocks < 0 || (n_blocks > 0 && !masks)) return DEMC_EINVAL;
+    if (h->masks) { hipFree(h->masks); h->masks = nullptr; }
+    h->c.n_blocks = n_blocks;
+    if (n_blocks > 0) {
+        ALLOC(h->masks, (size_t)n_blocks * h->c.D);
+        HIPCHK(hipMemcpy(h->masks, masks, (size_t)n_blocks * h->c.D, hipMemcpyHostToDevice));
+    }
+    return DEMC_OK;
+}
+
+int32_t demc_set_state(demc_handle* h, const double* theta, const double* weight, const int64_t* id) {
+    if (!h || !theta) return DEMC_EINVAL;
+    const size_t P = (size_t)h->P, D = (size_t)h->c.D;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->theta, theta, P * D * sizeof(double), hipMemcpyHostToDevice));
+    if (id) HIPCHK(hipMemcpy(h->id, id, P * sizeof(long long), hipMemcpyHostToDevice));
+    if (weight)
+        HIPCHK(hipMemcpy(h->weight, weight, P * sizeof(double), hipMemcpyHostToDevice));
+    else {
+        if (h->family < 0) return fail(h, DEMC_EINVAL, "demc_set_model before demc_set_state(weight = NULL)");
+        int rc = evaluate_rows(h, h->theta, h->weight);
+        if (rc != DEMC_OK) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipGetLastError());
+    }
+    return DEMC_OK;
+}
+
+int32_t demc_get_state(demc_handle* h, double* theta, double* weight, int64_t* id) {
+    if (!h) return DEMC_EINVAL;
+    const size_t P = (size_t)h->P, D = (size_t)h->c.D;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (theta) HIPCHK(hipMemcpy(theta, h->theta, P * D * sizeof(double), hipMemcpyDeviceToHost));
+    if (weight) HIPCHK(hipMemcpy(weight, h->weight, P * sizeof(double), hipMemcpyDeviceToHost));
+    if (id) HIPCHK(hipMemcpy(id, h->id, P * sizeof(long long), hipMemcpyDeviceToHost));
+    return DEMC_OK;
+}
+
+int32_t demc_set_history_rows(demc_handle* h, int64_t row0, int64_t nrows, const double* rows) {
+    if (!h || !rows) return DEMC_EINVAL;
+    if (!h->hist) return fail(h, DEMC_EINVAL, "history is not stored on this handle");
+    if (row0 < 0 || nrows < 0 || row0 + nrows > h->c.n_rows) return fail(h, DEMC_EINVAL, "history rows out of range");
+    const size_t PD = (size_t)h->P * h->c.D;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->hist + (size_t)row0 * PD, rows, (size_t)nrows * PD * sizeof(double), hipMemcpyHostToDevice));
+    return DEMC_OK;
+}
+
+int32_t demc_get_history(demc_handle* h, int64_t row0, int64_t row1, double* th, uint8_t* acc, double* lp, int64_t* idh) {
+    if (!h) return DEMC_EINVAL;
+    if (!h->hist) return fail(h, DEMC_EINVAL, "history is not stored on this handle");
+    if (row0 < 0 || row1 < row0 || row1 > h->c.n_rows) return fail(h, DEMC_EINVAL, "history rows out of range");
+    const size_t P = (size_t)h->P, D = (size_t)h->c.D, n = (size_t)(row1 - row0);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (th) HIPCHK(hipMemcpy(th, h->hist + (size_t)row0 * P * D, n * P * D * sizeof(double), hipMemcpyDeviceToHost));
+    if (acc) HIPCHK(hipMemcpy(acc, h->acc_hist + (size_t)row0 * P, n * P, hipMemcpyDeviceToHost));
+    if (lp) HIPCHK(hipMemcpy(lp, h->lp_hist + (size_t)row0 * P, n * P * sizeof(double), hipMemcpyDeviceToHost));
+    if (idh) {
+        std::vector<int> tmp(n * P);
+        HIPCHK(hipMemcpy(tmp.data(), h->id_hist + (size_t)row0 * P, n * P * sizeof(int), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n * P; ++i) idh[i] = tmp[i];
+    }
+    return DEMC_OK;
+}
+
+static int32_t step_impl(demc_handle* h, int64_t iter0, int32_t n_iters, bool with_migration) {
+    if (!h) return DEMC_EINVAL;
+    if (h->family < 0) return fail(h, DEMC_EINVAL, "demc_set_model has not been called");
+    if (iter0 < 1 || n_iters < 0) return fail(h, DEMC_EINVAL, "iter0 is 1-based (de.iter, main.jl:34)");
+    const demc_config& c = h->c;
+    if (c.partner_kind == DEMC_PARTNER_HISTORY && iter0 < 2)
+        return fail(h, DEMC_EINVAL, "history partners need at least one stored row (n_initial > 0)");
+    const int n_sweeps = c.n_blocks > 0 ? c.n_blocks : 1;  // block_update! main.jl:174-179
+    for (int64_t iter = iter0; iter < iter0 + n_iters; ++iter) {
+        if (with_migration && demc_migration_due(&c, iter)) {  // main.jl:85
+            if (c.n_groups_total != c.n_groups)
+                return fail(h, DEMC_EINVAL, "sharded handle: drive the exchange with demc_migration_pack/apply + demc_update");
+            migration_enqueue(h, iter, h->mig_rows, h->mig_rows, true, true);
+        }
+        for (int b = 0; b < n_sweeps; ++b) {
+            const unsigned char* mask = c.n_blocks > 0 ? h->masks + (size_t)b * c.D : nullptr;
+            const long long row = iter - 1;
+            const long long store_row = (b == n_sweeps - 1 && h->hist && row < c.n_rows) ? row : -1;
+            int rc = run_sweep(h, iter, (unsigned)b, mask, store_row);
+            if (rc != DEMC_OK) return rc;
+        }
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    return DEMC_OK;
+}
+
+int32_t demc_step(demc_handle* h, int64_t iter0, int32_t n_iters) { return step_impl(h, iter0, n_iters, true); }
+int32_t demc_update(demc_handle* h, int64_t iter0, int32_t n_iters) { return step_impl(h, iter0, n_iters, false); }
+
+int32_t demc_migration_due(const demc_config* cfg, int64_t iter) {
+    if (!cfg) return 0;
+    const int ngt = cfg->n_groups_total > 0 ? cfg->n_groups_total : cfg->n_groups;
+    const double alpha = ngt == 1 ? 0.0 : cfg->alpha;
+    const U4 r = draw_block(cfg->seed, S_STEP, 0, (uint64_t)iter, 0, 0);
+    return u53(r.x, r.y) <= alpha ? 1 : 0;
+}
+
+int32_t demc_migration_pack(demc_handle* h, int64_t iter, double* dev_rows) {
+    if (!h) return DEMC_EINVAL;
+    migration_enqueue(h, iter, dev_rows ? dev_rows : h->mig_rows, nullptr, true, false);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    return DEMC_OK;
+}
+
+int32_t demc_migration_apply(demc_handle* h, int64_t iter, const double* dev_all_rows) {
+    if (!h) return DEMC_EINVAL;
+    if (!dev_all_rows && h->c.n_groups_total != h->c.n_groups)
+        return fail(h, DEMC_EINVAL, "sharded handle needs the all-gathered rows");
+    migration_enqueue(h, iter, nullptr, dev_all_rows ? dev_all_rows : h->mig_rows, false, true);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    return DEMC_OK;
+}
+
+int32_t demc_logpost(demc_handle* h, const double* theta, int64_t n, double* out) {
+    if (!h || !theta || !out || n < 0) return DEMC_EINVAL;
+    if (h->family < 0) return fail(h, DEMC_EINVAL, "demc_set_model has not been called");
+    const size_t P = (size_t)h->P, D = (size_t)h->c.D;
+    std::vector<double> w(P);
+    for (int64_t off = 0; off < n; off += (int64_t)P) {
+        const size_t m = (size_t)((n - off < (int64_t)P) ? n - off : (int64_t)P);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemset(h->scratch_theta, 0, P * D * sizeof(double)));
+        HIPCHK(hipMemcpy(h->scratch_theta, theta + (size_t)off * D, m * D * sizeof(double), hipMemcpyHostToDevice));
+        int rc = evaluate_rows(h, h->scratch_theta, h->scratch_w);
+        if (rc != DEMC_OK) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(w.data(), h->scratch_w, P * sizeof(double), hipMemcpyDeviceToHost));
+        std::memcpy(out + off, w.data(), m * sizeof(double));
+    }
+    return DEMC_OK;
+}
+
+int32_t demc_get_trace(demc_handle* h, double* proposal, double* w_prop, double* log_adj, int32_t* idx, uint8_t* accepted) {
+    if (!h) return DEMC_EINVAL;
+    const size_t P = (size_t)h->P, D = (size_t)h->c.D;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (proposal) HIPCHK(hipMemcpy(proposal, h->prop, P * D * sizeof(double), hipMemcpyDeviceToHost));
+    if (w_prop) HIPCHK(hipMemcpy(w_prop, h->tr_w, P * sizeof(double), hipMemcpyDeviceToHost));
+    if (log_adj) HIPCHK(hipMemcpy(log_adj, h->prop_adj, P * sizeof(double), hipMemcpyDeviceToHost));
+    if (idx) HIPCHK(hipMemcpy(idx, h->tr_idx, P * 4 * sizeof(int), hipMemcpyDeviceToHost));
+    if (accepted) HIPCHK(hipMemcpy(accepted, h->tr_acc, P, hipMemcpyDeviceToHost));
+    return DEMC_OK;
+}
+
+int32_t demc_timing_enable(demc_handle* h, int32_t on) {
+    if (!h) return DEMC_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    drain_events(h);
+    h->timing = on != 0;
+    return DEMC_OK;
+}
+
+int32_t demc_timing_read(demc_handle* h, double* out10, int32_t reset) {
+    if (!h || !out10) return DEMC_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    drain_events(h);
+    for (int i = 0; i < 5; ++i) {
+        out10[i] = h->t_ms[i];
+        out10[5 + i] = (double)h->t_n[i];
+    }
+    if (reset)
+        for (int i = 0; i < 5; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
+    return DEMC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,788 @@
+// demc_kernels.hpp -- hand-written gfx950 kernels of the DE-MCMC hot path.
+//
+//   K1  k_propose        crossover!/snooker_update!/mutation!/recombination!/reset!/in_bounds + prior
+//                        (crossover.jl:30-99,154-257,301-352; mutation.jl:13-25; utilities.jl:70-78)
+//   K2  k_mvn_prep       y = A^-1 mu, a = mu.y for the MvNormal families (VALU)
+//       k_cross_mfma     S_p = sum_i y_p . x_i over all observations on v_mfma_f64_16x16x4_f64
+//       k_obs_loglike    thread-per-proposal streaming likelihoods (Gaussian, Binomial, LBA, LNR, rastrigin)
+//       k_hier_loglike   wave-per-proposal likelihoods whose cost is O(D) (hierarchical families)
+//   K3  k_accept_store   compute_posterior! finalisation + mh_update!/maximize!/minimize! + store_samples!
+//                        (utilities.jl:92-99,161-180,201-226)
+//   M   k_mig_pack / k_mig_apply   select_particle / select_groups + shift_particles! (migration.jl:31-91)
+//
+// Wave = 64 lanes everywhere.  A particle is handled by a power-of-two sub-group of LPP lanes
+// (LPP = lanes per particle, chosen on the host from D) so that rows of theta are read and written
+// as contiguous segments; every lane owns dims {2k, 2k+1} for k = sl, sl+LPP, ... which is also
+// the granularity of one Philox block (two 53-bit uniforms).
+#pragma once
+#include "demc_device.hpp"
+
+namespace demc {
+
+enum Family : int {
+    FAM_GAUSSIAN = 0, FAM_MVN_ISO = 1, FAM_MVN_FULL = 2, FAM_BINOMIAL = 3, FAM_HIER_BINOMIAL = 4,
+    FAM_HIER_GAUSSIAN = 5, FAM_LBA = 6, FAM_LNR = 7, FAM_RASTRIGIN = 8
+};
+enum Mode : int { MODE_STEP = 0, MODE_IDENT = 1 };  // IDENT: theta' = theta, always accepted (init / logpost)
+
+// Everything a sweep needs, passed by value as the kernarg.
+struct KParams {
+    // geometry
+    int n_groups, Np, D, group_offset;
+    int a_lo, n_act;                  // active particles of each group in this phase: [a_lo, a_lo+n_act)
+    int pool_lo, pool_n, exclude_self;  // partner pool of each group
+    int lpp;                          // lanes per particle
+    int mode;
+    // sampler
+    long long iter, burnin;
+    unsigned sweep;
+    unsigned long long seed;
+    double beta, eps, sigma, kappa, theta_snooker;
+    int proposal_kind, partner_kind, update_kind, fitness_kind;
+    // state
+    double* theta;        // [P][D]
+    double* weight;       // [P]
+    long long* id;        // [P]
+    double* prop;         // [P][D] proposals, by slot
+    double* prop_prior;   // [P]
+    double* prop_adj;     // [P]
+    unsigned char* prop_oob;  // [P]
+    int* tr_idx;          // [P][4]
+    double* tr_w;         // [P]
+    unsigned char* tr_acc;  // [P]
+    const double* lo;
+    const double* hi;
+    const unsigned char* mask;  // [D] or null
+    const int* pk;
+    const double* pa;
+    const double* pb;
+    const int* pref;
+    // history (slot keyed)
+    double* hist;             // [rows][P][D]
+    unsigned char* acc_hist;  // [rows][P]
+    double* lp_hist;          // [rows][P]
+    int* id_hist;             // [rows][P]
+    long long P;              // local particles
+    long long store_row;      // >= 0: K3 stores this history row
+    int tile_in_lds;          // K1: stage the group tile in LDS
+    // model
+    int family;
+    long long N;              // observations (or subjects)
+    int d;                    // data dimension
+    int n_acc;                // accumulators (LBA/LNR)
+    int n_partials;
+    double* partial;          // [n_partials][P]
+    double* aux;              // [P] per-proposal scalar (quadratic term)
+    const double* data;       // family specific
+    const double* data2;
+    double c0, c1, c2;        // family constants
+};
+
+// q-th active particle of the phase -> (group, particle-in-group, local slot); 32-bit on purpose (P < 2^31)
+__device__ inline int slot_of(const KParams& p, int q, int& g, int& pl) {
+    g = q / p.n_act;
+    pl = p.a_lo + (q - g * p.n_act);
+    return g * p.Np + pl;
+}
+__device__ inline int slot_of(const KParams& p, int q) {
+    int g, pl;
+    return slot_of(p, q, g, pl);
+}
+
+template <typename T>
+__device__ inline T subgroup_sum(T v, int lpp) {
+    for (int o = lpp >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: one workgroup per group.  Partner rows come from the group tile staged in LDS when it fits
+// (Np*D*8 bytes), else from theta in HBM/L2 -- either way a sweep-start snapshot, because theta is
+// only written by K3.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_propose(KParams p) {
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x;
+    const int g = blockIdx.x;
+    const int g_glob = p.group_offset + g;
+    const int D = p.D, Np = p.Np;
+    const double* grows = p.theta + (size_t)g * Np * D;
+    const double* gw = p.weight + (size_t)g * Np;
+    double* tile = lds;
+    double* cdf = lds + (p.tile_in_lds ? (size_t)Np * D : 0);
+    __shared__ double s_red[4];
+    __shared__ double s_total;
+
+    bool is_mut = false;
+    if (p.mode == MODE_STEP) {
+        const U4 r = draw_block(p.seed, S_GROUP, p.sweep, (uint64_t)p.iter, (uint32_t)g_glob, 0);
+        is_mut = u53(r.x, r.y) <= p.beta;  // mutate_or_crossover! main.jl:199-207
+    }
+    const bool de_any = (p.mode == MODE_STEP) && !is_mut;
+    const bool use_base = de_any && p.proposal_kind == 0 && p.iter <= p.burnin;  // crossover.jl:164
+
+    const double* rows = grows;
+    if (p.tile_in_lds && de_any && p.partner_kind == 0) {
+        for (int i = tid; i < Np * D; i += 256) tile[i] = grows[i];
+        rows = tile;
+    }
+    if (use_base) {
+        // select_base (crossover.jl:282-289), stabilised: e_j = exp(w_j - max w); sequential prefix sum so
+        // that the walk "first i with cumsum >= u*total" matches the CPU oracle exactly.
+        double m = -INFINITY;
+        for (int i = tid; i < Np; i += 256) m = fmax(m, gw[i]);
+        for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+        if ((tid & 63) == 0) s_red[tid >> 6] = m;
+        __syncthreads();
+        m = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+        for (int i = tid; i < Np; i += 256) cdf[i] = exp(gw[i] - m);
+        __syncthreads();
+        if (tid == 0) {
+            double c = 0.0;
+            for (int i = 0; i < Np; ++i) {
+                c += cdf[i];
+                cdf[i] = c;
+            }
+            s_total = c;
+        }
+    }
+    __syncthreads();
+
+    const int lpp = p.lpp;
+    const int ppp = 256 / lpp;  // particles per pass
+    const int sub = tid / lpp, sl = tid % lpp;
+    const int n_pass = (p.n_act + ppp - 1) / ppp;
+    const double eps = p.eps;
+
+    for (int pass = 0; pass < n_pass; ++pass) {
+        const int q = pass * ppp + sub;
+        const bool valid = q < p.n_act;
+        const int pl = p.a_lo + (valid ? q : 0);
+        const size_t slot = (size_t)g * Np + pl;
+        const uint32_t eslot = (uint32_t)g_glob * (uint32_t)Np + (uint32_t)pl;
+        const double* pt = rows + (size_t)pl * D;
+
+        int kind = 3;  // 0 DE, 1 snooker, 2 mutation, 3 identity
+        int i0 = -1, i1 = -1, i2 = -1;
+        const double *Pa = pt, *Pb2 = pt, *Pc = pt, *Pbase = pt;
+        double g1 = 0.0, g2 = 0.0, cm = 0.0, cn = 0.0;
+        bool base_on = false;
+        if (p.mode == MODE_STEP) {
+            if (is_mut)
+                kind = 2;
+            else {
+                const U4 r0 = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 0);
+                const U4 ri = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 1);
+                const U4 rg = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 2);
+                const double u_snk = u53(r0.x, r0.y), u_base = u53(r0.z, r0.w);
+                const double u_g1 = u53(rg.x, rg.y), u_g2 = u53(rg.z, rg.w);
+                const bool snooker = u_snk <= p.theta_snooker;  // crossover.jl:31
+                kind = snooker ? 1 : 0;
+                if (p.partner_kind == 1) {
+                    // resample (crossover.jl:113-124): distinct cells of rows 1:(iter-1) x local particles
+                    const U4 h4 = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 4);
+                    const U4 h5 = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 5);
+                    const uint64_t hd0 = ((uint64_t)h4.y << 32) | h4.x, hd1 = ((uint64_t)h4.w << 32) | h4.z,
+                                   hd2 = ((uint64_t)h5.y << 32) | h5.x;
+                    const uint64_t ub = (uint64_t)(p.iter - 1), M = ub * (uint64_t)p.P;
+                    uint64_t a = mulhi64(hd0, M), b = mulhi64(hd1, M - 1), c = 0;
+                    if (b >= a) ++b;
+                    if (snooker) {
+                        c = mulhi64(hd2, M - 2);
+                        const uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
+                        if (c >= lo) ++c;
+                        if (c >= hi) ++c;
+                    }
+                    Pa = p.hist + ((a % ub) * (uint64_t)p.P + a / ub) * (uint64_t)D;
+                    Pb2 = p.hist + ((b % ub) * (uint64_t)p.P + b / ub) * (uint64_t)D;
+                    Pc = p.hist + ((c % ub) * (uint64_t)p.P + c / ub) * (uint64_t)D;
+                    i0 = (int)(a & 0x7fffffff);
+                    i1 = (int)(b & 0x7fffffff);
+                    i2 = snooker ? (int)(c & 0x7fffffff) : -1;
+                } else if (snooker) {
+                    uint32_t a, b, c;  // snooker_update! draws 3 from the whole pool (crossover.jl:241)
+                    pick_triple(ri.x, ri.y, ri.z, (uint32_t)p.pool_n, a, b, c);
+                    a += p.pool_lo; b += p.pool_lo; c += p.pool_lo;
+                    Pa = rows + (size_t)a * D; Pb2 = rows + (size_t)b * D; Pc = rows + (size_t)c * D;
+                    i0 = (int)a; i1 = (int)b; i2 = (int)c;
+                } else {
+                    uint32_t a, b;
+                    if (p.exclude_self) {  // setdiff(group, [Pt]) crossover.jl:158
+                        pick_pair(ri.x, ri.y, (uint32_t)p.pool_n - 1, a, b);
+                        const uint32_t t = (uint32_t)(pl - p.pool_lo);
+                        a += (a >= t); b += (b >= t);
+                    } else
+                        pick_pair(ri.x, ri.y, (uint32_t)p.pool_n, a, b);
+                    a += p.pool_lo; b += p.pool_lo;
+                    Pa = rows + (size_t)a * D; Pb2 = rows + (size_t)b * D;
+                    i0 = (int)a; i1 = (int)b;
+                }
+                if (snooker) {
+                    g1 = 1.2 + (2.2 - 1.2) * u_g1;  // crossover.jl:249
+                    // project(Pm,Pd), project(Pn,Pd): dots over all scalars (utilities.jl:239-246)
+                    double vm = 0.0, vn = 0.0, vd = 0.0;
+                    for (int k = sl; 2 * k < D; k += lpp)
+                        for (int e = 0; e < 2; ++e) {
+                            const int j = 2 * k + e;
+                            if (j < D) {
+                                const double dj = pt[j] - Pa[j];
+                                vm += Pb2[j] * dj; vn += Pc[j] * dj; vd += dj * dj;
+                            }
+                        }
+                    vm = subgroup_sum(vm, lpp); vn = subgroup_sum(vn, lpp); vd = subgroup_sum(vd, lpp);
+                    cm = vm / vd; cn = vn / vd;
+                } else {
+                    if (p.proposal_kind == 0) {
+                        g1 = 0.5 + (1.0 - 0.5) * u_g1;  // crossover.jl:162
+                        if (use_base) {
+                            g2 = 0.5 + (1.0 - 0.5) * u_g2;
+                            const double total = s_total;
+                            int b;
+                            if (!(total > 0.0) || !(total < INFINITY)) {
+                                b = (int)(u_base * Np);
+                                b = b < Np ? b : Np - 1;
+                            } else {  // first i with cdf[i] >= t, else Np-1
+                                const double t = u_base * total;
+                                int lo = 0, hi = Np - 1;
+                                while (lo < hi) {
+                                    const int mid = (lo + hi) >> 1;
+                                    if (cdf[mid] >= t) hi = mid; else lo = mid + 1;
+                                }
+                                b = lo;
+                            }
+                            Pbase = rows + (size_t)b * D;
+                            i2 = b;
+                            base_on = true;
+                        }
+                    } else if (p.proposal_kind == 1)
+                        g1 = 2.38;  // crossover.jl:191
+                    else
+                        g1 = 2.38 / sqrt(2.0 * (double)D);  // crossover.jl:218
+                }
+            }
+        }
+
+        // proposal value of scalar j, after recombination! and reset!
+        auto value = [&](int j) -> double {
+            const double tj = pt[j];
+            if (kind == 3) return tj;
+            const int k = j >> 1;
+            const U4 nz = draw_block(p.seed, S_NOISE, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)k);
+            double v;
+            if (kind == 2) {  // pt + Normal(0, sigma): mutation.jl:15-18 (block mask ignored, main.jl:205)
+                const double u1 = u53(nz.x, nz.y), u2 = u53(nz.z, nz.w);
+                const double rad = sqrt(-2.0 * log(1.0 - u1));
+                double sn, cs;
+                sincos(2.0 * kPi * u2, &sn, &cs);
+                return tj + p.sigma * (rad * ((j & 1) ? sn : cs));
+            }
+            const double uu = (j & 1) ? u53(nz.z, nz.w) : u53(nz.x, nz.y);
+            const double bj = -eps + (eps - (-eps)) * uu;  // b = Uniform(-eps, eps) crossover.jl:166
+            if (kind == 1) {  // (Pt + gamma*(Pr1 - Pr2)) + b  crossover.jl:253
+                const double dj = tj - Pa[j];
+                const double t1 = dj * cm - dj * cn;
+                v = (tj + t1 * g1) + bj;
+            } else {  // ((Pt + g1*(Pm-Pn)) + g2*(Pb-Pt)) + b  crossover.jl:168
+                const double t1 = Pa[j] - Pb2[j];
+                double t6 = tj + t1 * g1;
+                if (base_on) {
+                    const double t4 = Pbase[j] - tj;
+                    t6 = t6 + t4 * g2;
+                }
+                v = t6 + bj;
+            }
+            if (p.kappa != 1.0) {  // recombination! crossover.jl:301-312
+                const U4 rc = draw_block(p.seed, S_RECOMB, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)k);
+                const double ur = (j & 1) ? u53(rc.z, rc.w) : u53(rc.x, rc.y);
+                if (ur <= 1.0 - p.kappa) v = tj;
+            }
+            if (p.mask && !p.mask[j]) v = tj;  // reset! crossover.jl:336-352
+            return v;
+        };
+
+        int oob = 0;
+        double prior = 0.0, s1 = 0.0, s2 = 0.0;
+        for (int k = sl; 2 * k < D; k += lpp)
+            for (int e = 0; e < 2; ++e) {
+                const int j = 2 * k + e;
+                if (j < D) {
+                    const double v = value(j);
+                    if (kind == 1) {  // adjust_loglike norms (crossover.jl:268-273)
+                        const double a = v - Pa[j], b = pt[j] - Pa[j];
+                        s1 += a * a; s2 += b * b;
+                    }
+                    oob |= !(v >= p.lo[j] && v <= p.hi[j]);  // in_bounds utilities.jl:70-78 (NaN fails)
+                    if (p.fitness_kind == 0) {
+                        const int pk = p.pk[j];
+                        if (pk != PR_FLAT) {
+                            const double sref = (pk == PR_NORMAL_REF) ? value(p.pref[j]) : 0.0;
+                            prior += prior_scalar(pk, p.pa[j], p.pb[j], sref, v);
+                        }
+                    }
+                    if (valid) p.prop[slot * D + j] = v;
+                }
+            }
+        prior = subgroup_sum(prior, lpp);
+        s1 = subgroup_sum(s1, lpp);
+        s2 = subgroup_sum(s2, lpp);
+        oob = subgroup_sum(oob, lpp);
+        if (sl == 0 && valid) {
+            p.prop_prior[slot] = prior;
+            p.prop_oob[slot] = oob ? 1 : 0;
+            // (d-1)(log|a| - log|b|): stable form of log(|a|^(d-1)/|b|^(d-1))  crossover.jl:268-273
+            p.prop_adj[slot] = (kind == 1) ? (double)(D - 1) * (0.5 * log(s1) - 0.5 * log(s2)) : 0.0;
+            p.tr_idx[slot * 4 + 0] = kind;
+            p.tr_idx[slot * 4 + 1] = i0;
+            p.tr_idx[slot * 4 + 2] = i1;
+            p.tr_idx[slot * 4 + 3] = i2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2a: MvNormal preparation.  y = A^-1 mu (FULL) or mu (ISO); a = mu . y.  One thread per proposal,
+// y kept in registers (DMAX compile-time), A^-1 read with wave-uniform (scalar) loads.
+// Ypad[slot][dpad] is zero padded to the MFMA k-step.
+// ------------------------------------------------------------------------------------------------
+template <int DMAX>
+__global__ __launch_bounds__(256) void k_mvn_prep(KParams p, const double* __restrict__ Ainv, double* __restrict__ Ypad,
+                                                  int dpad, const double* __restrict__ sx) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int n_prop = p.n_groups * p.n_act;
+    if (q >= n_prop) return;
+    const size_t slot = (size_t)slot_of(p, q);
+    const int d = p.d;
+    const double* mu = p.prop + slot * p.D;
+    double y[DMAX];
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c) y[c] = 0.0;
+    if (Ainv) {
+        for (int k = 0; k < d; ++k) {
+            const double mk = mu[k];
+#pragma unroll
+            for (int c = 0; c < DMAX; ++c)
+                if (c < d) y[c] += Ainv[(size_t)c * d + k] * mk;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < DMAX; ++c)
+            if (c < d) y[c] = mu[c];
+    }
+    double a = 0.0, s = 0.0;
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c)
+        if (c < d) {
+            a += mu[c] * y[c];
+            if (sx) s += y[c] * sx[c];
+        }
+    p.aux[slot] = a;
+    if (sx)
+        p.partial[slot] = s;  // SUFFSTAT: S = y . sum_i x_i, no pass over the data
+    else {
+#pragma unroll
+        for (int c = 0; c < DMAX; ++c)
+            if (c < dpad) Ypad[slot * dpad + c] = (c < d) ? y[c] : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2b: streaming cross term on the FP64 matrix cores.
+//   S[p] = sum_i sum_k Y[p][k] * X[i][k]
+// v_mfma_f64_16x16x4_f64: A = 16 particles x 4 dims (lane l: row l&15, k l>>4), B = 4 dims x 16
+// observations (lane l: k l>>4, col l&15), C/D 16x16, 4 doubles per lane (row (l>>4)+4r, col l&15).
+// A wave owns MT*16 particles whose Y fragments stay in registers for the whole pass; observations
+// stream through in tiles of 16 from a fragment-ordered copy of the data (Xf[tile][kstep][64 lanes],
+// one coalesced 512-byte load per k-step) and every tile accumulates into the SAME MT accumulators,
+// so the sum over observations happens inside the MFMA accumulate; the 16 columns are folded with
+// four shuffles at the end.  blockIdx -> (chunk = b % n_chunks, particle tile = b / n_chunks):
+// workgroups that share an XCD (b % 8) stream the same chunk(s) of X, so a chunk stays in that XCD's L2.
+// ------------------------------------------------------------------------------------------------
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+template <int KS, int MT>
+__global__ __launch_bounds__(256, 2) void k_cross_mfma(KParams p, const double* __restrict__ Ypad, int dpad, int k0,
+                                                       const double* __restrict__ Xf, int n_tiles, int n_chunks,
+                                                       int part0) {
+    // Xf holds n_tiles+1 tiles of (dpad/4) k-steps x 64 lanes; tile n_tiles is all zero and absorbs the odd tail.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunk = blockIdx.x % n_chunks;
+    const int ptile = blockIdx.x / n_chunks;
+    const int n_prop = p.n_groups * p.n_act;
+    const int q0 = (ptile * 4 + wave) * (MT * 16);
+    const int ksx = dpad >> 2;  // k-steps per tile in Xf (host pads so that k0/4 + KS <= ksx)
+
+    double a[MT][KS];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int q = q0 + mt * 16 + (lane & 15);
+        const bool ok = q < n_prop;
+        const size_t slot = ok ? (size_t)slot_of(p, q) : 0;
+        const double* yrow = Ypad + slot * dpad + k0 + (lane >> 4);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const double v = yrow[4 * ks];
+            a[mt][ks] = ok ? v : 0.0;
+        }
+    }
+    d4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    const int per = (n_tiles + n_chunks - 1) / n_chunks;
+    const int t0 = chunk * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
+    const size_t tstride = (size_t)ksx * 64;
+    const double* xb = Xf + (size_t)(k0 >> 2) * 64 + lane;
+    double b0[KS], b1[KS];
+    {
+        const double* x = xb + (size_t)(t0 < t1 ? t0 : n_tiles) * tstride;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) b0[ks] = x[ks * 64];
+    }
+    // two register sets in ping-pong: the loads of tile t+1 are in flight while tile t feeds the matrix core
+    for (int t = t0; t < t1; t += 2) {
+        {
+            const double* x = xb + (size_t)(t + 1 < t1 ? t + 1 : n_tiles) * tstride;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) b1[ks] = x[ks * 64];
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt][ks], b0[ks], acc[mt], 0, 0, 0);
+        {
+            const double* x = xb + (size_t)(t + 2 < t1 ? t + 2 : n_tiles) * tstride;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) b0[ks] = x[ks * 64];
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt][ks], b1[ks], acc[mt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double v = acc[mt][r];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 8);
+            const int q = q0 + mt * 16 + (lane >> 4) + 4 * r;
+            if ((lane & 15) == 0 && q < n_prop) p.partial[(size_t)(part0 + chunk) * p.P + slot_of(p, q)] = v;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2c: thread-per-proposal streaming likelihoods.  All lanes of a wave visit the same observation,
+// so data loads are wave-uniform (scalar) and the loop is pure FP64 VALU.  grid = (proposal blocks, chunks).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_obs_loglike(KParams p, int n_chunks) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int n_prop = p.n_groups * p.n_act;
+    const int chunk = blockIdx.y;
+    if (q >= n_prop) return;
+    const size_t slot = (size_t)slot_of(p, q);
+    const double* th = p.prop + slot * p.D;
+    const long long per = (p.N + n_chunks - 1) / n_chunks;
+    const long long i0 = chunk * per, i1 = (i0 + per < p.N) ? i0 + per : p.N;
+    double acc = 0.0;
+    switch (p.family) {
+        case FAM_GAUSSIAN: {  // sum_i ((x_i - mu)/sigma)^2   Gaussian_Example.jl:26-28
+            const double mu = th[0], sg = th[1];
+            for (long long i = i0; i < i1; ++i) {
+                const double z = (p.data[i] - mu) / sg;
+                acc += z * z;
+            }
+        } break;
+        case FAM_BINOMIAL: {  // binomial_tests.jl:15-17; data=[n], data2=[k], aux table in c-terms
+            const double pr = th[0];
+            const double lp = log(pr), l1p = log1p(-pr);
+            const double* lgc = p.data2 + p.N;
+            for (long long i = i0; i < i1; ++i) {
+                const double n = p.data[i], k = p.data2[i];
+                const double t1 = (k == 0.0) ? 0.0 : k * lp;
+                const double t2 = (n - k == 0.0) ? 0.0 : (n - k) * l1p;
+                acc += lgc[i] + t1 + t2;
+            }
+        } break;
+        case FAM_LBA: {  // Run_LBA.jl:33-37
+            const int na = p.n_acc;
+            double nu[8];
+            for (int a = 0; a < 8; ++a) nu[a] = a < na ? th[a] : 0.0;
+            const double A = th[na], kk = th[na + 1], tau = th[na + 2], b = A + kk;
+            double pneg = 1.0;
+            for (int a = 0; a < na; ++a) pneg *= Phi(-nu[a]);
+            const double inv = 1.0 / (1.0 - pneg);
+            for (long long i = i0; i < i1; ++i) {
+                const int c = (int)p.data[i];
+                const double rt = p.data2[i];
+                double ll;
+                if (rt < tau)
+                    ll = -INFINITY;
+                else {
+                    const double t = rt - tau;
+                    double den = 1.0;
+                    for (int a = 0; a < na; ++a)
+                        den *= (a + 1 == c) ? lba_dens(nu[a], b, A, t) : (1.0 - lba_cdf(nu[a], b, A, t));
+                    den *= inv;
+                    if (den != den)
+                        ll = -INFINITY;
+                    else
+                        ll = log(den < 1e-10 ? 1e-10 : den);
+                }
+                acc += ll;
+            }
+        } break;
+        case FAM_LNR: {  // lognormal_race_tests.jl:9-12
+            const int na = p.n_acc;
+            double nu[8];
+            for (int a = 0; a < 8; ++a) nu[a] = a < na ? th[a] : 0.0;
+            const double tau = th[na], sg = p.c0, lsg = log(sg);
+            for (long long i = i0; i < i1; ++i) {
+                const int c = (int)p.data[i];
+                const double t = p.data2[i] - tau;
+                double ll = 0.0;
+                if (!(t > 0.0))
+                    ll = -INFINITY;
+                else {
+                    const double lt = log(t);
+                    for (int a = 0; a < na; ++a) {
+                        const double z = (lt - nu[a]) / sg;
+                        ll += (a + 1 == c) ? (-(z * z + kLog2Pi) / 2.0 - lsg - lt) : log(0.5 * erfc(z * kInvSqrt2));
+                    }
+                }
+                acc += ll;
+            }
+        } break;
+        case FAM_RASTRIGIN: {  // optimization_tests.jl:15-23
+            if (chunk == 0) {
+                acc = 10.0 * p.D;
+                for (int j = 0; j < p.D; ++j) acc += th[j] * th[j] - 10.0 * cos(2.0 * kPi * th[j]);
+            }
+        } break;
+        default:
+            break;
+    }
+    p.partial[(size_t)chunk * p.P + slot] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2d: hierarchical families, cost O(D) per proposal: one wave per proposal, lanes across subjects,
+// coalesced reads of the proposal row, wave reduction (DPP shuffles).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hier_loglike(KParams p) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_prop = p.n_groups * p.n_act;
+    if (q >= n_prop) return;
+    const size_t slot = (size_t)slot_of(p, q);
+    const double* th = p.prop + slot * p.D;
+    const long long S = p.N;
+    double acc = 0.0;
+    if (p.family == FAM_HIER_BINOMIAL) {  // k_s ~ Binomial(n, logistic(mu_b0 + b0_s))  (BASELINE cfg4)
+        const double mu0 = th[0], n = p.c0;
+        const double* lgc = p.data + S;
+        for (long long s = lane; s < S; s += 64) {
+            const double eta = mu0 + th[2 + s], k = p.data[s];
+            acc += lgc[s] - k * softplus(-eta) - (n - k) * softplus(eta);
+        }
+    } else {  // FAM_HIER_GAUSSIAN  Hierarchical_Example.jl:36-44
+        const double mu0 = th[0], sg = th[2 + S];
+        const int n = p.d;
+        const double lsg = log(sg);
+        for (long long s = lane; s < S; s += 64) {
+            const double mu = mu0 + th[2 + s];
+            double l = 0.0;
+            for (int i = 0; i < n; ++i) {
+                const double z = (p.data[s * n + i] - mu) / sg;
+                l += -(z * z + kLog2Pi) / 2.0 - lsg;
+            }
+            acc += l;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) p.partial[slot] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: finalise the log-likelihood from the partial sums (fixed order -> deterministic), add the prior,
+// Metropolis accept with one uniform per particle, then move the accepted row into theta and write
+// the history row -- one pass over the particle's D scalars, LPP lanes per particle.
+// ------------------------------------------------------------------------------------------------
+__device__ inline double finalize_loglike(const KParams& p, size_t slot) {
+    double s = 0.0;
+    for (int c = 0; c < p.n_partials; ++c) s += p.partial[(size_t)c * p.P + slot];
+    switch (p.family) {
+        case FAM_MVN_FULL:  // c0 = -N/2 (d log2pi + logdet), c1 = sum_i x_i' A^-1 x_i
+            return p.c0 - 0.5 * (p.c1 - 2.0 * s + (double)p.N * p.aux[slot]);
+        case FAM_MVN_ISO: {  // c1 = sum_i |x_i|^2
+            const double sg = p.prop[slot * p.D + p.d];
+            const double nd = (double)p.N * (double)p.d;
+            return -0.5 * nd * kLog2Pi - nd * log(sg) - 0.5 * (p.c1 - 2.0 * s + (double)p.N * p.aux[slot]) / (sg * sg);
+        }
+        case FAM_GAUSSIAN: {
+            const double sg = p.prop[slot * p.D + 1];
+            return -0.5 * (s + (double)p.N * kLog2Pi) - (double)p.N * log(sg);
+        }
+        default:
+            return s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_accept_store(KParams p) {
+    const int tid = threadIdx.x;
+    const int lpp = p.lpp, ppp = 256 / lpp;
+    const int sub = tid / lpp, sl = tid % lpp;
+    const int n_prop = p.n_groups * p.n_act;
+    const int q = blockIdx.x * ppp + sub;
+    const bool valid = q < n_prop;
+    int g = 0, pl = 0;
+    const size_t slot = valid ? (size_t)slot_of(p, q, g, pl) : 0;
+    const int D = p.D;
+    int acc = 0;
+    double w_new = 0.0;
+    if (sl == 0 && valid) {
+        const double w = p.weight[slot];
+        const bool oob = p.prop_oob[slot] != 0;
+        double wp;
+        if (p.fitness_kind == 1)  // evaluate_fun! utilities.jl:113-120
+            wp = oob ? (p.update_kind == 1 ? -INFINITY : INFINITY) : finalize_loglike(p, slot);
+        else  // compute_posterior! utilities.jl:92-99
+            wp = oob ? -INFINITY : p.prop_prior[slot] + finalize_loglike(p, slot);
+        if (p.mode == MODE_IDENT)
+            acc = 1;
+        else if (p.update_kind == 1)
+            acc = wp > w;  // maximize! utilities.jl:212-218
+        else if (p.update_kind == 2)
+            acc = wp < w;  // minimize! utilities.jl:220-226
+        else {  // accept / mh_update! utilities.jl:55-58,201-210; min(1, NaN) = NaN -> reject
+            const uint32_t eslot = (uint32_t)(p.group_offset + g) * (uint32_t)p.Np + (uint32_t)pl;
+            const U4 r = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 3);
+            const double u = u53(r.x, r.y);
+            const double e = exp(wp - w + p.prop_adj[slot]);
+            acc = (e >= 1.0) || (u <= e);
+        }
+        w_new = acc ? wp : w;
+        if (acc) p.weight[slot] = wp;
+        p.tr_w[slot] = wp;
+        p.tr_acc[slot] = (unsigned char)acc;
+        if (p.store_row >= 0) {
+            const size_t hrow = (size_t)p.store_row * p.P + slot;
+            if (p.update_kind == 0 && p.mode == MODE_STEP) {  // utilities.jl:207-208
+                p.acc_hist[hrow] = (unsigned char)acc;
+                p.lp_hist[hrow] = w_new;
+            }
+            p.id_hist[hrow] = (int)p.id[slot];
+        }
+    }
+    acc = __shfl(acc, (tid & 63) & ~(lpp - 1));
+    if (!valid) return;
+    double* trow = p.theta + slot * D;
+    const double* prow = p.prop + slot * D;
+    double* hrow = (p.store_row >= 0) ? p.hist + ((size_t)p.store_row * p.P + slot) * D : nullptr;
+    if (!acc && !hrow) return;
+    for (int k = sl; 2 * k < D; k += lpp)
+        for (int e = 0; e < 2; ++e) {
+            const int j = 2 * k + e;
+            if (j < D) {
+                double v;
+                if (acc) {
+                    v = prow[j];
+                    trow[j] = v;  // current.theta = proposal.theta utilities.jl:204
+                } else
+                    v = trow[j];
+                if (hrow) hrow[j] = v;  // samples[iter, :, id] = theta utilities.jl:170-180
+            }
+        }
+}
+
+// history row for particles that were NOT active in the storing phase is never needed: every particle is
+// active exactly once per sweep, and the store happens in the phase that updates it.
+
+// ------------------------------------------------------------------------------------------------
+// Migration (migration.jl:11-91).  pack: one workgroup per local group picks its candidate
+// (select_particle: P(j) ~ exp(-(w_j - min w)); non-finite weights -> argmin, as findmin) and writes
+// the row (slot, theta[D], weight, id).  apply: every workgroup recomputes the group subset from the
+// shared Philox STEP stream (select_groups) and the i-th selected local group receives the candidate
+// of the (i-1)-th (circshift(particles, 1)).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mig_pack(KParams p, double* __restrict__ rows) {
+    extern __shared__ double lds[];
+    __shared__ int s_pick;
+    const int tid = threadIdx.x, g = blockIdx.x, Np = p.Np, D = p.D;
+    const double* gw = p.weight + (size_t)g * Np;
+    if (tid == 0) {
+        double wmin = INFINITY;
+        int amin = 0, bad = 0;
+        for (int i = 0; i < Np; ++i) {
+            const double w = gw[i];
+            if (!(w > -INFINITY && w < INFINITY)) bad = 1;
+            if (w < wmin) { wmin = w; amin = i; }
+        }
+        int pick = amin;
+        if (!bad) {
+            const U4 r = draw_block(p.seed, S_MIG, 0, (uint64_t)p.iter, (uint32_t)(p.group_offset + g), 0);
+            const double u = u53(r.x, r.y);
+            double total = 0.0;
+            for (int i = 0; i < Np; ++i) total += exp(wmin - gw[i]);
+            const double t = u * total;
+            int i = 0;
+            double cw = exp(wmin - gw[0]);
+            while (cw < t && i < Np - 1) {
+                ++i;
+                cw += exp(wmin - gw[i]);
+            }
+            pick = i;
+        }
+        s_pick = pick;
+    }
+    __syncthreads();
+    const int j = s_pick;
+    const size_t slot = (size_t)g * Np + j;
+    double* o = rows + (size_t)g * (D + 3);
+    if (tid == 0) {
+        o[0] = (double)j;
+        o[D + 1] = p.weight[slot];
+        o[D + 2] = (double)p.id[slot];
+    }
+    for (int k = tid; k < D; k += 256) o[1 + k] = p.theta[slot * D + k];
+}
+
+__global__ __launch_bounds__(256) void k_mig_apply(KParams p, const double* __restrict__ all_rows, int n_groups_total) {
+    extern __shared__ int perm[];  // [n_groups_total]
+    __shared__ int s_ns;
+    const int tid = threadIdx.x, D = p.D;
+    if (tid == 0) {  // select_groups migration.jl:31-35
+        const int ng = n_groups_total;
+        U4 r = draw_block(p.seed, S_STEP, 0, (uint64_t)p.iter, 0, 0);
+        const int ns = 2 + (int)mulhi32(r.z, (uint32_t)(ng - 1));
+        for (int i = 0; i < ng; ++i) perm[i] = i;
+        for (int i = 0; i < ns; ++i) {
+            if ((i & 3) == 0) r = draw_block(p.seed, S_STEP, 0, (uint64_t)p.iter, 0, 1 + (uint32_t)(i >> 2));
+            const uint32_t w = (i & 3) == 0 ? r.x : (i & 3) == 1 ? r.y : (i & 3) == 2 ? r.z : r.w;
+            const int j = i + (int)mulhi32(w, (uint32_t)(ng - i));
+            const int t = perm[i]; perm[i] = perm[j]; perm[j] = t;
+        }
+        s_ns = ns;
+    }
+    __syncthreads();
+    const int ns = s_ns;
+    for (int i = blockIdx.x; i < ns; i += gridDim.x) {
+        const int gd = perm[i], gs = perm[(i + ns - 1) % ns];  // shift_particles! migration.jl:84-91
+        const int gl = gd - p.group_offset;
+        if (gl < 0 || gl >= p.n_groups) continue;
+        const double* dst = all_rows + (size_t)gd * (D + 3);
+        const double* src = all_rows + (size_t)gs * (D + 3);
+        const size_t slot = (size_t)gl * p.Np + (size_t)dst[0];
+        for (int k = tid; k < D; k += 256) p.theta[slot * D + k] = src[1 + k];
+        if (tid == 0) {
+            p.weight[slot] = src[D + 1];
+            p.id[slot] = (long long)src[D + 2];
+        }
+    }
+}
+
+}  // namespace demc

@@ -1,0 +1,181 @@
+/*
+ * demc.h -- C-ABI of libdemc_hip.so: the MI355X (gfx950) DE-MCMC hot path.
+ *
+ * This is the drop-in boundary for ONE path of itsdfish/DifferentialEvolutionMCMC.jl
+ * (v0.7.10): the per-iteration particle update
+ *     proposal (crossover / snooker / mutation) -> prior + log-likelihood -> Metropolis accept
+ *     -> history store, plus the migration exchange,
+ * i.e. what `groups = stepfun(model, de, groups)` does once per iteration in
+ * src/main.jl:33-38 (step!/pstep!, src/main.jl:84-107).  A Julia maintainer binds these
+ * symbols with @ccall; the Python host in
+ * differentialevolutionmcmc.jl_amd/ binds them with ctypes.
+ *
+ * Conventions
+ *   - every function returns int32 status (DEMC_OK == 0); no C++ exception crosses the ABI;
+ *     demc_last_error(h) gives the message (valid until the next call on that handle);
+ *   - "host" pointers are caller-allocated, caller-owned and only borrowed for the call;
+ *     "dev" pointers are device (HBM) addresses on the handle's device, e.g. torch
+ *     tensor.data_ptr(); the library never returns pointers to its own memory;
+ *   - a handle is not thread-safe; one handle per GPU; calls enqueue on the handle's HIP
+ *     stream and (unless stated) return after the stream has drained;
+ *   - all arithmetic is IEEE double (the reference is Float64 throughout), ids int64,
+ *     flags uint8;
+ *   - particles are flattened: theta[P][D] row-major (particle-contiguous = Julia
+ *     Matrix{Float64}(D, P)), P = n_groups*Np, slot s = g*Np + p  (structs.jl:202-208,
+ *     main.jl:263-271).
+ */
+#ifndef DEMC_H
+#define DEMC_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DEMC_VERSION 100 /* 0.1.0 */
+
+enum {
+    DEMC_OK = 0,
+    DEMC_EINVAL = 1,       /* bad argument / inconsistent configuration */
+    DEMC_EHIP = 2,         /* HIP runtime error (message has hipGetErrorString) */
+    DEMC_ENOMEM = 3,
+    DEMC_ERCCL = 4,        /* reserved for a library-owned communicator */
+    DEMC_EUNSUPPORTED = 5  /* hook / model outside the registered family: no CPU fallback */
+};
+
+/* de.generate_proposal (structs.jl:71; crossover.jl:154-226) */
+enum { DEMC_PROPOSAL_RANDOM_GAMMA = 0, DEMC_PROPOSAL_FIXED_GAMMA = 1, DEMC_PROPOSAL_VARIABLE_GAMMA = 2 };
+/* de.sample (structs.jl:74): sample = current population (crossover.jl:138-140), resample = history (:113-121) */
+enum { DEMC_PARTNER_CURRENT = 0, DEMC_PARTNER_HISTORY = 1 };
+/* de.update_particle! (structs.jl:72): mh_update! / maximize! / minimize! (utilities.jl:201-226) */
+enum { DEMC_UPDATE_MH = 0, DEMC_UPDATE_MAXIMIZE = 1, DEMC_UPDATE_MINIMIZE = 2 };
+/* de.evaluate_fitness! (structs.jl:73): compute_posterior! / evaluate_fun! (utilities.jl:92-120) */
+enum { DEMC_FITNESS_POSTERIOR = 0, DEMC_FITNESS_FUN = 1 };
+/* Sweep schedule inside a group.  The reference sweeps particles one at a time in place
+ * (crossover.jl:13-15), which a fused kernel cannot do; the device schedules are
+ *   SYNCHRONOUS: all particles of a group propose from the sweep-start state;
+ *   TWO_COLOUR : the first half of the group proposes with partners from the second half,
+ *                then the halves swap (each half-update is a valid Metropolis-within-Gibbs step).
+ * DEMC_SCHED_SEQUENTIAL is defined for the CPU oracle only and is rejected here. */
+enum { DEMC_SCHED_SEQUENTIAL = 0, DEMC_SCHED_SYNCHRONOUS = 1, DEMC_SCHED_TWO_COLOUR = 2 };
+/* How Gaussian-family likelihoods are evaluated.
+ *   STREAMING : every proposal visits every observation, as model.loglike does
+ *               (structs.jl:186; test/multivariate_normal_tests.jl:31-33) -- FP64 MFMA bound;
+ *   SUFFSTAT  : one pass over the data at demc_set_model, O(D^2) per proposal -- HBM bound.
+ * Reported separately and labelled. */
+enum { DEMC_LOGLIKE_STREAMING = 0, DEMC_LOGLIKE_SUFFSTAT = 1 };
+
+/* Registered model family evaluated on device (user closures cannot run on the GPU). */
+enum {
+    DEMC_FAM_GAUSSIAN = 0,       /* theta=(mu,sigma); data x[N]; dims=[N]                 Examples/Gaussian_Example.jl:26-28 */
+    DEMC_FAM_MVN_ISO = 1,        /* theta=(mu[d],sigma); data X[N][d]; dims=[N,d]         test/multivariate_normal_tests.jl:31-33 */
+    DEMC_FAM_MVN_FULL = 2,       /* theta=mu[d]; data X[N][d]; dims=[N,d]; hyper=Sigma[d][d]   BASELINE cfg2/cfg3 */
+    DEMC_FAM_BINOMIAL = 3,       /* theta=p; data=[n[N], k[N]]; dims=[N]                  test/binomial_tests.jl:15-17 */
+    DEMC_FAM_HIER_BINOMIAL = 4,  /* theta=(mu_b0,sd_b0,b0[S]); data k[S]; dims=[S]; hyper=[n]  BASELINE cfg4 */
+    DEMC_FAM_HIER_GAUSSIAN = 5,  /* theta=(mu_b0,sd_b0,b0[S],sigma); data Y[S][n]; dims=[S,n]  Examples/Hierarchical_Example.jl:36-44 */
+    DEMC_FAM_LBA = 6,            /* theta=(nu[A],A,k,tau); data=[choice[N], rt[N]]; dims=[N,A] Examples/Run_LBA.jl:33-37 */
+    DEMC_FAM_LNR = 7,            /* theta=(nu[A],tau); data=[choice[N], rt[N]]; dims=[N,A]; hyper=[sigma] test/lognormal_race_tests.jl:9-12 */
+    DEMC_FAM_RASTRIGIN = 8       /* objective only; dims=[]                                test/optimization_tests.jl:15-23 */
+};
+
+/* Per-scalar prior table = the registered form of model.prior_loglike (structs.jl:185). */
+enum {
+    DEMC_PRIOR_FLAT = 0,
+    DEMC_PRIOR_NORMAL = 1,      /* Normal(a, b) */
+    DEMC_PRIOR_HALFCAUCHY = 2,  /* truncated(Cauchy(a, b), 0, Inf) */
+    DEMC_PRIOR_UNIFORM = 3,     /* Uniform(a, b) */
+    DEMC_PRIOR_BETA = 4,        /* Beta(a, b) */
+    DEMC_PRIOR_NORMAL_REF = 5   /* Normal(a, theta[ref]) */
+};
+
+/* POD mirror of the DE keyword constructor (structs.jl:80-131). */
+typedef struct demc_config {
+    int32_t n_groups;        /* groups owned by THIS handle (shard) */
+    int32_t Np;              /* particles per group */
+    int32_t D;               /* scalar parameters after flattening nested Theta */
+    int32_t n_blocks;        /* 0: blocking_on(de) == false */
+    int64_t burnin;
+    int64_t n_initial;
+    int64_t n_rows;          /* history rows = n_iter + n_initial (utilities.jl:29-34) */
+    double alpha;            /* migration probability      (main.jl:85)      */
+    double beta;             /* mutation probability       (main.jl:200)     */
+    double eps;              /* crossover noise            (crossover.jl:166)*/
+    double sigma;            /* mutation sd                (mutation.jl:15)  */
+    double kappa;            /* recombination              (crossover.jl:302)*/
+    double theta_snooker;    /* snooker probability        (crossover.jl:31) */
+    int32_t proposal_kind;
+    int32_t partner_kind;
+    int32_t update_kind;
+    int32_t fitness_kind;
+    int32_t schedule;
+    int32_t store_history;   /* 1: keep samples/accept/lp history on device (utilities.jl:161-180) */
+    int32_t group_offset;    /* global index of this shard's first group */
+    int32_t n_groups_total;  /* groups over all shards (0 -> n_groups) */
+    uint64_t seed;           /* Philox key */
+    int32_t device_id;
+    int32_t loglike_mode;
+} demc_config;
+
+typedef struct demc_handle demc_handle;
+
+int32_t demc_version(void);
+int32_t demc_create(const demc_config* cfg, demc_handle** out);
+int32_t demc_destroy(demc_handle* h);
+const char* demc_last_error(demc_handle* h);
+/* Enqueue on an existing HIP stream (hipStream_t passed as void*; NULL -> the handle's own stream). */
+int32_t demc_set_stream(demc_handle* h, void* hip_stream);
+
+/* replaces the closure pair built by DEModel(...) (structs.jl:176-189) */
+int32_t demc_set_model(demc_handle* h, int32_t family, const double* host_data, const int64_t* dims, int32_t ndims,
+                       const double* host_hyper, int32_t nhyper);
+int32_t demc_set_priors(demc_handle* h, const int32_t* kind, const double* a, const double* b, const int32_t* ref);
+/* de.bounds flattened to one (lo,hi) per scalar; +-Inf allowed (utilities.jl:70-78) */
+int32_t demc_set_bounds(demc_handle* h, const double* lo, const double* hi);
+/* de.blocks flattened to n_blocks x D byte masks (crossover.jl:336-352) */
+int32_t demc_set_blocks(demc_handle* h, const uint8_t* masks, int32_t n_blocks);
+
+/* sample_init (main.jl:263-271): particles as flat rows; weight == NULL -> evaluate_fitness! on device
+ * (utilities.jl:19); id == NULL -> group_offset*Np + slot. */
+int32_t demc_set_state(demc_handle* h, const double* theta, const double* weight, const int64_t* id);
+int32_t demc_get_state(demc_handle* h, double* theta, double* weight, int64_t* id);
+/* initialize_samples (utilities.jl:35-39): prior draws for history rows [row0, row0+nrows), [nrows][P][D] by slot */
+int32_t demc_set_history_rows(demc_handle* h, int64_t row0, int64_t nrows, const double* theta_rows);
+/* Raw history rows [row0,row1), keyed by SLOT, plus the particle id that occupied the slot at that
+ * row; the host re-keys by id (samples[iter, :, p.id], utilities.jl:170-180).  Any output may be NULL. */
+int32_t demc_get_history(demc_handle* h, int64_t row0, int64_t row1, double* theta_hist, uint8_t* accept_hist,
+                         double* lp_hist, int64_t* id_hist);
+
+/* n_iters of step!/pstep! (main.jl:84-107) starting at de.iter == iter0 (1-based, n_initial included):
+ * migration coin + exchange (single shard only), update of every group, store. */
+int32_t demc_step(demc_handle* h, int64_t iter0, int32_t n_iters);
+/* update! + store_samples! only (main.jl:86-87): for drivers that run the migration exchange themselves */
+int32_t demc_update(demc_handle* h, int64_t iter0, int32_t n_iters);
+
+/* migration! (migration.jl:11-19) in two halves around the one exchange.
+ * demc_migration_due : the alpha coin of iteration `iter` (main.jl:85) -- pure function of (seed, iter).
+ * demc_migration_pack: select_particle for each local group (migration.jl:64-70); writes
+ *                      [n_groups][D+3] doubles (slot, theta[D], weight, id) to dev_rows.
+ * demc_migration_apply: select_groups + shift_particles! (migration.jl:31-35, :84-91) given the rows of ALL
+ *                      groups [n_groups_total][D+3] (after an all-gather); only local groups are written. */
+int32_t demc_migration_due(const demc_config* cfg, int64_t iter);
+int32_t demc_migration_pack(demc_handle* h, int64_t iter, double* dev_rows);
+int32_t demc_migration_apply(demc_handle* h, int64_t iter, const double* dev_all_rows);
+
+/* compute_posterior! / evaluate_fun! for n arbitrary host rows [n][D] (utilities.jl:92-120) */
+int32_t demc_logpost(demc_handle* h, const double* theta, int64_t n, double* out);
+
+/* Test/diagnostic mode: the last sweep's proposals, proposal weights, snooker adjustments,
+ * partner indices [P][4] = (kind 0 DE / 1 snooker / 2 mutation, i0, i1, i2) and accept flags. */
+int32_t demc_get_trace(demc_handle* h, double* proposal, double* w_prop, double* log_adj, int32_t* idx,
+                       uint8_t* accepted);
+
+/* Device time (ms) spent in each kernel class since the last reset, measured with HIP events on the handle's
+ * stream when timing is enabled: out[0]=propose (K1), [1]=likelihood preparation, [2]=main likelihood kernel (K2),
+ * [3]=accept/store (K3), [4]=migration; the number of timed launch groups of each class in out[5..9]. */
+int32_t demc_timing_enable(demc_handle* h, int32_t on);
+int32_t demc_timing_read(demc_handle* h, double* out10, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -943,8 +943,11 @@ static int decide(const orc_handle* h, int64_t iter, uint32_t sweep, uint32_t sl
     uint32_t r[4];
     draw_block(h->c.seed, S_PART, sweep, (uint64_t)iter, slot, 3, r);
     const double u = orc_u53(r[0], r[1]);
-    const double pr = fmin(1.0, exp(w_prop - w_cur + adj)); /* NaN propagates -> reject */
-    return u <= pr;
+    /* p = min(1, exp(..)) with Julia's NaN-propagating min: NaN -> `rand() <= NaN` is false -> reject.
+     * (C's fmin would drop the NaN, so spell it out.) */
+    const double e = exp(w_prop - w_cur + adj);
+    if (e >= 1.0) return 1;
+    return u <= e;
 }
 
 static void sweep_group(orc_handle* h, int64_t iter, uint32_t sweep, int32_t g, const uint8_t* mask, double* snap_rows,
@@ -1067,7 +1070,11 @@ int orc_migration_apply(orc_handle* h, int64_t iter, const double* all_rows) {
 
 /* ------------------------------------------------------------------ step ------ */
 /* step!/pstep! main.jl:84-107 */
-int orc_step(orc_handle* h, int64_t iter0, int32_t n_iters) {
+static int step_impl(orc_handle* h, int64_t iter0, int32_t n_iters, int with_migration);
+int orc_step(orc_handle* h, int64_t iter0, int32_t n_iters) { return step_impl(h, iter0, n_iters, 1); }
+/* update! + store_samples! only (main.jl:86-87), for a driver that runs the exchange itself */
+int orc_update(orc_handle* h, int64_t iter0, int32_t n_iters) { return step_impl(h, iter0, n_iters, 0); }
+static int step_impl(orc_handle* h, int64_t iter0, int32_t n_iters, int with_migration) {
     if (!h || h->family < 0) return ORC_EINVAL;
     const int D = h->c.D, Np = h->c.Np;
     const int nthreads = h->c.n_threads > 0 ? h->c.n_threads : 1;
@@ -1076,7 +1083,7 @@ int orc_step(orc_handle* h, int64_t iter0, int32_t n_iters) {
     for (int64_t iter = iter0; iter < iter0 + n_iters; ++iter) {
         if (h->c.partner_kind == ORC_PARTNER_HISTORY && (iter < 2 || !h->hist))
             return fail(h, ORC_EINVAL, "history partners need n_initial > 0 and stored history");
-        if (orc_migration_due(&h->c, iter)) { /* main.jl:85 */
+        if (with_migration && orc_migration_due(&h->c, iter)) { /* main.jl:85 */
             if (h->c.n_groups_total != h->c.n_groups)
                 return fail(h, ORC_EINVAL, "sharded handle: drive migration with pack/apply");
             double* rows = (double*)malloc(sizeof(double) * (size_t)h->c.n_groups * (D + 3));

@@ -65,6 +65,7 @@ def lib():
         L.orc_set_history_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int64, _dp]
         L.orc_get_history.argtypes = [C.c_void_p, C.c_int64, C.c_int64, _dp, _bp, _dp, _lp]
         L.orc_step.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
+        L.orc_update.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
         L.orc_logpost.argtypes = [C.c_void_p, _dp, C.c_int64, _dp]
         L.orc_loglike.argtypes = [C.c_void_p, _dp, C.c_int64, _dp]
         L.orc_prior.argtypes = [C.c_void_p, _dp, C.c_int64, _dp]
@@ -193,6 +194,9 @@ class Oracle:
 
     def step(self, iter0, n_iters=1):
         self._ck(self.L.orc_step(self.h, iter0, n_iters))
+
+    def update(self, iter0, n_iters=1):
+        self._ck(self.L.orc_update(self.h, iter0, n_iters))
 
     def logpost(self, theta):
         theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(-1, self.D)

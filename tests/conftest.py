@@ -1,0 +1,101 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from oracle import oracle as O
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def demc():
+    import demc_amd
+    return demc_amd
+
+
+def make_problem(family, rng, **kw):
+    """Synthetic model spec shared by the oracle and the HIP engine: dict(family, data, dims, hyper, D, priors, bounds, theta0(P))."""
+    from demc_amd import families as F
+    inf = np.inf
+    if family == "gaussian":
+        N = kw.get("N", 50)
+        data = rng.normal(0.3, 1.2, N)
+        return dict(fam=F.FAM_GAUSSIAN, data=data, dims=[N], hyper=None, D=2, pk=[1, 2], pa=[0, 0], pb=[10, 1], pref=[0, 0],
+                    lo=[-inf, 0], hi=[inf, inf],
+                    init=lambda P: np.stack([rng.normal(0, 1, P), np.abs(rng.standard_cauchy(P)) + 0.3], 1))
+    if family == "binomial":
+        N = kw.get("N", 5)
+        n = rng.integers(5, 20, N).astype(float)
+        k = np.floor(n * rng.uniform(0.2, 0.8, N))
+        return dict(fam=F.FAM_BINOMIAL, data=np.concatenate([n, k]), dims=[N], hyper=None, D=1, pk=[4], pa=[1.0], pb=[1.0],
+                    pref=[0], lo=[0], hi=[1], init=lambda P: rng.uniform(0.05, 0.95, (P, 1)))
+    if family == "mvn_iso":
+        N, d = kw.get("N", 100), kw.get("d", 5)
+        X = rng.normal(0, 1, (N, d)) + rng.normal(0, 1, d)
+        return dict(fam=F.FAM_MVN_ISO, data=X, dims=[N, d], hyper=None, D=d + 1, pk=[1] * d + [2], pa=[0] * (d + 1),
+                    pb=[1] * (d + 1), pref=[0] * (d + 1), lo=[-inf] * d + [0], hi=[inf] * (d + 1),
+                    init=lambda P: np.concatenate([rng.normal(0, 1, (P, d)), np.abs(rng.standard_cauchy((P, 1))) + 0.5], 1))
+    if family == "mvn_full":
+        N, d = kw.get("N", 200), kw.get("d", 8)
+        A = rng.normal(0, 1, (d, d))
+        Sigma = A @ A.T / d + 0.5 * np.eye(d)
+        mu = rng.normal(0, 1, d)
+        X = rng.multivariate_normal(mu, Sigma, N)
+        return dict(fam=F.FAM_MVN_FULL, data=X, dims=[N, d], hyper=Sigma, D=d, pk=[1] * d, pa=[0] * d, pb=[1] * d,
+                    pref=[0] * d, lo=[-inf] * d, hi=[inf] * d, init=lambda P: rng.normal(0, 1, (P, d)), mu=mu, Sigma=Sigma)
+    if family == "hier_binomial":
+        S, n = kw.get("S", 40), 50.0
+        b0 = rng.normal(0, 1, S)
+        k = rng.binomial(int(n), 1 / (1 + np.exp(-(1.0 + b0)))).astype(float)
+        D = S + 2
+        return dict(fam=F.FAM_HIER_BINOMIAL, data=k, dims=[S], hyper=[n], D=D, pk=[1, 2] + [5] * S, pa=[1, 0] + [0] * S,
+                    pb=[1, 1] + [1] * S, pref=[0, 0] + [1] * S, lo=[-inf, 0] + [-inf] * S, hi=[inf] * D,
+                    init=lambda P: np.concatenate([rng.normal(1, 1, (P, 1)), np.abs(rng.standard_cauchy((P, 1))) + 0.3,
+                                                   rng.normal(0, 1, (P, S))], 1))
+    if family == "hier_gaussian":
+        S, n = kw.get("S", 12), kw.get("n", 7)
+        b0 = rng.normal(0, 1, S)
+        Y = 1.0 + b0[:, None] + rng.normal(0, 0.5, (S, n))
+        D = S + 3
+        return dict(fam=F.FAM_HIER_GAUSSIAN, data=Y, dims=[S, n], hyper=None, D=D, pk=[1, 2] + [5] * S + [2],
+                    pa=[1, 0] + [0] * S + [0], pb=[1, 1] + [1] * S + [1], pref=[0, 0] + [1] * S + [0],
+                    lo=[-inf, 0] + [-inf] * S + [0], hi=[inf] * D,
+                    init=lambda P: np.concatenate([rng.normal(1, 1, (P, 1)), np.abs(rng.standard_cauchy((P, 1))) + 0.3,
+                                                   rng.normal(0, 1, (P, S)), np.abs(rng.standard_cauchy((P, 1))) + 0.3], 1))
+    if family in ("lba", "lnr"):
+        N, na = kw.get("N", 60), kw.get("na", 3)
+        choice = rng.integers(1, na + 1, N).astype(float)
+        rt = rng.uniform(0.45, 1.6, N)
+        min_rt = rt.min()
+        data = np.concatenate([choice, rt])
+        if family == "lba":
+            D = na + 3
+            return dict(fam=F.FAM_LBA, data=data, dims=[N, na], hyper=None, D=D, pk=[1] * na + [1, 1, 3],
+                        pa=[1] * na + [0.8, 0.2, 0.0], pb=[5] * na + [0.2, 0.1, min_rt], pref=[0] * D,
+                        lo=[0] * D, hi=[inf] * (D - 1) + [min_rt],
+                        init=lambda P: np.concatenate([rng.uniform(0.5, 4, (P, na)), rng.uniform(0.5, 1.1, (P, 1)),
+                                                       rng.uniform(0.05, 0.4, (P, 1)), rng.uniform(0.05, min_rt * 0.9, (P, 1))], 1))
+        D = na + 1
+        return dict(fam=F.FAM_LNR, data=data, dims=[N, na], hyper=[1.0], D=D, pk=[1] * na + [3], pa=[0] * na + [0.0],
+                    pb=[3] * na + [min_rt], pref=[0] * D, lo=[-inf] * na + [0], hi=[inf] * na + [min_rt],
+                    init=lambda P: np.concatenate([rng.normal(-1, 1, (P, na)), rng.uniform(0.05, min_rt * 0.9, (P, 1))], 1))
+    raise KeyError(family)
+
+
+def setup_engine(eng, prob):
+    eng.set_model(prob["fam"], prob["data"], prob["dims"], prob["hyper"])
+    eng.set_priors(prob["pk"], prob["pa"], prob["pb"], prob["pref"])
+    eng.set_bounds(prob["lo"], prob["hi"])
