@@ -1,0 +1,70 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/demc.h declares; the Python binding,
+the oracle's mirror struct and the header agree on the config layout.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = open(os.path.join(ROOT, "include", "demc.h")).read()
+
+
+def declared_functions():
+    body = re.sub(r"/\*.*?\*/", "", HEADER, flags=re.S)
+    return sorted(set(re.findall(r"\b(demc_[a-z_0-9]+)\s*\(", body)))
+
+
+def test_library_exports_every_declared_symbol(demc):
+    lib = demc._ffi.load()
+    names = declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/demc.h but not exported by libdemc_hip.so"
+    assert sorted(demc._ffi.EXPORTS) == names, "the Python binding must bind exactly the header's entry points"
+    assert lib.demc_version() == int(re.search(r"#define DEMC_VERSION (\d+)", HEADER).group(1))
+
+
+def test_config_struct_matches_header(demc, orc):
+    m = re.search(r"typedef struct demc_config \{(.*?)\} demc_config;", HEADER, re.S)
+    fields = re.findall(r"\b(?:int32_t|int64_t|uint64_t|double)\s+([a-z_A-Z0-9, ]+);", re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S))
+    names = [x.strip() for f in fields for x in f.split(",")]
+    assert names == demc._ffi.CFG_KEYS
+    # sizeof/offsetof as the C compiler sees the header
+    import subprocess, tempfile
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "sz.c")
+        open(src, "w").write('#include <stdio.h>\n#include <stddef.h>\n#include "demc.h"\nint main(){printf("%zu %zu %zu",'
+                             'sizeof(demc_config), offsetof(demc_config, seed), offsetof(demc_config, alpha));return 0;}')
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", os.path.join(td, "sz")])
+        size, off_seed, off_alpha = map(int, subprocess.check_output([os.path.join(td, "sz")]).split())
+    assert C.sizeof(demc._ffi.DemcConfig) == size
+    assert demc._ffi.DemcConfig.seed.offset == off_seed and demc._ffi.DemcConfig.alpha.offset == off_alpha
+    # enum values are shared by convention between include/demc.h, the oracle and families.py
+    for fam in ("GAUSSIAN", "MVN_ISO", "MVN_FULL", "BINOMIAL", "HIER_BINOMIAL", "HIER_GAUSSIAN", "LBA", "LNR", "RASTRIGIN"):
+        v = int(re.search(rf"DEMC_FAM_{fam} = (\d+)", HEADER).group(1))
+        assert getattr(demc.families, f"FAM_{fam}") == v
+    oh = open(os.path.join(ROOT, "oracle", "demc_oracle.h")).read()
+    for nm in re.findall(r"DEMC_((?:FAM|PRIOR|SCHED|PROPOSAL|PARTNER|UPDATE|FITNESS)_[A-Z_]+) = (\d+)", HEADER):
+        mo = re.search(rf"ORC_{nm[0]} = (\d+)", oh)
+        assert mo and mo.group(1) == nm[1], nm
+
+
+def test_no_gpu_means_loud_failure_not_fallback(demc):
+    """On a box without a GPU every compute entry point must fail loudly (DEMC_EHIP), never fall back to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(demc.DemcError) as e:
+        demc.HipEngine(n_groups=2, Np=4, D=2, schedule=1)
+    assert e.value.code == demc._ffi.EHIP
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "differentialevolutionmcmc.jl_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")) or f == "Makefile":
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle/" not in txt and "import oracle" not in txt and "from oracle" not in txt and \
+                    "demc_oracle" not in txt, f"{f} references the oracle"
