@@ -60,6 +60,14 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
             "There is no CPU fallback.")
+    # PyTorch wheels bundle their own libamdhip64.so / libhsa-runtime64.so (same SONAME as /opt/rocm's).  If this
+    # library pulled in /opt/rocm's copy first and torch loaded its own afterwards, the process would hold two HIP
+    # runtimes and the second would see no GPU.  Loading torch first makes the loader resolve our DT_NEEDED
+    # libamdhip64.so.7 to the copy that is already mapped, so both share one runtime (device memory, streams).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     H = C.c_void_p
     L.demc_version.restype = C.c_int32

@@ -1,0 +1,239 @@
+"""GPU tests through the public API (DEModel / DE / sample) and at BASELINE sizes.
+
+Statistical gates mirror the reference's own tests with closed-form or grid targets (no Turing/NUTS here);
+full-size tests use size-independent properties (weights re-evaluate to themselves, ids stay a permutation,
+suffstat == streaming, same seed => same bits, two shards == one)."""
+import numpy as np
+import pytest
+from scipy import stats
+
+import demc_amd as D
+from conftest import make_problem, setup_engine
+from demc_amd import families as F
+
+pytestmark = pytest.mark.gpu
+
+
+def test_binomial_tests_jl():
+    """test/binomial_tests.jl: Beta(1,1) prior, k ~ Binomial(10, theta): posterior Beta(k+1, N-k+1), rtol 0.02"""
+    rng = np.random.default_rng(29542)
+    N, k = 10, int(rng.binomial(10, 0.5))
+    sp = lambda: [rng.uniform()]
+    model = D.DEModel(sample_prior=sp, prior_loglike=D.Priors(θ=D.Beta(1, 1)), loglike=D.BinomialLikelihood(),
+                      data=dict(N=N, k=k), names=("θ",))
+    de = D.DE(sample_prior=sp, bounds=((0, 1),), burnin=1500, Np=4)
+    ch = D.sample(model, de, D.HIPBackend(seed=11), 6000)
+    d = ch.describe()["θ"]
+    sol = stats.beta(k + 1, N - k + 1)
+    assert abs(d["mean"] - sol.mean()) < 0.02 * sol.mean()
+    assert abs(d["std"] - sol.std()) < 0.03 * sol.std()
+    assert abs(d["rhat"] - 1.0) < 0.02
+    assert len(ch) == 4500 and 0.2 < ch["acceptance"].mean() < 0.95
+
+
+@pytest.mark.parametrize("schedule", ["two_colour", "synchronous"])
+def test_gaussian_tests_jl(schedule):
+    """test/gaussian_tests.jl: mu ~ N(0,10), sigma ~ Cauchy+(0,1), 50 obs, DE(burnin=1500, Np=6).  Target: the
+    numerically integrated posterior (the north-star gate "posterior means within 1 %")."""
+    rng = np.random.default_rng(973536)
+    data = rng.normal(0, 1, 50)
+    sp = lambda: [rng.normal(0, 10), abs(rng.standard_cauchy())]
+    model = D.DEModel(sample_prior=sp, prior_loglike=D.Priors(μ=D.Normal(0, 10), σ=D.TruncatedCauchy(0, 1)),
+                      loglike=D.GaussianLikelihood(), data=data, names=("μ", "σ"))
+    de = D.DE(sample_prior=sp, bounds=((-np.inf, np.inf), (0.0, np.inf)), burnin=1500, Np=6)
+    ch = D.sample(model, de, D.HIPBackend(schedule=schedule, seed=5), 21500)
+    d = ch.describe()
+    mu, sg = np.linspace(-1.2, 1.2, 481), np.linspace(0.5, 2.2, 481)
+    M, S = np.meshgrid(mu, sg, indexing="ij")
+    lp = (-0.5 * ((data[None, None] - M[..., None]) / S[..., None]) ** 2).sum(-1) - 50 * np.log(S) - 0.5 * (M / 10) ** 2 - np.log1p(S ** 2)
+    p = np.exp(lp - lp.max())
+    p /= p.sum()
+    em, es = (p * M).sum(), (p * S).sum()
+    sm, ss = np.sqrt((p * M ** 2).sum() - em ** 2), np.sqrt((p * S ** 2).sum() - es ** 2)
+    assert abs(d["μ"]["mean"] - em) < 0.01 and abs(d["σ"]["mean"] - es) < 0.01 * es + 0.005
+    assert abs(d["μ"]["std"] - sm) < 0.01 and abs(d["σ"]["std"] - ss) < 0.01
+    assert abs(d["μ"]["rhat"] - 1) < 0.05 and abs(d["σ"]["rhat"] - 1) < 0.05
+
+
+def test_multivariate_normal_tests_jl():
+    """test/multivariate_normal_tests.jl (10 means instead of 30, 20k iterations instead of 50k): sample = resample,
+    theta_snooker = 0.1, Np = 3, n_groups = 1, nested Theta [mu, sigma]; sds ~ 0.1, cor(data means, post means) > 0.98"""
+    rng = np.random.default_rng(505514)
+    n_mu, n_d = 10, 100
+    data = rng.normal(0, 1, (n_mu, n_d))  # Julia layout: variables x observations
+    sp = lambda: [rng.normal(0, 1, n_mu), abs(rng.standard_cauchy())]
+    model = D.DEModel(sample_prior=sp, prior_loglike=D.Priors(μ=D.Normal(0, 1), σ=D.TruncatedCauchy(0, 1)),
+                      loglike=D.MvNormalIsoLikelihood(), data=data, names=("μ", "σ"))
+    with pytest.warns(UserWarning):
+        de = D.DE(sample_prior=sp, bounds=((-np.inf, np.inf), (0.0, np.inf)), sample=D.resample, burnin=5000,
+                  n_initial=(n_mu + 1) * 4, Np=3, n_groups=1, θsnooker=0.1)
+    ch = D.sample(model, de, D.MCMCThreads(), 20000)
+    d = ch.describe()
+    sds = np.array([d[f"μ[{i + 1}]"]["std"] for i in range(n_mu)])
+    means = np.array([d[f"μ[{i + 1}]"]["mean"] for i in range(n_mu)])
+    np.testing.assert_allclose(sds, 0.1, atol=0.012)
+    assert np.all(np.abs(means) < 0.3)
+    assert np.corrcoef(data.mean(1), means)[0, 1] > 0.98
+
+
+def test_blocking_tests_jl():
+    """test/blocking_tests.jl: blocks [[true,false],[false,true]], blocking on every iteration; means ~ (0, 1)"""
+    rng = np.random.default_rng(58122)
+    data = rng.normal(0, 1, 1000)
+    sp = lambda: [rng.normal(0, 10), abs(rng.standard_cauchy())]
+    model = D.DEModel(sample_prior=sp, prior_loglike=D.Priors(μ=D.Normal(0, 10), σ=D.TruncatedCauchy(0, 1)),
+                      loglike=D.GaussianLikelihood(), data=data, names=("μ", "σ"))
+    de = D.DE(sample_prior=sp, bounds=((-np.inf, np.inf), (0.0, np.inf)), burnin=1000, Np=6,
+              blocking_on=lambda de: True, blocks=[[True, False], [False, True]])
+    ch = D.sample(model, de, D.HIPBackend(seed=2), 2000)
+    d = ch.describe()
+    assert abs(d["μ"]["mean"] - 0.0) < 0.1 and abs(d["σ"]["mean"] - 1.0) < 0.1
+    assert abs(d["μ"]["rhat"] - 1) < 0.05
+
+
+def test_optimization_tests_jl():
+    """test/optimization_tests.jl: rastrigin minimum (minimize! + evaluate_fun!) and Gaussian MLE (maximize!)"""
+    rng = np.random.default_rng(78454111)
+    sp = lambda: [rng.uniform(-5, 5, 2)]
+    model = D.DEModel(sample_prior=sp, loglike=D.RastriginObjective(), data=None, names=("x",))
+    with pytest.warns(UserWarning):
+        de = D.DE(sample_prior=sp, bounds=((-5.0, 5.0),), Np=6, n_groups=1, update_particle=D.minimize,
+                  evaluate_fitness=D.evaluate_fun)
+    vals = []
+    for seed in (1, 4, 6):
+        parts = D.optimize(model, de, D.HIPBackend(schedule="synchronous", seed=seed), 10000)
+        vals.append(D.get_optimal(de, model, parts)[1])
+    assert min(vals) < 1e-8
+    data = rng.normal(0, 1, 100)
+    sp2 = lambda: [rng.normal(0, 1), rng.uniform(0.5, 2)]
+    model = D.DEModel(sample_prior=sp2, loglike=D.GaussianLikelihood(), data=data, names=("μ", "σ"))
+    de = D.DE(sample_prior=sp2, bounds=((-np.inf, np.inf), (0.0, np.inf)), Np=6, n_groups=4, update_particle=D.maximize,
+              evaluate_fitness=D.evaluate_fun)
+    parts = D.optimize(model, de, D.MCMCThreads(), 5000)
+    best, _ = D.get_optimal(de, model, parts)
+    assert abs(best["μ"] - data.mean()) < 1e-4 and abs(best["σ"] - data.std()) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ full size
+
+
+def _cfg3(N=100000, d=32, G=256, Np=256, **kw):
+    rng = np.random.default_rng(20260002)
+    A = rng.normal(0, 1, (d, d))
+    Sigma = A @ A.T / d + 0.5 * np.eye(d)
+    X = rng.normal(0, 1, d) + rng.normal(0, 1, (N, d)) @ np.linalg.cholesky(Sigma).T
+    cfg = dict(n_groups=G, Np=Np, D=d, n_rows=6, schedule=2, seed=7)
+    cfg.update(kw)
+    eng = D.HipEngine(**cfg)
+    eng.set_model(F.FAM_MVN_FULL, X, [N, d], Sigma)
+    eng.set_priors([F.PRIOR_NORMAL] * d, [0.0] * d, [1.0] * d)
+    eng.set_bounds([-np.inf] * d, [np.inf] * d)
+    return eng, X, Sigma
+
+
+def test_cfg3_full_size_properties(orc):
+    """BASELINE cfg3 (D=32, N=1e5, 256 x 256 particles): properties that need no full-size oracle run"""
+    d, P = 32, 65536
+    eng, X, Sigma = _cfg3()
+    th0 = np.random.default_rng(1).normal(0, 1, (P, d))
+    eng.set_state(th0)
+    _, w0, _ = eng.get_state()
+    # (1) streaming weights against the closed form with sufficient statistics, computed independently in numpy
+    Ainv = np.linalg.inv(Sigma)
+    xbar, N = X.mean(0), X.shape[0]
+    Sc = (X - xbar).T @ (X - xbar)
+    _, logdet = np.linalg.slogdet(Sigma)
+    sub = np.arange(0, P, 257)
+    dm = th0[sub] - xbar
+    ll = -0.5 * N * (d * np.log(2 * np.pi) + logdet) - 0.5 * (N * np.einsum("pi,ij,pj->p", dm, Ainv, dm) + np.trace(Ainv @ Sc))
+    pr = stats.norm(0, 1).logpdf(th0[sub]).sum(1)
+    np.testing.assert_allclose(w0[sub], ll + pr, rtol=1e-9)
+    # (2) a sample of rows against the CPU oracle (whitened O(N d) form)
+    o = orc.Oracle(n_groups=1, Np=4, D=d, n_rows=0, store_history=0)
+    o.set_model(F.FAM_MVN_FULL, X, [N, d], Sigma)
+    o.set_priors([F.PRIOR_NORMAL] * d, [0.0] * d, [1.0] * d)
+    np.testing.assert_allclose(w0[sub[:32]], o.logpost(th0[sub[:32]]), rtol=1e-9)
+    # (3) after stepping: stored weights re-evaluate to themselves; ids stay a permutation; history row == state
+    eng.step(1, 5)
+    th, w, ids = eng.get_state()
+    np.testing.assert_allclose(eng.logpost(th[sub]), w[sub], rtol=1e-10)
+    assert np.array_equal(np.sort(ids), np.arange(P))
+    hth, hacc, hlp, hid = eng.get_history(4, 5)
+    assert np.array_equal(hth[0], th) and np.array_equal(hid[0], ids) and np.array_equal(hlp[0], w)
+    assert 0.01 < hacc.mean() < 0.99
+    eng.close()
+    # (4) sufficient-statistic mode gives the same posterior values
+    eng2, _, _ = _cfg3(loglike_mode=1)
+    eng2.set_state(th0)
+    np.testing.assert_allclose(eng2.get_state()[1], w0, rtol=1e-9)
+    eng2.close()
+
+
+def test_same_seed_same_bits_and_two_shards_equal_one():
+    """determinism and SURVEY 8e on one GPU: two handles each owning half of the groups,
+    exchanging through demc_migration_pack/apply, reproduce the single-handle run bit for bit"""
+    import torch
+    prob = make_problem("mvn_full", np.random.default_rng(3), N=2000, d=16)
+    G, Np, d, n_it = 16, 32, 16, 30
+    th0 = prob["init"](G * Np)
+
+    def mk(ng, off):
+        e = D.HipEngine(n_groups=ng, Np=Np, D=d, n_rows=n_it, schedule=2, seed=42, alpha=0.5, theta_snooker=0.1,
+                        group_offset=off, n_groups_total=G, burnin=10)
+        setup_engine(e, prob)
+        return e
+    runs = []
+    for _ in range(2):
+        e = mk(G, 0)
+        e.set_state(th0)
+        e.step(1, n_it)
+        runs.append(e.get_history(0, n_it))
+        e.close()
+    for a, b in zip(*runs):
+        assert np.array_equal(a, b)
+    a, b = mk(G // 2, 0), mk(G // 2, G // 2)
+    a.set_state(th0[: G // 2 * Np])
+    b.set_state(th0[G // 2 * Np:])
+    rows = torch.zeros((G, d + 3), dtype=torch.float64, device="cuda")
+    half = G // 2 * (d + 3) * 8
+    n_mig = 0
+    for it in range(1, n_it + 1):
+        if a.migration_due(it):
+            a.migration_pack_dev(it, rows.data_ptr())
+            b.migration_pack_dev(it, rows.data_ptr() + half)
+            torch.cuda.synchronize()
+            a.migration_apply_dev(it, rows.data_ptr())
+            b.migration_apply_dev(it, rows.data_ptr())
+            n_mig += 1
+        a.update(it, 1)
+        b.update(it, 1)
+    assert n_mig >= 5
+    ha, hb = a.get_history(0, n_it), b.get_history(0, n_it)
+    for one, x, y in zip(runs[0], ha, hb):
+        assert np.array_equal(one, np.concatenate([x, y], axis=1))
+    a.close()
+    b.close()
+
+
+def test_sharded_driver_on_gpu_world1():
+    """ShardedDriver on a CUDA device without a process group: pack -> (no gather) -> apply on device pointers"""
+    import torch
+    from demc_amd.distributed import ShardedDriver
+    prob = make_problem("gaussian", np.random.default_rng(5))
+    th0 = prob["init"](48)
+    hs = []
+    for use_driver in (False, True):
+        e = D.HipEngine(n_groups=8, Np=6, D=2, n_rows=40, schedule=2, seed=9, alpha=0.4)
+        setup_engine(e, prob)
+        e.set_state(th0)
+        if use_driver:
+            e.set_stream(torch.cuda.current_stream().cuda_stream)
+            drv = ShardedDriver(e, None, torch.device("cuda", 0))
+            drv.step(1, 40)
+            assert drv.n_exchanges >= 8
+        else:
+            e.step(1, 40)
+        hs.append(e.get_history(0, 40))
+        e.close()
+    for a, b in zip(*hs):
+        assert np.array_equal(a, b)
