@@ -159,10 +159,10 @@ def main():
                             launch_ms=t_launch * 1e3, executed_tflops=2.0 * N * d * units / t_launch / 1e12)
         else:
             t_launch = (tm["propose"]["ms"] + tm["loglike_prep"]["ms"] + tm["accept_store"]["ms"]) / max(
-                1, tm["accept_store"]["launches"]) * 1e-3
+                1, tm["propose"]["launches"]) * 1e-3
             byts = (24.0 * d + 17.0) * units  # algorithmic bytes per particle-update
             ach = byts / t_launch / 1e9
-            roofline = dict(bound="hbm", kernel="k_propose + k_mvn_prep + k_accept_store (per phase)", achieved=ach,
+            roofline = dict(bound="hbm", kernel="k_propose with fused prep/accept/store tail (one launch per colour phase)", achieved=ach,
                             peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None, launch_ms=t_launch * 1e3)
         roofline["per_kernel_ms_per_iter"] = {n: v["ms"] / k for n, v in tm.items()}
 

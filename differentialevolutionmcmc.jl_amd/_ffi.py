@@ -40,6 +40,7 @@ class DemcConfig(C.Structure):
         ("fitness_kind", C.c_int32), ("schedule", C.c_int32), ("store_history", C.c_int32),
         ("group_offset", C.c_int32), ("n_groups_total", C.c_int32),
         ("seed", C.c_uint64), ("device_id", C.c_int32), ("loglike_mode", C.c_int32),
+        ("trace", C.c_int32), ("fuse", C.c_int32),
     ]
 
 
@@ -105,7 +106,7 @@ def make_config(**kw):
     d = dict(n_groups=4, Np=4, D=1, n_blocks=0, burnin=1000, n_initial=0, n_rows=0, alpha=0.1, beta=0.1, eps=0.001,
              sigma=0.05, kappa=1.0, theta_snooker=0.0, proposal_kind=0, partner_kind=0, update_kind=0,
              fitness_kind=0, schedule=2, store_history=1, group_offset=0, n_groups_total=0, seed=1, device_id=0,
-             loglike_mode=0)
+             loglike_mode=0, trace=1, fuse=0)
     for k, v in kw.items():
         if k in d:
             d[k] = v

@@ -38,7 +38,7 @@ struct demc_handle {
     bool own_stream = false;
     // state
     double *theta = nullptr, *weight = nullptr, *prop = nullptr, *prop_prior = nullptr, *prop_adj = nullptr;
-    double *tr_w = nullptr, *partial = nullptr, *aux = nullptr, *lo = nullptr, *hi = nullptr, *pa = nullptr, *pb = nullptr;
+    double *tr_w = nullptr, *partial = nullptr, *aux = nullptr, *lo = nullptr, *hi = nullptr, *pa = nullptr, *pb = nullptr, *pc = nullptr;
     double *hist = nullptr, *lp_hist = nullptr, *mig_rows = nullptr, *scratch_theta = nullptr, *scratch_w = nullptr;
     long long* id = nullptr;
     unsigned char *prop_oob = nullptr, *tr_acc = nullptr, *masks = nullptr, *acc_hist = nullptr;
@@ -139,12 +139,14 @@ KParams base_params(demc_handle* h) {
     k.fitness_kind = c.fitness_kind;
     k.theta = h->theta; k.weight = h->weight; k.id = h->id; k.prop = h->prop; k.prop_prior = h->prop_prior;
     k.prop_adj = h->prop_adj; k.prop_oob = h->prop_oob; k.tr_idx = h->tr_idx; k.tr_w = h->tr_w; k.tr_acc = h->tr_acc;
-    k.lo = h->lo; k.hi = h->hi; k.mask = nullptr; k.pk = h->pk; k.pa = h->pa; k.pb = h->pb; k.pref = h->pref;
+    k.lo = h->lo; k.hi = h->hi; k.mask = nullptr; k.pk = h->pk; k.pa = h->pa; k.pb = h->pb; k.pc = h->pc; k.pref = h->pref;
     k.hist = h->hist; k.acc_hist = h->acc_hist; k.lp_hist = h->lp_hist; k.id_hist = h->id_hist;
     k.P = h->P; k.store_row = -1; k.tile_in_lds = h->tile_in_lds;
     k.family = h->family; k.N = h->N; k.d = h->d; k.n_acc = h->n_acc; k.n_partials = 1;
     k.partial = h->partial; k.aux = h->aux; k.data = h->data; k.data2 = h->data ? h->data + h->data2_off : nullptr;
     k.c0 = h->c0; k.c1 = h->c1; k.c2 = h->c2;
+    k.n_split = 1; k.fuse_prep = 0; k.fuse_accept = 0; k.write_prop = 1; k.trace = c.trace;
+    k.Ainv = h->Ainv; k.sx = nullptr; k.Ypad = h->Ypad; k.dpad = h->dpad;
     return k;
 }
 
@@ -154,11 +156,6 @@ void launch_cross(demc_handle* h, const KParams& k, int grid, int k0, int n_chun
                        h->n_tiles, n_chunks, part0);
 }
 
-template <int DMAX>
-void launch_prep(demc_handle* h, const KParams& k, int grid, const double* Ainv, const double* sx) {
-    hipLaunchKernelGGL((k_mvn_prep<DMAX>), dim3(grid), dim3(256), 0, h->stream, k, Ainv, h->Ypad, h->dpad, sx);
-}
-
 // K2 dispatch for the active set described by k.  Sets k.n_partials.
 int launch_loglike(demc_handle* h, KParams& k) {
     const long long n_prop = (long long)k.n_groups * k.n_act;
@@ -166,18 +163,7 @@ int launch_loglike(demc_handle* h, KParams& k) {
     switch (h->family) {
         case FAM_MVN_FULL:
         case FAM_MVN_ISO: {
-            const bool suff = h->c.loglike_mode == DEMC_LOGLIKE_SUFFSTAT;
-            const double* Ainv = (h->family == FAM_MVN_FULL) ? h->Ainv : nullptr;
-            const double* sx = suff ? h->sx : nullptr;
-            const int grid = (int)((n_prop + 255) / 256);
-            const int dm = pow2_ceil(h->d < 4 ? 4 : h->d);
-            tick(h, 1, true);
-            if (dm <= 4) launch_prep<4>(h, k, grid, Ainv, sx);
-            else if (dm <= 8) launch_prep<8>(h, k, grid, Ainv, sx);
-            else if (dm <= 16) launch_prep<16>(h, k, grid, Ainv, sx);
-            else if (dm <= 32) launch_prep<32>(h, k, grid, Ainv, sx);
-            else launch_prep<64>(h, k, grid, Ainv, sx);
-            tick(h, 1, false);
+            const bool suff = h->c.loglike_mode == DEMC_LOGLIKE_SUFFSTAT;  // then K1 already formed S
             k.n_partials = 1;
             if (!suff) {
                 tick(h, 2, true);
@@ -235,16 +221,34 @@ int launch_loglike(demc_handle* h, KParams& k) {
     return DEMC_OK;
 }
 
+bool is_mvn(int fam) { return fam == FAM_MVN_FULL || fam == FAM_MVN_ISO; }
+
 int launch_phase(demc_handle* h, KParams& k) {
     const long long n_prop = (long long)k.n_groups * k.n_act;
     if (n_prop == 0) return DEMC_OK;
+    const demc_config& c = h->c;
+    const bool suff = c.loglike_mode == DEMC_LOGLIKE_SUFFSTAT;
+    // K1 tails: MvNormal preparation always; the whole update when the likelihood is O(D^2) given data-only
+    // statistics and a phase writes only rows that no other workgroup reads (two_colour, or the identity pass)
+    k.fuse_prep = is_mvn(h->family) ? 1 : 0;
+    k.sx = (k.fuse_prep && suff) ? h->sx : nullptr;
+    k.Ainv = (h->family == FAM_MVN_FULL) ? h->Ainv : nullptr;
+    k.fuse_accept = (k.fuse_prep && suff && c.fuse != 1 &&
+                     (c.schedule == DEMC_SCHED_TWO_COLOUR || k.mode == MODE_IDENT)) ? 1 : 0;
+    k.write_prop = (!k.fuse_accept || k.trace) ? 1 : 0;
+    const int ppp = 256 / k.lpp;
+    const int max_split = (k.n_act + ppp - 1) / ppp;
+    int n_split = (512 + k.n_groups - 1) / k.n_groups;
+    if (n_split > max_split) n_split = max_split;
+    if (n_split < 1) n_split = 1;
+    k.n_split = n_split;
     tick(h, 0, true);
-    hipLaunchKernelGGL(k_propose, dim3(k.n_groups), dim3(256), h->k1_lds, h->stream, k);
+    hipLaunchKernelGGL(k_propose, dim3(k.n_groups * n_split), dim3(256), h->k1_lds, h->stream, k);
     tick(h, 0, false);
+    if (k.fuse_accept) return DEMC_OK;
     int rc = launch_loglike(h, k);
     if (rc != DEMC_OK) return rc;
     tick(h, 3, true);
-    const int ppp = 256 / k.lpp;
     hipLaunchKernelGGL(k_accept_store, dim3((unsigned)((n_prop + ppp - 1) / ppp)), dim3(256), 0, h->stream, k);
     tick(h, 3, false);
     return DEMC_OK;
@@ -287,6 +291,21 @@ int evaluate_rows(demc_handle* h, double* theta_dev, double* weight_dev) {
     k.mode = MODE_IDENT; k.theta = theta_dev; k.weight = weight_dev; k.store_row = -1; k.iter = 0;
     k.tile_in_lds = 0;
     return launch_phase(h, k);
+}
+
+// K1 LDS carve-up (must match k_propose): group tile (if it fits) | Np prefix sums | A^-1 [d][d] | theta' scratch
+int size_k1_lds(demc_handle* h) {
+    const demc_config& c = h->c;
+    const size_t D = (size_t)c.D;
+    const size_t cdf = ((size_t)c.Np + ((size_t)c.Np + 15) / 16) * sizeof(double);
+    const size_t ainv = (h->family == FAM_MVN_FULL) ? (size_t)h->d * h->d * sizeof(double) : 0;
+    const size_t scr = is_mvn(h->family) ? (size_t)(256 / h->lpp) * (D + 2) * sizeof(double) : 0;
+    const size_t tile = (size_t)c.Np * D * sizeof(double);
+    h->tile_in_lds = (tile + cdf + ainv + scr <= 96 * 1024) ? 1 : 0;
+    h->k1_lds = (h->tile_in_lds ? tile : 0) + cdf + ainv + scr;
+    if (h->k1_lds > 150 * 1024) return fail(h, DEMC_EINVAL, "K1 LDS budget exceeded (Np too large for this D)");
+    HIPCHK(hipFuncSetAttribute((const void*)k_propose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k1_lds));
+    return DEMC_OK;
 }
 
 bool chol_inv(const double* S, int d, std::vector<double>& Ainv, double& logdet) {
@@ -364,7 +383,7 @@ int32_t demc_create(const demc_config* cfg, demc_handle** out) {
     ALLOC(h->prop_prior, P); ALLOC(h->prop_adj, P); ALLOC(h->prop_oob, P);
     ALLOC(h->tr_idx, P * 4); ALLOC(h->tr_w, P); ALLOC(h->tr_acc, P);
     ALLOC(h->partial, (size_t)h->partial_cap * P); ALLOC(h->aux, P);
-    ALLOC(h->lo, D); ALLOC(h->hi, D); ALLOC(h->pk, D); ALLOC(h->pa, D); ALLOC(h->pb, D); ALLOC(h->pref, D);
+    ALLOC(h->lo, D); ALLOC(h->hi, D); ALLOC(h->pk, D); ALLOC(h->pa, D); ALLOC(h->pb, D); ALLOC(h->pc, D); ALLOC(h->pref, D);
     ALLOC(h->mig_rows, (size_t)c.n_groups_total * (D + 3));
     ALLOC(h->scratch_theta, P * D); ALLOC(h->scratch_w, P);
     if (c.store_history && c.n_rows > 0) {
@@ -390,11 +409,8 @@ int32_t demc_create(const demc_config* cfg, demc_handle** out) {
     // lanes per particle: every lane owns dim pairs {2k,2k+1}
     h->lpp = pow2_ceil((c.D + 1) / 2);
     if (h->lpp > 64) h->lpp = 64;
-    // K1 LDS: group tile (if it fits) + Np doubles for the select_base prefix sums
-    const size_t tile = (size_t)c.Np * D * sizeof(double), cdf = (size_t)c.Np * sizeof(double);
-    h->tile_in_lds = (tile + cdf <= 128 * 1024) ? 1 : 0;
-    h->k1_lds = (h->tile_in_lds ? tile : 0) + cdf;
-    HIPCHK(hipFuncSetAttribute((const void*)k_propose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k1_lds));
+    int rc_lds = size_k1_lds(h);
+    if (rc_lds != DEMC_OK) return rc_lds;
     if ((size_t)c.n_groups_total * sizeof(int) > 48 * 1024) return fail(h, DEMC_EINVAL, "n_groups_total too large");
     return DEMC_OK;
 }
@@ -404,7 +420,7 @@ int32_t demc_destroy(demc_handle* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     drain_events(h);
     void* ptrs[] = {h->theta, h->weight, h->prop, h->prop_prior, h->prop_adj, h->tr_w, h->partial, h->aux, h->lo, h->hi,
-                    h->pa, h->pb, h->hist, h->lp_hist, h->mig_rows, h->scratch_theta, h->scratch_w, h->id, h->prop_oob,
+                    h->pa, h->pb, h->pc, h->hist, h->lp_hist, h->mig_rows, h->scratch_theta, h->scratch_w, h->id, h->prop_oob,
                     h->tr_acc, h->masks, h->acc_hist, h->tr_idx, h->pk, h->pref, h->id_hist, h->data, h->Ainv, h->Ypad,
                     h->Xf, h->sx};
     for (void* p : ptrs)
@@ -555,13 +571,13 @@ int32_t demc_set_model(demc_handle* h, int32_t family, const double* data, const
         HIPCHK(hipMemcpy(h->data, dev.data(), sizeof(double) * dev.size(), hipMemcpyHostToDevice));
     }
     h->family = family;
-    return DEMC_OK;
+    return size_k1_lds(h);
 }
 
 int32_t demc_set_priors(demc_handle* h, const int32_t* kind, const double* a, const double* b, const int32_t* ref) {
     if (!h || !kind) return DEMC_EINVAL;
     const size_t D = (size_t)h->c.D;
-    std::vector<double> va(D, 0.0), vb(D, 1.0);
+    std::vector<double> va(D, 0.0), vb(D, 1.0), vc(D, 0.0);
     std::vector<int> vr(D, 0), vk(kind, kind + D);
     for (size_t j = 0; j < D; ++j) {
         if (vk[j] < 0 || vk[j] > DEMC_PRIOR_NORMAL_REF) return fail(h, DEMC_EUNSUPPORTED, "prior kind not registered");
@@ -573,6 +589,8 @@ int32_t demc_set_priors(demc_handle* h, const int32_t* kind, const double* a, co
     HIPCHK(hipMemcpy(h->pk, vk.data(), D * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->pa, va.data(), D * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->pb, vb.data(), D * sizeof(double), hipMemcpyHostToDevice));
+    for (size_t j = 0; j < D; ++j) vc[j] = prior_const(vk[j], va[j], vb[j]);
+    HIPCHK(hipMemcpy(h->pc, vc.data(), D * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->pref, vr.data(), D * sizeof(int), hipMemcpyHostToDevice));
     return DEMC_OK;
 }

@@ -2,7 +2,7 @@
 //
 //   K1  k_propose        crossover!/snooker_update!/mutation!/recombination!/reset!/in_bounds + prior
 //                        (crossover.jl:30-99,154-257,301-352; mutation.jl:13-25; utilities.jl:70-78)
-//   K2  k_mvn_prep       y = A^-1 mu, a = mu.y for the MvNormal families (VALU)
+//       (fused tails)    MvNormal preparation y = A^-1 theta', a = theta'.y; optional accept/store
 //       k_cross_mfma     S_p = sum_i y_p . x_i over all observations on v_mfma_f64_16x16x4_f64
 //       k_obs_loglike    thread-per-proposal streaming likelihoods (Gaussian, Binomial, LBA, LNR, rastrigin)
 //       k_hier_loglike   wave-per-proposal likelihoods whose cost is O(D) (hierarchical families)
@@ -56,6 +56,7 @@ struct KParams {
     const int* pk;
     const double* pa;
     const double* pb;
+    const double* pc;     // per-scalar prior normalisation constant, precomputed on the host
     const int* pref;
     // history (slot keyed)
     double* hist;             // [rows][P][D]
@@ -65,6 +66,15 @@ struct KParams {
     long long P;              // local particles
     long long store_row;      // >= 0: K3 stores this history row
     int tile_in_lds;          // K1: stage the group tile in LDS
+    int n_split;              // K1: workgroups per group
+    int fuse_prep;            // K1 computes y = A^-1 theta', a = theta'.y (MvNormal families)
+    int fuse_accept;          // K1 finishes the update (cheap likelihoods, two_colour)
+    int write_prop;           // K1 writes proposals to HBM (needed by K2/K3 or by the trace)
+    int trace;                // keep the per-slot diagnostic trace
+    const double* Ainv;       // [d][d] or null (ISO)
+    const double* sx;         // [d] sum_i x_i, non-null in SUFFSTAT mode
+    double* Ypad;             // [P][dpad]
+    int dpad;
     // model
     int family;
     long long N;              // observations (or subjects)
@@ -96,22 +106,68 @@ __device__ inline T subgroup_sum(T v, int lpp) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: one workgroup per group.  Partner rows come from the group tile staged in LDS when it fits
-// (Np*D*8 bytes), else from theta in HBM/L2 -- either way a sweep-start snapshot, because theta is
-// only written by K3.
+// Log-likelihood from the accumulated statistics of one proposal (shared by the fused K1 tail and K3).
+//   s   = sum of the partial sums (MvNormal: cross term S = sum_i y.x_i; Gaussian: sum z^2; else the log-likelihood)
+//   aux = quadratic term mu.y (MvNormal);  sg = the proposal's sigma where the family has one
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_propose(KParams p) {
+__device__ inline double loglike_from_stats(const KParams& p, double s, double aux, double sg) {
+    switch (p.family) {
+        case FAM_MVN_FULL:  // c0 = -N/2 (d log2pi + logdet), c1 = sum_i x_i' A^-1 x_i
+            return p.c0 - 0.5 * (p.c1 - 2.0 * s + (double)p.N * aux);
+        case FAM_MVN_ISO: {  // c1 = sum_i |x_i|^2
+            const double nd = (double)p.N * (double)p.d;
+            return -0.5 * nd * kLog2Pi - nd * log(sg) - 0.5 * (p.c1 - 2.0 * s + (double)p.N * aux) / (sg * sg);
+        }
+        case FAM_GAUSSIAN:
+            return -0.5 * (s + (double)p.N * kLog2Pi) - (double)p.N * log(sg);
+        default:
+            return s;
+    }
+}
+
+// mh_update! / maximize! / minimize! decision for one particle (utilities.jl:55-58, 201-226)
+__device__ inline int decide(const KParams& p, uint32_t eslot, double wp, double w, double adj) {
+    if (p.mode == MODE_IDENT) return 1;
+    if (p.update_kind == 1) return wp > w;
+    if (p.update_kind == 2) return wp < w;
+    const U4 r = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 3);
+    const double u = u53(r.x, r.y);
+    const double e = exp(wp - w + adj);  // min(1, NaN) = NaN in Julia -> `rand() <= NaN` is false -> reject
+    return (e >= 1.0) || (u <= e);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: proposals.  grid = n_groups x n_split workgroups; workgroup (g, sp) proposes for a slice of the
+// active particles of group g.  Partner rows come from the group tile staged in LDS when it fits
+// (Np*D*8 bytes), else from theta in HBM/L2 -- either way a phase-start snapshot: in the unfused path
+// theta is only written by K3, and in the fused path (two_colour) a phase writes active rows only while
+// partners come from the other colour.
+//
+// Optional fused tails (uniform flags, no divergence):
+//   fuse_prep   (MvNormal families): y = A^-1 theta' and a = theta'.y from an LDS copy of theta' and A^-1
+//               (replaces a separate preparation kernel); SUFFSTAT mode also forms S = y . sum_i x_i here.
+//   fuse_accept (likelihoods that are O(D^2) given data-only statistics, two_colour schedule): finishes the
+//               whole update -- prior + loglike, Metropolis accept, theta/weight write-back and the history
+//               row -- so that one launch per colour phase is the entire DE-MCMC sweep.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     extern __shared__ double lds[];
-    const int tid = threadIdx.x;
-    const int g = blockIdx.x;
-    const int g_glob = p.group_offset + g;
-    const int D = p.D, Np = p.Np;
-    const double* grows = p.theta + (size_t)g * Np * D;
-    const double* gw = p.weight + (size_t)g * Np;
-    double* tile = lds;
-    double* cdf = lds + (p.tile_in_lds ? (size_t)Np * D : 0);
     __shared__ double s_red[4];
     __shared__ double s_total;
+    const int tid = threadIdx.x;
+    const int g = blockIdx.x / p.n_split, sp = blockIdx.x % p.n_split;
+    const int g_glob = p.group_offset + g;
+    const int D = p.D, Np = p.Np, d = p.d;
+    const double* grows = p.theta + (size_t)g * Np * D;
+    const double* gw = p.weight + (size_t)g * Np;
+    const int lpp = p.lpp;
+    const int ppp = 256 / lpp;  // particles per pass
+    // LDS carve-up (host computes the same sizes): tile | cdf | A^-1 | theta' scratch
+    double* tile = lds;
+    double* cdf = tile + (p.tile_in_lds ? (size_t)Np * D : 0);
+    double* ainv_s = cdf + Np + ((Np + 15) >> 4);
+    const int scr_stride = D + 2;
+    double* scr = ainv_s + ((p.fuse_prep && p.Ainv) ? (size_t)d * d : 0);
 
     bool is_mut = false;
     if (p.mode == MODE_STEP) {
@@ -126,6 +182,8 @@ __global__ __launch_bounds__(256) void k_propose(KParams p) {
         for (int i = tid; i < Np * D; i += 256) tile[i] = grows[i];
         rows = tile;
     }
+    if (p.fuse_prep && p.Ainv)
+        for (int i = tid; i < d * d; i += 256) ainv_s[i] = p.Ainv[i];
     if (use_base) {
         // select_base (crossover.jl:282-289), stabilised: e_j = exp(w_j - max w); sequential prefix sum so
         // that the walk "first i with cumsum >= u*total" matches the CPU oracle exactly.
@@ -135,29 +193,46 @@ __global__ __launch_bounds__(256) void k_propose(KParams p) {
         if ((tid & 63) == 0) s_red[tid >> 6] = m;
         __syncthreads();
         m = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
-        for (int i = tid; i < Np; i += 256) cdf[i] = exp(gw[i] - m);
+        // two-level prefix in a fixed order (same as the oracle): sequential inside chunks of 16, sequential over
+        // the chunk totals, cdf[i] = offset[chunk] + prefix[i]
+        const int n_chunk = (Np + 15) >> 4;
+        double* ctot = cdf + Np;  // [n_chunk] chunk totals, then exclusive offsets
+        for (int c = tid; c < n_chunk; c += 256) {
+            double pre = 0.0;
+            const int i1 = (c * 16 + 16 < Np) ? c * 16 + 16 : Np;
+            for (int i = c * 16; i < i1; ++i) {
+                pre += exp(gw[i] - m);
+                cdf[i] = pre;
+            }
+            ctot[c] = pre;
+        }
         __syncthreads();
         if (tid == 0) {
-            double c = 0.0;
-            for (int i = 0; i < Np; ++i) {
-                c += cdf[i];
-                cdf[i] = c;
+            double off = 0.0;
+            for (int c = 0; c < n_chunk; ++c) {
+                const double t = ctot[c];
+                ctot[c] = off;
+                off = off + t;
             }
-            s_total = c;
         }
+        __syncthreads();
+        for (int i = tid; i < Np; i += 256) cdf[i] = ctot[i >> 4] + cdf[i];
+        __syncthreads();
+        if (tid == 0) s_total = cdf[Np - 1];
     }
     __syncthreads();
 
-    const int lpp = p.lpp;
-    const int ppp = 256 / lpp;  // particles per pass
     const int sub = tid / lpp, sl = tid % lpp;
-    const int n_pass = (p.n_act + ppp - 1) / ppp;
+    const int per_split = (p.n_act + p.n_split - 1) / p.n_split;
+    const int q_lo = sp * per_split;
+    const int q_hi = (q_lo + per_split < p.n_act) ? q_lo + per_split : p.n_act;
+    const int n_pass = (q_hi - q_lo + ppp - 1) / ppp;
     const double eps = p.eps;
 
     for (int pass = 0; pass < n_pass; ++pass) {
-        const int q = pass * ppp + sub;
-        const bool valid = q < p.n_act;
-        const int pl = p.a_lo + (valid ? q : 0);
+        const int q = q_lo + pass * ppp + sub;
+        const bool valid = q < q_hi;
+        const int pl = p.a_lo + (valid ? q : q_lo);
         const size_t slot = (size_t)g * Np + pl;
         const uint32_t eslot = (uint32_t)g_glob * (uint32_t)Np + (uint32_t)pl;
         const double* pt = rows + (size_t)pl * D;
@@ -273,7 +348,7 @@ __global__ __launch_bounds__(256) void k_propose(KParams p) {
                 const double u1 = u53(nz.x, nz.y), u2 = u53(nz.z, nz.w);
                 const double rad = sqrt(-2.0 * log(1.0 - u1));
                 double sn, cs;
-                sincos(2.0 * kPi * u2, &sn, &cs);
+                sincospi(2.0 * u2, &sn, &cs);  // Box-Muller angle 2*pi*u2
                 return tj + p.sigma * (rad * ((j & 1) ? sn : cs));
             }
             const double uu = (j & 1) ? u53(nz.z, nz.w) : u53(nz.x, nz.y);
@@ -302,6 +377,8 @@ __global__ __launch_bounds__(256) void k_propose(KParams p) {
 
         int oob = 0;
         double prior = 0.0, s1 = 0.0, s2 = 0.0;
+        int ref_cached = -1;
+        double sref = 0.0;
         for (int k = sl; 2 * k < D; k += lpp)
             for (int e = 0; e < 2; ++e) {
                 const int j = 2 * k + e;
@@ -315,73 +392,128 @@ __global__ __launch_bounds__(256) void k_propose(KParams p) {
                     if (p.fitness_kind == 0) {
                         const int pk = p.pk[j];
                         if (pk != PR_FLAT) {
-                            const double sref = (pk == PR_NORMAL_REF) ? value(p.pref[j]) : 0.0;
-                            prior += prior_scalar(pk, p.pa[j], p.pb[j], sref, v);
+                            if (pk == PR_NORMAL_REF && p.pref[j] != ref_cached) {
+                                ref_cached = p.pref[j];
+                                sref = value(ref_cached);
+                            }
+                            prior += prior_scalar(pk, p.pa[j], p.pb[j], p.pc[j], sref, v);
                         }
                     }
-                    if (valid) p.prop[slot * D + j] = v;
+                    if (valid && p.write_prop) p.prop[slot * D + j] = v;
+                    if (p.fuse_prep) scr[sub * scr_stride + j] = v;
                 }
             }
         prior = subgroup_sum(prior, lpp);
         s1 = subgroup_sum(s1, lpp);
         s2 = subgroup_sum(s2, lpp);
         oob = subgroup_sum(oob, lpp);
-        if (sl == 0 && valid) {
-            p.prop_prior[slot] = prior;
-            p.prop_oob[slot] = oob ? 1 : 0;
-            // (d-1)(log|a| - log|b|): stable form of log(|a|^(d-1)/|b|^(d-1))  crossover.jl:268-273
-            p.prop_adj[slot] = (kind == 1) ? (double)(D - 1) * (0.5 * log(s1) - 0.5 * log(s2)) : 0.0;
-            p.tr_idx[slot * 4 + 0] = kind;
-            p.tr_idx[slot * 4 + 1] = i0;
-            p.tr_idx[slot * 4 + 2] = i1;
-            p.tr_idx[slot * 4 + 3] = i2;
-        }
-    }
-}
+        // (d-1)(log|a| - log|b|): stable form of log(|a|^(d-1)/|b|^(d-1))  crossover.jl:268-273
+        const double adj = (kind == 1) ? (double)(D - 1) * (0.5 * log(s1) - 0.5 * log(s2)) : 0.0;
 
-// ------------------------------------------------------------------------------------------------
-// K2a: MvNormal preparation.  y = A^-1 mu (FULL) or mu (ISO); a = mu . y.  One thread per proposal,
-// y kept in registers (DMAX compile-time), A^-1 read with wave-uniform (scalar) loads.
-// Ypad[slot][dpad] is zero padded to the MFMA k-step.
-// ------------------------------------------------------------------------------------------------
-template <int DMAX>
-__global__ __launch_bounds__(256) void k_mvn_prep(KParams p, const double* __restrict__ Ainv, double* __restrict__ Ypad,
-                                                  int dpad, const double* __restrict__ sx) {
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    const int n_prop = p.n_groups * p.n_act;
-    if (q >= n_prop) return;
-    const size_t slot = (size_t)slot_of(p, q);
-    const int d = p.d;
-    const double* mu = p.prop + slot * p.D;
-    double y[DMAX];
-#pragma unroll
-    for (int c = 0; c < DMAX; ++c) y[c] = 0.0;
-    if (Ainv) {
-        for (int k = 0; k < d; ++k) {
-            const double mk = mu[k];
-#pragma unroll
-            for (int c = 0; c < DMAX; ++c)
-                if (c < d) y[c] += Ainv[(size_t)c * d + k] * mk;
+        double aux = 0.0, S = 0.0;
+        if (p.fuse_prep) {
+            // y = A^-1 theta' (FULL) or theta' (ISO) for the data dimensions; each lane owns output columns {2k, 2k+1}.
+            // A scratch row is written and read by ONE sub-group, which lives inside one wave: LDS operations of a
+            // wave execute in order, so only the compiler must be kept from reordering them.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const double* th = scr + sub * scr_stride;
+            for (int k = sl; 2 * k < d; k += lpp) {
+                const int c0 = 2 * k, c1 = 2 * k + 1;
+                double y0 = 0.0, y1 = 0.0;
+                if (p.Ainv) {
+                    for (int j = 0; j < d; ++j) {
+                        const double t = th[j];
+                        y0 = fma(ainv_s[j * d + c0], t, y0);  // A^-1 is symmetric: column c == row c
+                        if (c1 < d) y1 = fma(ainv_s[j * d + c1], t, y1);
+                    }
+                } else {
+                    y0 = th[c0];
+                    if (c1 < d) y1 = th[c1];
+                }
+                aux = fma(th[c0], y0, aux);
+                if (c1 < d) aux = fma(th[c1], y1, aux);
+                if (p.sx) {
+                    S = fma(y0, p.sx[c0], S);
+                    if (c1 < d) S = fma(y1, p.sx[c1], S);
+                } else if (valid) {
+                    p.Ypad[slot * p.dpad + c0] = y0;
+                    if (c1 < p.dpad) p.Ypad[slot * p.dpad + c1] = (c1 < d) ? y1 : 0.0;
+                }
+            }
+            if (!p.sx && valid)  // zero the k-step padding beyond d
+                for (int c = 2 * ((d + 1) / 2) + sl; c < p.dpad; c += lpp) p.Ypad[slot * p.dpad + c] = 0.0;
+            aux = subgroup_sum(aux, lpp);
+            S = subgroup_sum(S, lpp);
         }
-    } else {
-#pragma unroll
-        for (int c = 0; c < DMAX; ++c)
-            if (c < d) y[c] = mu[c];
-    }
-    double a = 0.0, s = 0.0;
-#pragma unroll
-    for (int c = 0; c < DMAX; ++c)
-        if (c < d) {
-            a += mu[c] * y[c];
-            if (sx) s += y[c] * sx[c];
+
+        if (!p.fuse_accept) {
+            if (sl == 0 && valid) {
+                p.prop_prior[slot] = prior;
+                p.prop_oob[slot] = oob ? 1 : 0;
+                p.prop_adj[slot] = adj;
+                if (p.fuse_prep) {
+                    p.aux[slot] = aux;
+                    if (p.sx) p.partial[slot] = S;
+                }
+                if (p.trace) {
+                    p.tr_idx[slot * 4 + 0] = kind;
+                    p.tr_idx[slot * 4 + 1] = i0;
+                    p.tr_idx[slot * 4 + 2] = i1;
+                    p.tr_idx[slot * 4 + 3] = i2;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            continue;
         }
-    p.aux[slot] = a;
-    if (sx)
-        p.partial[slot] = s;  // SUFFSTAT: S = y . sum_i x_i, no pass over the data
-    else {
-#pragma unroll
-        for (int c = 0; c < DMAX; ++c)
-            if (c < dpad) Ypad[slot * dpad + c] = (c < d) ? y[c] : 0.0;
+
+        // ---- fused tail: compute_posterior! + mh_update! + store_samples! for this particle ----
+        int acc = 0;
+        if (sl == 0) {
+            const double w = gw[pl];
+            const double sg = (p.family == FAM_MVN_ISO) ? scr[sub * scr_stride + d] : 0.0;
+            double wp;
+            if (p.fitness_kind == 1)
+                wp = oob ? (p.update_kind == 1 ? -INFINITY : INFINITY) : loglike_from_stats(p, S, aux, sg);
+            else
+                wp = oob ? -INFINITY : prior + loglike_from_stats(p, S, aux, sg);
+            acc = decide(p, eslot, wp, w, adj);
+            if (valid) {
+                if (acc) p.weight[slot] = wp;
+                if (p.trace) {
+                    p.tr_idx[slot * 4 + 0] = kind; p.tr_idx[slot * 4 + 1] = i0;
+                    p.tr_idx[slot * 4 + 2] = i1; p.tr_idx[slot * 4 + 3] = i2;
+                    p.tr_w[slot] = wp; p.tr_acc[slot] = (unsigned char)acc; p.prop_adj[slot] = adj;
+                }
+                if (p.store_row >= 0) {
+                    const size_t hrow = (size_t)p.store_row * p.P + slot;
+                    if (p.update_kind == 0 && p.mode == MODE_STEP) {  // utilities.jl:207-208
+                        p.acc_hist[hrow] = (unsigned char)acc;
+                        p.lp_hist[hrow] = acc ? wp : w;
+                    }
+                    p.id_hist[hrow] = (int)p.id[slot];
+                }
+            }
+        }
+        acc = __shfl(acc, (tid & 63) & ~(lpp - 1));
+        if (valid) {
+            double* trow = p.theta + slot * D;
+            double* hrow = (p.store_row >= 0) ? p.hist + ((size_t)p.store_row * p.P + slot) * D : nullptr;
+            const double* th = scr + sub * scr_stride;
+            if (acc || hrow)
+                for (int k = sl; 2 * k < D; k += lpp)
+                    for (int e = 0; e < 2; ++e) {
+                        const int j = 2 * k + e;
+                        if (j < D) {
+                            const double v = acc ? th[j] : pt[j];
+                            if (acc) trow[j] = v;  // current.theta = proposal.theta utilities.jl:204
+                            if (hrow) hrow[j] = v;  // samples[iter, :, id] = theta utilities.jl:170-180
+                        }
+                    }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // scratch rows are reused by the same sub-group in the next pass
     }
 }
 
@@ -615,21 +747,10 @@ __global__ __launch_bounds__(256) void k_hier_loglike(KParams p) {
 __device__ inline double finalize_loglike(const KParams& p, size_t slot) {
     double s = 0.0;
     for (int c = 0; c < p.n_partials; ++c) s += p.partial[(size_t)c * p.P + slot];
-    switch (p.family) {
-        case FAM_MVN_FULL:  // c0 = -N/2 (d log2pi + logdet), c1 = sum_i x_i' A^-1 x_i
-            return p.c0 - 0.5 * (p.c1 - 2.0 * s + (double)p.N * p.aux[slot]);
-        case FAM_MVN_ISO: {  // c1 = sum_i |x_i|^2
-            const double sg = p.prop[slot * p.D + p.d];
-            const double nd = (double)p.N * (double)p.d;
-            return -0.5 * nd * kLog2Pi - nd * log(sg) - 0.5 * (p.c1 - 2.0 * s + (double)p.N * p.aux[slot]) / (sg * sg);
-        }
-        case FAM_GAUSSIAN: {
-            const double sg = p.prop[slot * p.D + 1];
-            return -0.5 * (s + (double)p.N * kLog2Pi) - (double)p.N * log(sg);
-        }
-        default:
-            return s;
-    }
+    double sg = 0.0;
+    if (p.family == FAM_MVN_ISO) sg = p.prop[slot * p.D + p.d];
+    if (p.family == FAM_GAUSSIAN) sg = p.prop[slot * p.D + 1];
+    return loglike_from_stats(p, s, p.aux[slot], sg);
 }
 
 __global__ __launch_bounds__(256) void k_accept_store(KParams p) {
@@ -652,23 +773,14 @@ __global__ __launch_bounds__(256) void k_accept_store(KParams p) {
             wp = oob ? (p.update_kind == 1 ? -INFINITY : INFINITY) : finalize_loglike(p, slot);
         else  // compute_posterior! utilities.jl:92-99
             wp = oob ? -INFINITY : p.prop_prior[slot] + finalize_loglike(p, slot);
-        if (p.mode == MODE_IDENT)
-            acc = 1;
-        else if (p.update_kind == 1)
-            acc = wp > w;  // maximize! utilities.jl:212-218
-        else if (p.update_kind == 2)
-            acc = wp < w;  // minimize! utilities.jl:220-226
-        else {  // accept / mh_update! utilities.jl:55-58,201-210; min(1, NaN) = NaN -> reject
-            const uint32_t eslot = (uint32_t)(p.group_offset + g) * (uint32_t)p.Np + (uint32_t)pl;
-            const U4 r = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 3);
-            const double u = u53(r.x, r.y);
-            const double e = exp(wp - w + p.prop_adj[slot]);
-            acc = (e >= 1.0) || (u <= e);
-        }
+        const uint32_t eslot = (uint32_t)(p.group_offset + g) * (uint32_t)p.Np + (uint32_t)pl;
+        acc = decide(p, eslot, wp, w, p.prop_adj[slot]);  // mh_update! / maximize! / minimize!
         w_new = acc ? wp : w;
         if (acc) p.weight[slot] = wp;
-        p.tr_w[slot] = wp;
-        p.tr_acc[slot] = (unsigned char)acc;
+        if (p.trace) {
+            p.tr_w[slot] = wp;
+            p.tr_acc[slot] = (unsigned char)acc;
+        }
         if (p.store_row >= 0) {
             const size_t hrow = (size_t)p.store_row * p.P + slot;
             if (p.update_kind == 0 && p.mode == MODE_STEP) {  // utilities.jl:207-208

@@ -1,0 +1,142 @@
+# DEMCHIP.jl -- the binding a maintainer of DifferentialEvolutionMCMC.jl would add to route the per-iteration
+# hot path (step!/pstep!, src/main.jl:84-107) through libdemc_hip.so.  Thin, mechanical @ccall wrappers over
+# include/demc.h plus one new `sample` method selected by dispatch on a tag type, exactly like the existing
+# MCMCThreads method (src/main.jl:62-71).
+#
+# STATUS: written against include/demc.h but NOT executed -- there is no Julia runtime in the build container
+# or on the GPU box (SURVEY.md 8c).  The tested host is the Python mirror in differentialevolutionmcmc.jl_amd/.
+module DEMCHIP
+
+using DifferentialEvolutionMCMC
+import DifferentialEvolutionMCMC: DE, DEModel, sample_init, bundle_samples, random_gamma, fixed_gamma,
+    variable_gamma, resample, mh_update!, maximize!, minimize!, compute_posterior!, evaluate_fun!
+import DifferentialEvolutionMCMC: sample
+
+const LIB = get(ENV, "DEMC_HIP_LIB", "libdemc_hip.so")
+
+# POD mirror of demc_config (include/demc.h); field order and types must not change
+struct DemcConfig
+    n_groups::Int32; Np::Int32; D::Int32; n_blocks::Int32
+    burnin::Int64; n_initial::Int64; n_rows::Int64
+    alpha::Float64; beta::Float64; eps::Float64; sigma::Float64; kappa::Float64; theta_snooker::Float64
+    proposal_kind::Int32; partner_kind::Int32; update_kind::Int32; fitness_kind::Int32
+    schedule::Int32; store_history::Int32; group_offset::Int32; n_groups_total::Int32
+    seed::UInt64; device_id::Int32; loglike_mode::Int32; trace::Int32; fuse::Int32
+end
+
+"""
+Registered model family: what replaces the closures of `DEModel` on the device (closures cannot run in a kernel).
+`family` is a DEMC_FAM_* id, `data`/`dims`/`hyper` as documented in include/demc.h, and one prior entry
+`(kind, a, b, ref)` per scalar parameter.
+"""
+struct ModelSpec
+    family::Int32
+    data::Vector{Float64}
+    dims::Vector{Int64}
+    hyper::Vector{Float64}
+    prior_kind::Vector{Int32}
+    prior_a::Vector{Float64}
+    prior_b::Vector{Float64}
+    prior_ref::Vector{Int32}
+end
+
+struct HIPBackend
+    schedule::Symbol      # :two_colour (default) or :synchronous
+    loglike_mode::Symbol  # :streaming or :suffstat
+    device_id::Int
+    seed::UInt64
+end
+HIPBackend(; schedule = :two_colour, loglike_mode = :streaming, device_id = 0, seed = rand(UInt64)) =
+    HIPBackend(schedule, loglike_mode, device_id, seed)
+
+function check(h, rc)
+    rc == 0 && return nothing
+    msg = unsafe_string(@ccall LIB.demc_last_error(h::Ptr{Cvoid})::Cstring)
+    error("libdemc_hip: status $rc: $msg")   # non-zero status -> Julia exception (SURVEY 8b)
+end
+
+# function-valued hooks of DE (src/structs.jl:71-74) -> enums; anything else has no device implementation
+hook_code(f, table, what) = haskey(table, f) ? table[f] :
+    error("DE.$what = $f cannot run on the device; use the CPU path (step!/pstep!)")
+const PROPOSALS = IdDict(random_gamma => 0, fixed_gamma => 1, variable_gamma => 2)
+const PARTNERS = IdDict(DifferentialEvolutionMCMC.sample => 0, resample => 1)
+const UPDATES = IdDict(mh_update! => 0, maximize! => 1, minimize! => 2)
+const FITNESS = IdDict(compute_posterior! => 0, evaluate_fun! => 1)
+
+flatten(Θ) = collect(Float64, Iterators.flatten(Θ))
+
+"flatten de.bounds (one tuple per top-level parameter, zip-truncated: utilities.jl:73-78) to per-scalar lo/hi"
+function flat_bounds(de, Θ)
+    lo = Float64[]; hi = Float64[]
+    for (i, θ) in enumerate(Θ)
+        b = i <= length(de.bounds) ? de.bounds[i] : (-Inf, Inf)
+        append!(lo, fill(Float64(b[1]), length(θ))); append!(hi, fill(Float64(b[2]), length(θ)))
+    end
+    return lo, hi
+end
+
+"""
+    sample(model::DEModel, de::DE, backend::HIPBackend, n_iter; model_spec, progress=false)
+
+Same contract as `sample(model, de, MCMCThreads(), n_iter)` (src/main.jl:62-71): `sample_init` and
+`bundle_samples` run unchanged on the host; the iteration loop (src/main.jl:33-38) becomes `demc_step`.
+"""
+function sample(model::DEModel, de::DE, b::HIPBackend, n_iter::Int; model_spec::ModelSpec, progress = false, kwargs...)
+    groups = sample_init(model, de, n_iter)                      # src/main.jl:263-271 (allocates de.samples)
+    particles = vcat(groups...)
+    P = length(particles); D = length(flatten(particles[1].Θ))
+    blocking = de.blocking_on(de)
+    cfg = DemcConfig(de.n_groups, de.Np, D, 0, de.burnin, de.n_initial, n_iter + de.n_initial,
+        de.α, de.β, de.ϵ, de.σ, de.κ, de.θsnooker,
+        hook_code(de.generate_proposal, PROPOSALS, "generate_proposal"), hook_code(de.sample, PARTNERS, "sample"),
+        hook_code(de.update_particle!, UPDATES, "update_particle!"), hook_code(de.evaluate_fitness!, FITNESS, "evaluate_fitness!"),
+        b.schedule == :two_colour ? 2 : 1, 1, 0, de.n_groups, b.seed, b.device_id, b.loglike_mode == :streaming ? 0 : 1, 0, 0)
+    href = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = @ccall LIB.demc_create(Ref(cfg)::Ptr{DemcConfig}, href::Ptr{Ptr{Cvoid}})::Int32
+    h = href[]
+    try
+        check(h, rc)
+        m = model_spec
+        GC.@preserve m begin
+            check(h, @ccall LIB.demc_set_model(h::Ptr{Cvoid}, m.family::Int32, m.data::Ptr{Float64}, m.dims::Ptr{Int64},
+                Int32(length(m.dims))::Int32, m.hyper::Ptr{Float64}, Int32(length(m.hyper))::Int32)::Int32)
+            check(h, @ccall LIB.demc_set_priors(h::Ptr{Cvoid}, m.prior_kind::Ptr{Int32}, m.prior_a::Ptr{Float64},
+                m.prior_b::Ptr{Float64}, m.prior_ref::Ptr{Int32})::Int32)
+        end
+        lo, hi = flat_bounds(de, particles[1].Θ)
+        check(h, @ccall LIB.demc_set_bounds(h::Ptr{Cvoid}, lo::Ptr{Float64}, hi::Ptr{Float64})::Int32)
+        if blocking
+            masks = UInt8[x for blk in de.blocks for x in Iterators.flatten(blk)]   # nblocks x D, row-major
+            check(h, @ccall LIB.demc_set_blocks(h::Ptr{Cvoid}, masks::Ptr{UInt8}, Int32(length(de.blocks))::Int32)::Int32)
+        end
+        if de.n_initial > 0   # initialize_samples (utilities.jl:35-39): rows 1:n_initial, [row][particle][D]
+            rows = Float64[x for i = 1:de.n_initial for p = 1:P for x in Iterators.flatten(de.samples[i, :, p])]
+            check(h, @ccall LIB.demc_set_history_rows(h::Ptr{Cvoid}, 0::Int64, Int64(de.n_initial)::Int64, rows::Ptr{Float64})::Int32)
+        end
+        theta = Float64[x for p in particles for x in flatten(p.Θ)]        # D x P column-major == [P][D] row-major
+        weight = Float64[p.weight for p in particles]                      # evaluated by sample_init on the host
+        ids = Int64[p.id - 1 for p in particles]                           # ids are 0-based across the ABI
+        check(h, @ccall LIB.demc_set_state(h::Ptr{Cvoid}, theta::Ptr{Float64}, weight::Ptr{Float64}, ids::Ptr{Int64})::Int32)
+        # for iter in 1:n_iter: de.iter = iter + n_initial; groups = stepfun(model, de, groups)   (src/main.jl:33-38)
+        check(h, @ccall LIB.demc_step(h::Ptr{Cvoid}, Int64(1 + de.n_initial)::Int64, Int32(n_iter)::Int32)::Int32)
+        de.iter = n_iter + de.n_initial
+        n_rows = n_iter + de.n_initial
+        th = Array{Float64}(undef, D, P, n_rows); acc = Array{UInt8}(undef, P, n_rows)
+        lp = Array{Float64}(undef, P, n_rows); idh = Array{Int64}(undef, P, n_rows)
+        check(h, @ccall LIB.demc_get_history(h::Ptr{Cvoid}, 0::Int64, Int64(n_rows)::Int64, th::Ptr{Float64}, acc::Ptr{UInt8},
+            lp::Ptr{Float64}, idh::Ptr{Int64})::Int32)
+        # re-key by particle id: samples[iter, :, p.id] (utilities.jl:170-180); accept/lp live on the Particle
+        for r = 1:n_rows, s = 1:P
+            id = idh[s, r] + 1
+            de.samples[r, :, id] = th[:, s, r]            # flat parameters; un-flatten here for nested Θ
+            particles[id].accept[r] = acc[s, r] != 0
+            particles[id].lp[r] = lp[s, r]
+        end
+    finally
+        h != C_NULL && @ccall LIB.demc_destroy(h::Ptr{Cvoid})::Int32
+    end
+    # particles are now ordered by id, so Θ columns and accept/lp agree (fixes the pairing quirk of main.jl:232-239)
+    return bundle_samples(model, de, [particles], n_iter)                   # src/main.jl:222-250, unchanged
+end
+
+end # module

@@ -689,25 +689,38 @@ int32_t orc_select_particle_ref(const double* w, int32_t n, double u) {
 }
 
 /* ------------------------------------------------------------------ selection -- */
-/* Stabilised select_base (SURVEY H5 deviation): softmax(w - max) over the whole group. */
+/* Stabilised select_base (SURVEY H5 deviation): softmax(w - max) over the whole group.
+ * The cumulative weights are formed in a fixed two-level order that a GPU workgroup can reproduce bit for bit:
+ * sequential prefix sums inside chunks of 16, a sequential prefix over the chunk totals, and
+ * cdf[i] = offset[chunk(i)] + prefix[i].  The pick is StatsBase's walk: first i with cdf[i] >= u*total. */
+#define ORC_CDF_CHUNK 16
 static int32_t select_base_stable(const double* w, int32_t n, double u) {
     double wmax = -INFINITY;
     for (int i = 0; i < n; ++i)
         if (w[i] > wmax) wmax = w[i];
-    double total = 0.0;
-    for (int i = 0; i < n; ++i) total += exp(w[i] - wmax);
+    double* cdf = (double*)malloc(sizeof(double) * (size_t)n);
+    double off = 0.0;
+    for (int c0 = 0; c0 < n; c0 += ORC_CDF_CHUNK) {
+        double pre = 0.0;
+        const int c1 = c0 + ORC_CDF_CHUNK < n ? c0 + ORC_CDF_CHUNK : n;
+        for (int i = c0; i < c1; ++i) {
+            pre += exp(w[i] - wmax);
+            cdf[i] = off + pre;
+        }
+        off = off + pre;
+    }
+    const double total = cdf[n - 1];
+    int32_t r;
     if (!(total > 0.0) || !(total < INFINITY)) { /* all -Inf or NaN present: uniform pick */
-        int32_t r = (int32_t)(u * n);
-        return r < n ? r : n - 1;
+        r = (int32_t)(u * n);
+        r = r < n ? r : n - 1;
+    } else {
+        const double t = u * total;
+        r = 0;
+        while (cdf[r] < t && r < n - 1) ++r;
     }
-    const double t = u * total;
-    int32_t i = 0;
-    double cw = exp(w[0] - wmax);
-    while (cw < t && i < n - 1) {
-        ++i;
-        cw += exp(w[i] - wmax);
-    }
-    return i;
+    free(cdf);
+    return r;
 }
 /* Stabilised select_particle: P(j) ~ exp(-(w_j - wmin)); non-finite weights -> argmin (first), like findmin. */
 static int32_t select_particle_stable(const double* w, int32_t n, double u) {

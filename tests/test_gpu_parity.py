@@ -148,8 +148,10 @@ def test_step_parity_blocks(demc, orc):
 def test_step_parity_history_partners(demc, orc, schedule):
     """sample = resample (DE-MC_Z, crossover.jl:113-124) with snooker, as test/multivariate_normal_tests.jl:50-59"""
     prob = make_problem("mvn_iso", np.random.default_rng(14), d=4)
+    # partners come from the engine's own history, which is not teacher-forced and may hold rows accepted from
+    # 1-ulp-different snooker / mutation proposals: proposals are compared to 1e-11, indices stay exact
     teacher_forced(demc, orc, prob, n_iter=10, n_initial=6, n_groups=2, Np=4, schedule=schedule, burnin=5,
-                   theta_snooker=0.3, partner_kind=1, alpha=0.0)
+                   theta_snooker=0.3, partner_kind=1, alpha=0.0, exact_de=False)
 
 
 def test_migration_parity(demc, orc):
@@ -182,6 +184,33 @@ def test_suffstat_mode_matches_streaming(demc, orc):
         vals.append(eng.logpost(th))
         eng.close()
     np.testing.assert_allclose(vals[0], vals[1], rtol=1e-10)
+
+
+@pytest.mark.parametrize("family", ["mvn_full", "mvn_iso"])
+@pytest.mark.parametrize("schedule", [1, 2])
+def test_step_parity_suffstat_fused(demc, orc, family, schedule):
+    """SUFFSTAT likelihood: with two_colour the whole update runs in the fused K1 tail (one launch per colour phase);
+    the oracle still visits every observation"""
+    prob = make_problem(family, np.random.default_rng(21), N=300, d=7)
+    teacher_forced(demc, orc, prob, n_iter=10, n_groups=4, Np=12, schedule=schedule, burnin=5, theta_snooker=0.2,
+                   loglike_mode=1, alpha=0.5)
+
+
+def test_fused_equals_unfused(demc):
+    """the fused tail is an implementation detail: same bits as K1 -> K3"""
+    prob = make_problem("mvn_full", np.random.default_rng(22), N=400, d=10)
+    th0 = prob["init"](6 * 20)
+    hs = []
+    for fuse in (0, 1):
+        e = demc.HipEngine(n_groups=6, Np=20, D=10, n_rows=25, schedule=2, seed=3, loglike_mode=1, fuse=fuse,
+                           theta_snooker=0.1, alpha=0.3, burnin=10)
+        setup_engine(e, prob)
+        e.set_state(th0)
+        e.step(1, 25)
+        hs.append(e.get_history(0, 25) + e.get_state())
+        e.close()
+    for a, b in zip(*hs):
+        assert np.array_equal(a, b)
 
 
 def test_rejects_unsupported(demc):
