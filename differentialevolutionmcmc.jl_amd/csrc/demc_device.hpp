@@ -96,34 +96,7 @@ __device__ inline double softplus(double x) { return x > 0 ? x + log1p(exp(-x)) 
 
 enum Prior : int { PR_FLAT = 0, PR_NORMAL = 1, PR_HALFCAUCHY = 2, PR_UNIFORM = 3, PR_BETA = 4, PR_NORMAL_REF = 5 };
 
-// c is the x-independent part, precomputed on the host by demc_set_priors (prior_const below), which keeps lgamma /
-// atan out of the kernels
-__device__ inline double prior_scalar(int kind, double a, double b, double c, double sref, double x) {
-    switch (kind) {
-        case PR_NORMAL: {
-            const double z = (x - a) / b;
-            return c - 0.5 * (z * z);
-        }
-        case PR_NORMAL_REF:
-            return norm_logpdf(x, a, sref);
-        case PR_HALFCAUCHY: {  // truncated(Cauchy(a,b),0,Inf)  Examples/Gaussian_Example.jl:14
-            if (x < 0.0) return -INFINITY;
-            const double z = (x - a) / b;
-            return c - log1p(z * z);
-        }
-        case PR_UNIFORM:
-            return (x >= a && x <= b) ? c : -INFINITY;
-        case PR_BETA: {
-            if (x < 0.0 || x > 1.0) return -INFINITY;
-            const double t1 = (a == 1.0) ? 0.0 : (a - 1.0) * log(x);
-            const double t2 = (b == 1.0) ? 0.0 : (b - 1.0) * log1p(-x);
-            return t1 + t2 + c;
-        }
-        default:
-            return 0.0;
-    }
-}
-
+// x-independent part of a scalar's log-prior, computed on the host (keeps lgamma / atan out of the kernels)
 inline double prior_const(int kind, double a, double b) {
     switch (kind) {
         case PR_NORMAL:

@@ -39,6 +39,8 @@ struct demc_handle {
     // state
     double *theta = nullptr, *weight = nullptr, *prop = nullptr, *prop_prior = nullptr, *prop_adj = nullptr;
     double *tr_w = nullptr, *partial = nullptr, *aux = nullptr, *lo = nullptr, *hi = nullptr, *pa = nullptr, *pb = nullptr, *pc = nullptr;
+    DimTab* dimtab = nullptr;
+    std::vector<DimTab> h_tab;  // host copy: bounds and priors arrive in separate calls
     double *hist = nullptr, *lp_hist = nullptr, *mig_rows = nullptr, *scratch_theta = nullptr, *scratch_w = nullptr;
     long long* id = nullptr;
     unsigned char *prop_oob = nullptr, *tr_acc = nullptr, *masks = nullptr, *acc_hist = nullptr;
@@ -55,7 +57,7 @@ struct demc_handle {
     int partial_cap = 64;
     int lpp = 1;
     int tile_in_lds = 0;
-    size_t k1_lds = 0;
+    size_t k1_lds = 0, k1_tile_bytes = 0;
     bool bounds_set = false, priors_set = false;
     std::string err;
     // timing
@@ -139,7 +141,7 @@ KParams base_params(demc_handle* h) {
     k.fitness_kind = c.fitness_kind;
     k.theta = h->theta; k.weight = h->weight; k.id = h->id; k.prop = h->prop; k.prop_prior = h->prop_prior;
     k.prop_adj = h->prop_adj; k.prop_oob = h->prop_oob; k.tr_idx = h->tr_idx; k.tr_w = h->tr_w; k.tr_acc = h->tr_acc;
-    k.lo = h->lo; k.hi = h->hi; k.mask = nullptr; k.pk = h->pk; k.pa = h->pa; k.pb = h->pb; k.pc = h->pc; k.pref = h->pref;
+    k.dimtab = h->dimtab; k.mask = nullptr;
     k.hist = h->hist; k.acc_hist = h->acc_hist; k.lp_hist = h->lp_hist; k.id_hist = h->id_hist;
     k.P = h->P; k.store_row = -1; k.tile_in_lds = h->tile_in_lds;
     k.family = h->family; k.N = h->N; k.d = h->d; k.n_acc = h->n_acc; k.n_partials = 1;
@@ -242,8 +244,12 @@ int launch_phase(demc_handle* h, KParams& k) {
     if (n_split > max_split) n_split = max_split;
     if (n_split < 1) n_split = 1;
     k.n_split = n_split;
+    const bool tile = k.tile_in_lds && c.partner_kind == DEMC_PARTNER_CURRENT;
     tick(h, 0, true);
-    hipLaunchKernelGGL(k_propose, dim3(k.n_groups * n_split), dim3(256), h->k1_lds, h->stream, k);
+    if (tile)
+        hipLaunchKernelGGL(k_propose<true>, dim3(k.n_groups * n_split), dim3(256), h->k1_lds, h->stream, k);
+    else
+        hipLaunchKernelGGL(k_propose<false>, dim3(k.n_groups * n_split), dim3(256), h->k1_lds - h->k1_tile_bytes, h->stream, k);
     tick(h, 0, false);
     if (k.fuse_accept) return DEMC_OK;
     int rc = launch_loglike(h, k);
@@ -302,9 +308,11 @@ int size_k1_lds(demc_handle* h) {
     const size_t scr = is_mvn(h->family) ? (size_t)(256 / h->lpp) * (D + 2) * sizeof(double) : 0;
     const size_t tile = (size_t)c.Np * D * sizeof(double);
     h->tile_in_lds = (tile + cdf + ainv + scr <= 96 * 1024) ? 1 : 0;
-    h->k1_lds = (h->tile_in_lds ? tile : 0) + cdf + ainv + scr;
+    h->k1_tile_bytes = h->tile_in_lds ? tile : 0;
+    h->k1_lds = h->k1_tile_bytes + cdf + ainv + scr;
     if (h->k1_lds > 150 * 1024) return fail(h, DEMC_EINVAL, "K1 LDS budget exceeded (Np too large for this D)");
-    HIPCHK(hipFuncSetAttribute((const void*)k_propose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k1_lds));
+    HIPCHK(hipFuncSetAttribute((const void*)k_propose<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k1_lds));
+    HIPCHK(hipFuncSetAttribute((const void*)k_propose<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k1_lds));
     return DEMC_OK;
 }
 
@@ -383,7 +391,7 @@ int32_t demc_create(const demc_config* cfg, demc_handle** out) {
     ALLOC(h->prop_prior, P); ALLOC(h->prop_adj, P); ALLOC(h->prop_oob, P);
     ALLOC(h->tr_idx, P * 4); ALLOC(h->tr_w, P); ALLOC(h->tr_acc, P);
     ALLOC(h->partial, (size_t)h->partial_cap * P); ALLOC(h->aux, P);
-    ALLOC(h->lo, D); ALLOC(h->hi, D); ALLOC(h->pk, D); ALLOC(h->pa, D); ALLOC(h->pb, D); ALLOC(h->pc, D); ALLOC(h->pref, D);
+    ALLOC(h->dimtab, D);
     ALLOC(h->mig_rows, (size_t)c.n_groups_total * (D + 3));
     ALLOC(h->scratch_theta, P * D); ALLOC(h->scratch_w, P);
     if (c.store_history && c.n_rows > 0) {
@@ -393,9 +401,10 @@ int32_t demc_create(const demc_config* cfg, demc_handle** out) {
         ALLOC(h->id_hist, (size_t)c.n_rows * P);
     }
     {
-        std::vector<double> lo(D, -INFINITY), hi(D, INFINITY);
-        HIPCHK(hipMemcpy(h->lo, lo.data(), D * sizeof(double), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(h->hi, hi.data(), D * sizeof(double), hipMemcpyHostToDevice));
+        DimTab t0;
+        t0.lo = -INFINITY; t0.hi = INFINITY; t0.a = 0.0; t0.b = 1.0; t0.c = 0.0; t0.kind = PR_FLAT; t0.ref = 0;
+        h->h_tab.assign(D, t0);
+        HIPCHK(hipMemcpy(h->dimtab, h->h_tab.data(), D * sizeof(DimTab), hipMemcpyHostToDevice));
         std::vector<long long> id(P);
         for (size_t s = 0; s < P; ++s) id[s] = (long long)c.group_offset * c.Np + (long long)s;
         HIPCHK(hipMemcpy(h->id, id.data(), P * sizeof(long long), hipMemcpyHostToDevice));
@@ -420,7 +429,7 @@ int32_t demc_destroy(demc_handle* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     drain_events(h);
     void* ptrs[] = {h->theta, h->weight, h->prop, h->prop_prior, h->prop_adj, h->tr_w, h->partial, h->aux, h->lo, h->hi,
-                    h->pa, h->pb, h->pc, h->hist, h->lp_hist, h->mig_rows, h->scratch_theta, h->scratch_w, h->id, h->prop_oob,
+                    h->pa, h->pb, h->pc, h->dimtab, h->hist, h->lp_hist, h->mig_rows, h->scratch_theta, h->scratch_w, h->id, h->prop_oob,
                     h->tr_acc, h->masks, h->acc_hist, h->tr_idx, h->pk, h->pref, h->id_hist, h->data, h->Ainv, h->Ypad,
                     h->Xf, h->sx};
     for (void* p : ptrs)
@@ -577,29 +586,35 @@ int32_t demc_set_model(demc_handle* h, int32_t family, const double* data, const
 int32_t demc_set_priors(demc_handle* h, const int32_t* kind, const double* a, const double* b, const int32_t* ref) {
     if (!h || !kind) return DEMC_EINVAL;
     const size_t D = (size_t)h->c.D;
-    std::vector<double> va(D, 0.0), vb(D, 1.0), vc(D, 0.0);
-    std::vector<int> vr(D, 0), vk(kind, kind + D);
     for (size_t j = 0; j < D; ++j) {
-        if (vk[j] < 0 || vk[j] > DEMC_PRIOR_NORMAL_REF) return fail(h, DEMC_EUNSUPPORTED, "prior kind not registered");
-        if (a) va[j] = a[j];
-        if (b) vb[j] = b[j];
-        if (ref) vr[j] = ref[j];
-        if (vk[j] == DEMC_PRIOR_NORMAL_REF && (vr[j] < 0 || vr[j] >= (int)D)) return fail(h, DEMC_EINVAL, "prior ref out of range");
+        if (kind[j] < 0 || kind[j] > DEMC_PRIOR_NORMAL_REF) return fail(h, DEMC_EUNSUPPORTED, "prior kind not registered");
+        if (kind[j] == DEMC_PRIOR_NORMAL_REF && (!ref || ref[j] < 0 || ref[j] >= (int)D))
+            return fail(h, DEMC_EINVAL, "prior ref out of range");
     }
-    HIPCHK(hipMemcpy(h->pk, vk.data(), D * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->pa, va.data(), D * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->pb, vb.data(), D * sizeof(double), hipMemcpyHostToDevice));
-    for (size_t j = 0; j < D; ++j) vc[j] = prior_const(vk[j], va[j], vb[j]);
-    HIPCHK(hipMemcpy(h->pc, vc.data(), D * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->pref, vr.data(), D * sizeof(int), hipMemcpyHostToDevice));
+    for (size_t j = 0; j < D; ++j) {
+        DimTab& t = h->h_tab[j];
+        const double aj = a ? a[j] : 0.0, bj = b ? b[j] : 1.0;
+        t.kind = kind[j];
+        t.ref = ref ? ref[j] : 0;
+        t.a = aj;
+        // reciprocal scale for the location-scale families: no FP64 division per scalar in the kernels
+        t.b = (kind[j] == PR_NORMAL || kind[j] == PR_HALFCAUCHY) ? 1.0 / bj : bj;
+        t.c = prior_const(kind[j], aj, bj);
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->dimtab, h->h_tab.data(), D * sizeof(DimTab), hipMemcpyHostToDevice));
     return DEMC_OK;
 }
 
 int32_t demc_set_bounds(demc_handle* h, const double* lo, const double* hi) {
     if (!h || !lo || !hi) return DEMC_EINVAL;
     const size_t D = (size_t)h->c.D;
-    HIPCHK(hipMemcpy(h->lo, lo, D * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->hi, hi, D * sizeof(double), hipMemcpyHostToDevice));
+    for (size_t j = 0; j < D; ++j) {
+        h->h_tab[j].lo = lo[j];
+        h->h_tab[j].hi = hi[j];
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->dimtab, h->h_tab.data(), D * sizeof(DimTab), hipMemcpyHostToDevice));
     return DEMC_OK;
 }
 

@@ -25,6 +25,16 @@ enum Family : int {
 };
 enum Mode : int { MODE_STEP = 0, MODE_IDENT = 1 };  // IDENT: theta' = theta, always accepted (init / logpost)
 
+// Per-scalar constants, packed so that one dimension costs three 16-byte loads: bounds (de.bounds flattened) and
+// the prior entry (model.prior_loglike as data).  b = 1/scale for Normal / half-Cauchy; c = the x-independent
+// part of the log-density (prior_const()).
+struct DimTab {
+    double lo, hi;
+    double a, b;
+    double c;
+    int kind, ref;
+};
+
 // Everything a sweep needs, passed by value as the kernarg.
 struct KParams {
     // geometry
@@ -50,14 +60,8 @@ struct KParams {
     int* tr_idx;          // [P][4]
     double* tr_w;         // [P]
     unsigned char* tr_acc;  // [P]
-    const double* lo;
-    const double* hi;
+    const DimTab* dimtab;       // [D] bounds + prior of every scalar, packed
     const unsigned char* mask;  // [D] or null
-    const int* pk;
-    const double* pa;
-    const double* pb;
-    const double* pc;     // per-scalar prior normalisation constant, precomputed on the host
-    const int* pref;
     // history (slot keyed)
     double* hist;             // [rows][P][D]
     unsigned char* acc_hist;  // [rows][P]
@@ -126,30 +130,76 @@ __device__ inline double loglike_from_stats(const KParams& p, double s, double a
 }
 
 // mh_update! / maximize! / minimize! decision for one particle (utilities.jl:55-58, 201-226)
-__device__ inline int decide(const KParams& p, uint32_t eslot, double wp, double w, double adj) {
+// ra = Philox block 3 of the particle's PART stream (the accept uniform)
+__device__ inline int decide(const KParams& p, const U4& ra, double wp, double w, double adj) {
     if (p.mode == MODE_IDENT) return 1;
     if (p.update_kind == 1) return wp > w;
     if (p.update_kind == 2) return wp < w;
-    const U4 r = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 3);
-    const double u = u53(r.x, r.y);
+    const double u = u53(ra.x, ra.y);
     const double e = exp(wp - w + adj);  // min(1, NaN) = NaN in Julia -> `rand() <= NaN` is false -> reject
     return (e >= 1.0) || (u <= e);
 }
 
 // ------------------------------------------------------------------------------------------------
 // K1: proposals.  grid = n_groups x n_split workgroups; workgroup (g, sp) proposes for a slice of the
-// active particles of group g.  Partner rows come from the group tile staged in LDS when it fits
-// (Np*D*8 bytes), else from theta in HBM/L2 -- either way a phase-start snapshot: in the unfused path
-// theta is only written by K3, and in the fused path (two_colour) a phase writes active rows only while
-// partners come from the other colour.
+// active particles of group g.  TILE = true: the group tile [Np][D] is staged in LDS and every partner /
+// base / current row is read from there (partner rows never re-read HBM); TILE = false (tile too large, or
+// history partners): rows come from theta / hist in HBM-L2.  Either way a phase-start snapshot: in the
+// unfused path theta is only written by K3, and in the fused path (two_colour) a phase writes active rows only
+// while partners come from the other colour.
+//
+// Instruction economy (the kernel is issue-bound, not bandwidth-bound, at D = 32):
+//   - the per-particle Philox blocks (snooker/base, indices, gammas, accept, history cells) are evaluated ONCE per
+//     sub-group: lane b of the sub-group computes block b, the words are handed out with shuffles;
+//   - one noise block per lane covers its two dims; per-dimension constants come packed in one 48-byte DimTab;
+//   - no FP64 division in the per-dimension path (reciprocal scales are precomputed on the host).
 //
 // Optional fused tails (uniform flags, no divergence):
-//   fuse_prep   (MvNormal families): y = A^-1 theta' and a = theta'.y from an LDS copy of theta' and A^-1
-//               (replaces a separate preparation kernel); SUFFSTAT mode also forms S = y . sum_i x_i here.
+//   fuse_prep   (MvNormal families): y = A^-1 theta' and a = theta'.y from an LDS copy of theta' and A^-1;
+//               SUFFSTAT mode also forms S = y . sum_i x_i here.
 //   fuse_accept (likelihoods that are O(D^2) given data-only statistics, two_colour schedule): finishes the
 //               whole update -- prior + loglike, Metropolis accept, theta/weight write-back and the history
 //               row -- so that one launch per colour phase is the entire DE-MCMC sweep.
 // ------------------------------------------------------------------------------------------------
+__device__ inline U4 shfl_u4(const U4& v, int src) {
+    U4 r;
+    r.x = (uint32_t)__shfl((int)v.x, src);
+    r.y = (uint32_t)__shfl((int)v.y, src);
+    r.z = (uint32_t)__shfl((int)v.z, src);
+    r.w = (uint32_t)__shfl((int)v.w, src);
+    return r;
+}
+
+// x-dependent part of one scalar's log-prior; DimTab.b holds 1/scale for Normal / half-Cauchy
+__device__ inline double prior_term(const DimTab& t, double x, double inv_sref, double log_sref) {
+    switch (t.kind) {
+        case PR_NORMAL: {
+            const double z = (x - t.a) * t.b;
+            return t.c - 0.5 * (z * z);
+        }
+        case PR_NORMAL_REF: {
+            const double z = (x - t.a) * inv_sref;
+            return -(z * z + kLog2Pi) / 2.0 - log_sref;
+        }
+        case PR_HALFCAUCHY: {
+            if (x < 0.0) return -INFINITY;
+            const double z = (x - t.a) * t.b;
+            return t.c - log1p(z * z);
+        }
+        case PR_UNIFORM:
+            return (x >= t.a && x <= t.b) ? t.c : -INFINITY;
+        case PR_BETA: {
+            if (x < 0.0 || x > 1.0) return -INFINITY;
+            const double t1 = (t.a == 1.0) ? 0.0 : (t.a - 1.0) * log(x);
+            const double t2 = (t.b == 1.0) ? 0.0 : (t.b - 1.0) * log1p(-x);
+            return t1 + t2 + t.c;
+        }
+        default:
+            return 0.0;
+    }
+}
+
+template <bool TILE>
 __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     extern __shared__ double lds[];
     __shared__ double s_red[4];
@@ -158,13 +208,14 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     const int g = blockIdx.x / p.n_split, sp = blockIdx.x % p.n_split;
     const int g_glob = p.group_offset + g;
     const int D = p.D, Np = p.Np, d = p.d;
+    const bool even = (D & 1) == 0;
     const double* grows = p.theta + (size_t)g * Np * D;
     const double* gw = p.weight + (size_t)g * Np;
     const int lpp = p.lpp;
     const int ppp = 256 / lpp;  // particles per pass
-    // LDS carve-up (host computes the same sizes): tile | cdf | A^-1 | theta' scratch
+    // LDS carve-up (host computes the same sizes): tile | cdf + chunk totals | A^-1 | theta' scratch
     double* tile = lds;
-    double* cdf = tile + (p.tile_in_lds ? (size_t)Np * D : 0);
+    double* cdf = tile + (TILE ? (size_t)Np * D : 0);
     double* ainv_s = cdf + Np + ((Np + 15) >> 4);
     const int scr_stride = D + 2;
     double* scr = ainv_s + ((p.fuse_prep && p.Ainv) ? (size_t)d * d : 0);
@@ -176,27 +227,31 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     }
     const bool de_any = (p.mode == MODE_STEP) && !is_mut;
     const bool use_base = de_any && p.proposal_kind == 0 && p.iter <= p.burnin;  // crossover.jl:164
+    const bool hist_partners = !TILE && p.partner_kind == 1;
 
-    const double* rows = grows;
-    if (p.tile_in_lds && de_any && p.partner_kind == 0) {
-        for (int i = tid; i < Np * D; i += 256) tile[i] = grows[i];
-        rows = tile;
+    if (TILE) {
+        if (even) {
+            const double2* src = reinterpret_cast<const double2*>(grows);
+            double2* dst = reinterpret_cast<double2*>(tile);
+            for (int i = tid; i < (Np * D) >> 1; i += 256) dst[i] = src[i];
+        } else
+            for (int i = tid; i < Np * D; i += 256) tile[i] = grows[i];
     }
+    const double* rows = TILE ? (const double*)tile : grows;
     if (p.fuse_prep && p.Ainv)
         for (int i = tid; i < d * d; i += 256) ainv_s[i] = p.Ainv[i];
     if (use_base) {
-        // select_base (crossover.jl:282-289), stabilised: e_j = exp(w_j - max w); sequential prefix sum so
-        // that the walk "first i with cumsum >= u*total" matches the CPU oracle exactly.
+        // select_base (crossover.jl:282-289), stabilised: e_j = exp(w_j - max w); cumulative weights in a fixed
+        // two-level order (same as the oracle): sequential inside chunks of 16, sequential over the chunk totals,
+        // cdf[i] = offset[chunk] + prefix[i]
         double m = -INFINITY;
         for (int i = tid; i < Np; i += 256) m = fmax(m, gw[i]);
         for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
         if ((tid & 63) == 0) s_red[tid >> 6] = m;
         __syncthreads();
         m = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
-        // two-level prefix in a fixed order (same as the oracle): sequential inside chunks of 16, sequential over
-        // the chunk totals, cdf[i] = offset[chunk] + prefix[i]
         const int n_chunk = (Np + 15) >> 4;
-        double* ctot = cdf + Np;  // [n_chunk] chunk totals, then exclusive offsets
+        double* ctot = cdf + Np;
         for (int c = tid; c < n_chunk; c += 256) {
             double pre = 0.0;
             const int i1 = (c * 16 + 16 < Np) ? c * 16 + 16 : Np;
@@ -223,11 +278,13 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     __syncthreads();
 
     const int sub = tid / lpp, sl = tid % lpp;
+    const int sub_base = (tid & 63) & ~(lpp - 1);  // lane 0 of this sub-group inside its wave
     const int per_split = (p.n_act + p.n_split - 1) / p.n_split;
     const int q_lo = sp * per_split;
     const int q_hi = (q_lo + per_split < p.n_act) ? q_lo + per_split : p.n_act;
     const int n_pass = (q_hi - q_lo + ppp - 1) / ppp;
-    const double eps = p.eps;
+    const double eps = p.eps, eps2 = p.eps - (-p.eps);
+    const int nblk = hist_partners ? 6 : 4;
 
     for (int pass = 0; pass < n_pass; ++pass) {
         const int q = q_lo + pass * ppp + sub;
@@ -236,6 +293,31 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
         const size_t slot = (size_t)g * Np + pl;
         const uint32_t eslot = (uint32_t)g_glob * (uint32_t)Np + (uint32_t)pl;
         const double* pt = rows + (size_t)pl * D;
+
+        // per-particle Philox blocks: lane b of the sub-group evaluates block b (when the sub-group is wide enough)
+        U4 r0 = {0, 0, 0, 0}, ri = r0, rg = r0, ra = r0, h4 = r0, h5 = r0;
+        if (p.mode == MODE_STEP) {
+            if (lpp >= nblk) {
+                const U4 mine = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)(sl < nblk ? sl : 0));
+                r0 = shfl_u4(mine, sub_base + 0);
+                ri = shfl_u4(mine, sub_base + 1);
+                rg = shfl_u4(mine, sub_base + 2);
+                ra = shfl_u4(mine, sub_base + 3);
+                if (hist_partners) {
+                    h4 = shfl_u4(mine, sub_base + 4);
+                    h5 = shfl_u4(mine, sub_base + 5);
+                }
+            } else {
+                r0 = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 0);
+                ri = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 1);
+                rg = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 2);
+                ra = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 3);
+                if (hist_partners) {
+                    h4 = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 4);
+                    h5 = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 5);
+                }
+            }
+        }
 
         int kind = 3;  // 0 DE, 1 snooker, 2 mutation, 3 identity
         int i0 = -1, i1 = -1, i2 = -1;
@@ -246,17 +328,12 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             if (is_mut)
                 kind = 2;
             else {
-                const U4 r0 = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 0);
-                const U4 ri = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 1);
-                const U4 rg = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 2);
                 const double u_snk = u53(r0.x, r0.y), u_base = u53(r0.z, r0.w);
                 const double u_g1 = u53(rg.x, rg.y), u_g2 = u53(rg.z, rg.w);
                 const bool snooker = u_snk <= p.theta_snooker;  // crossover.jl:31
                 kind = snooker ? 1 : 0;
-                if (p.partner_kind == 1) {
+                if (hist_partners) {
                     // resample (crossover.jl:113-124): distinct cells of rows 1:(iter-1) x local particles
-                    const U4 h4 = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 4);
-                    const U4 h5 = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 5);
                     const uint64_t hd0 = ((uint64_t)h4.y << 32) | h4.x, hd1 = ((uint64_t)h4.w << 32) | h4.z,
                                    hd2 = ((uint64_t)h5.y << 32) | h5.x;
                     const uint64_t ub = (uint64_t)(p.iter - 1), M = ub * (uint64_t)p.P;
@@ -337,78 +414,115 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             }
         }
 
-        // proposal value of scalar j, after recombination! and reset!
-        auto value = [&](int j) -> double {
-            const double tj = pt[j];
-            if (kind == 3) return tj;
-            const int k = j >> 1;
-            const U4 nz = draw_block(p.seed, S_NOISE, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)k);
-            double v;
-            if (kind == 2) {  // pt + Normal(0, sigma): mutation.jl:15-18 (block mask ignored, main.jl:205)
-                const double u1 = u53(nz.x, nz.y), u2 = u53(nz.z, nz.w);
-                const double rad = sqrt(-2.0 * log(1.0 - u1));
-                double sn, cs;
-                sincospi(2.0 * u2, &sn, &cs);  // Box-Muller angle 2*pi*u2
-                return tj + p.sigma * (rad * ((j & 1) ? sn : cs));
-            }
-            const double uu = (j & 1) ? u53(nz.z, nz.w) : u53(nz.x, nz.y);
-            const double bj = -eps + (eps - (-eps)) * uu;  // b = Uniform(-eps, eps) crossover.jl:166
+        // crossover / snooker value of scalar j given its uniform (before recombination! / reset!)
+        auto cross = [&](int j, double tj, double uu) -> double {
+            const double bj = -eps + eps2 * uu;  // b = Uniform(-eps, eps) crossover.jl:166
             if (kind == 1) {  // (Pt + gamma*(Pr1 - Pr2)) + b  crossover.jl:253
                 const double dj = tj - Pa[j];
                 const double t1 = dj * cm - dj * cn;
-                v = (tj + t1 * g1) + bj;
-            } else {  // ((Pt + g1*(Pm-Pn)) + g2*(Pb-Pt)) + b  crossover.jl:168
-                const double t1 = Pa[j] - Pb2[j];
-                double t6 = tj + t1 * g1;
-                if (base_on) {
-                    const double t4 = Pbase[j] - tj;
-                    t6 = t6 + t4 * g2;
-                }
-                v = t6 + bj;
+                return (tj + t1 * g1) + bj;
             }
+            // ((Pt + g1*(Pm-Pn)) + g2*(Pb-Pt)) + b  crossover.jl:168
+            const double t1 = Pa[j] - Pb2[j];
+            double t6 = tj + t1 * g1;
+            if (base_on) {
+                const double t4 = Pbase[j] - tj;
+                t6 = t6 + t4 * g2;
+            }
+            return t6 + bj;
+        };
+        // both scalars {2k, 2k+1} of one noise block, after recombination! and reset!
+        auto value_pair = [&](int k, double& v0, double& v1) {
+            const int j0 = 2 * k, j1 = j0 + 1;
+            const bool has1 = j1 < D;
+            double t0, t1 = 0.0;
+            if (even) {
+                const double2 t = *reinterpret_cast<const double2*>(pt + j0);
+                t0 = t.x; t1 = t.y;
+            } else {
+                t0 = pt[j0];
+                if (has1) t1 = pt[j1];
+            }
+            v0 = t0; v1 = t1;
+            if (kind == 3) return;
+            const U4 nz = draw_block(p.seed, S_NOISE, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)k);
+            const double u0 = u53(nz.x, nz.y), u1 = u53(nz.z, nz.w);
+            if (kind == 2) {  // pt + Normal(0, sigma): mutation.jl:15-18 (block mask ignored, main.jl:205)
+                const double rad = sqrt(-2.0 * log(1.0 - u0));
+                double sn, cs;
+                sincospi(2.0 * u1, &sn, &cs);  // Box-Muller angle 2*pi*u1
+                v0 = t0 + p.sigma * (rad * cs);
+                v1 = t1 + p.sigma * (rad * sn);
+                return;
+            }
+            v0 = cross(j0, t0, u0);
+            if (has1) v1 = cross(j1, t1, u1);
             if (p.kappa != 1.0) {  // recombination! crossover.jl:301-312
                 const U4 rc = draw_block(p.seed, S_RECOMB, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)k);
-                const double ur = (j & 1) ? u53(rc.z, rc.w) : u53(rc.x, rc.y);
-                if (ur <= 1.0 - p.kappa) v = tj;
+                if (u53(rc.x, rc.y) <= 1.0 - p.kappa) v0 = t0;
+                if (u53(rc.z, rc.w) <= 1.0 - p.kappa) v1 = t1;
             }
-            if (p.mask && !p.mask[j]) v = tj;  // reset! crossover.jl:336-352
-            return v;
+            if (p.mask) {  // reset! crossover.jl:336-352
+                if (!p.mask[j0]) v0 = t0;
+                if (has1 && !p.mask[j1]) v1 = t1;
+            }
         };
 
         int oob = 0;
         double prior = 0.0, s1 = 0.0, s2 = 0.0;
         int ref_cached = -1;
-        double sref = 0.0;
-        for (int k = sl; 2 * k < D; k += lpp)
-            for (int e = 0; e < 2; ++e) {
-                const int j = 2 * k + e;
-                if (j < D) {
-                    const double v = value(j);
-                    if (kind == 1) {  // adjust_loglike norms (crossover.jl:268-273)
-                        const double a = v - Pa[j], b = pt[j] - Pa[j];
-                        s1 += a * a; s2 += b * b;
-                    }
-                    oob |= !(v >= p.lo[j] && v <= p.hi[j]);  // in_bounds utilities.jl:70-78 (NaN fails)
-                    if (p.fitness_kind == 0) {
-                        const int pk = p.pk[j];
-                        if (pk != PR_FLAT) {
-                            if (pk == PR_NORMAL_REF && p.pref[j] != ref_cached) {
-                                ref_cached = p.pref[j];
-                                sref = value(ref_cached);
-                            }
-                            prior += prior_scalar(pk, p.pa[j], p.pb[j], p.pc[j], sref, v);
-                        }
-                    }
-                    if (valid && p.write_prop) p.prop[slot * D + j] = v;
-                    if (p.fuse_prep) scr[sub * scr_stride + j] = v;
+        double inv_sref = 0.0, log_sref = 0.0;
+        for (int k = sl; 2 * k < D; k += lpp) {
+            const int j0 = 2 * k;
+            const bool has1 = j0 + 1 < D;
+            double v0, v1;
+            value_pair(k, v0, v1);
+            if (kind == 1) {  // adjust_loglike norms (crossover.jl:268-273)
+                const double a0 = v0 - Pa[j0], b0 = pt[j0] - Pa[j0];
+                s1 += a0 * a0; s2 += b0 * b0;
+                if (has1) {
+                    const double a1 = v1 - Pa[j0 + 1], b1 = pt[j0 + 1] - Pa[j0 + 1];
+                    s1 += a1 * a1; s2 += b1 * b1;
                 }
             }
+            for (int e = 0; e < 2; ++e) {
+                if (e == 1 && !has1) break;
+                const double v = e ? v1 : v0;
+                const DimTab t = p.dimtab[j0 + e];
+                oob |= !(v >= t.lo && v <= t.hi);  // in_bounds utilities.jl:70-78 (NaN fails)
+                if (p.fitness_kind == 0 && t.kind != PR_FLAT) {
+                    if (t.kind == PR_NORMAL_REF && t.ref != ref_cached) {
+                        ref_cached = t.ref;
+                        double r0v, r1v;
+                        value_pair(ref_cached >> 1, r0v, r1v);
+                        const double sref = (ref_cached & 1) ? r1v : r0v;
+                        inv_sref = 1.0 / sref;
+                        log_sref = log(sref);
+                    }
+                    prior += prior_term(t, v, inv_sref, log_sref);
+                }
+            }
+            if (valid && p.write_prop) {
+                if (even)
+                    *reinterpret_cast<double2*>(p.prop + slot * D + j0) = make_double2(v0, v1);
+                else {
+                    p.prop[slot * D + j0] = v0;
+                    if (has1) p.prop[slot * D + j0 + 1] = v1;
+                }
+            }
+            if (p.fuse_prep) {
+                scr[sub * scr_stride + j0] = v0;
+                if (has1) scr[sub * scr_stride + j0 + 1] = v1;
+            }
+        }
         prior = subgroup_sum(prior, lpp);
-        s1 = subgroup_sum(s1, lpp);
-        s2 = subgroup_sum(s2, lpp);
         oob = subgroup_sum(oob, lpp);
-        // (d-1)(log|a| - log|b|): stable form of log(|a|^(d-1)/|b|^(d-1))  crossover.jl:268-273
-        const double adj = (kind == 1) ? (double)(D - 1) * (0.5 * log(s1) - 0.5 * log(s2)) : 0.0;
+        double adj = 0.0;
+        if (kind == 1) {  // (d-1)(log|a| - log|b|): stable form of log(|a|^(d-1)/|b|^(d-1))  crossover.jl:268-273
+            s1 = subgroup_sum(s1, lpp);
+            s2 = subgroup_sum(s2, lpp);
+            adj = (double)(D - 1) * (0.5 * log(s1) - 0.5 * log(s2));
+        }
 
         double aux = 0.0, S = 0.0;
         if (p.fuse_prep) {
@@ -422,11 +536,15 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
                 const int c0 = 2 * k, c1 = 2 * k + 1;
                 double y0 = 0.0, y1 = 0.0;
                 if (p.Ainv) {
-                    for (int j = 0; j < d; ++j) {
-                        const double t = th[j];
-                        y0 = fma(ainv_s[j * d + c0], t, y0);  // A^-1 is symmetric: column c == row c
-                        if (c1 < d) y1 = fma(ainv_s[j * d + c1], t, y1);
-                    }
+                    if (c1 < d) {
+#pragma unroll 4
+                        for (int j = 0; j < d; ++j) {
+                            const double t = th[j];
+                            y0 = fma(ainv_s[j * d + c0], t, y0);  // A^-1 is symmetric: column c == row c
+                            y1 = fma(ainv_s[j * d + c1], t, y1);
+                        }
+                    } else
+                        for (int j = 0; j < d; ++j) y0 = fma(ainv_s[j * d + c0], th[j], y0);
                 } else {
                     y0 = th[c0];
                     if (c1 < d) y1 = th[c1];
@@ -469,48 +587,48 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
         }
 
         // ---- fused tail: compute_posterior! + mh_update! + store_samples! for this particle ----
-        int acc = 0;
-        if (sl == 0) {
-            const double w = gw[pl];
-            const double sg = (p.family == FAM_MVN_ISO) ? scr[sub * scr_stride + d] : 0.0;
-            double wp;
-            if (p.fitness_kind == 1)
-                wp = oob ? (p.update_kind == 1 ? -INFINITY : INFINITY) : loglike_from_stats(p, S, aux, sg);
-            else
-                wp = oob ? -INFINITY : prior + loglike_from_stats(p, S, aux, sg);
-            acc = decide(p, eslot, wp, w, adj);
-            if (valid) {
-                if (acc) p.weight[slot] = wp;
-                if (p.trace) {
-                    p.tr_idx[slot * 4 + 0] = kind; p.tr_idx[slot * 4 + 1] = i0;
-                    p.tr_idx[slot * 4 + 2] = i1; p.tr_idx[slot * 4 + 3] = i2;
-                    p.tr_w[slot] = wp; p.tr_acc[slot] = (unsigned char)acc; p.prop_adj[slot] = adj;
+        const double w = gw[pl];
+        const double sg = (p.family == FAM_MVN_ISO) ? scr[sub * scr_stride + d] : 0.0;
+        double wp;
+        if (p.fitness_kind == 1)
+            wp = oob ? (p.update_kind == 1 ? -INFINITY : INFINITY) : loglike_from_stats(p, S, aux, sg);
+        else
+            wp = oob ? -INFINITY : prior + loglike_from_stats(p, S, aux, sg);
+        const int acc = decide(p, ra, wp, w, adj);  // every lane of the sub-group holds the same inputs
+        if (sl == 0 && valid) {
+            if (acc) p.weight[slot] = wp;
+            if (p.trace) {
+                p.tr_idx[slot * 4 + 0] = kind; p.tr_idx[slot * 4 + 1] = i0;
+                p.tr_idx[slot * 4 + 2] = i1; p.tr_idx[slot * 4 + 3] = i2;
+                p.tr_w[slot] = wp; p.tr_acc[slot] = (unsigned char)acc; p.prop_adj[slot] = adj;
+            }
+            if (p.store_row >= 0) {
+                const size_t hrow = (size_t)p.store_row * p.P + slot;
+                if (p.update_kind == 0 && p.mode == MODE_STEP) {  // utilities.jl:207-208
+                    p.acc_hist[hrow] = (unsigned char)acc;
+                    p.lp_hist[hrow] = acc ? wp : w;
                 }
-                if (p.store_row >= 0) {
-                    const size_t hrow = (size_t)p.store_row * p.P + slot;
-                    if (p.update_kind == 0 && p.mode == MODE_STEP) {  // utilities.jl:207-208
-                        p.acc_hist[hrow] = (unsigned char)acc;
-                        p.lp_hist[hrow] = acc ? wp : w;
-                    }
-                    p.id_hist[hrow] = (int)p.id[slot];
-                }
+                p.id_hist[hrow] = (int)p.id[slot];
             }
         }
-        acc = __shfl(acc, (tid & 63) & ~(lpp - 1));
         if (valid) {
             double* trow = p.theta + slot * D;
             double* hrow = (p.store_row >= 0) ? p.hist + ((size_t)p.store_row * p.P + slot) * D : nullptr;
             const double* th = scr + sub * scr_stride;
             if (acc || hrow)
-                for (int k = sl; 2 * k < D; k += lpp)
-                    for (int e = 0; e < 2; ++e) {
-                        const int j = 2 * k + e;
-                        if (j < D) {
-                            const double v = acc ? th[j] : pt[j];
-                            if (acc) trow[j] = v;  // current.theta = proposal.theta utilities.jl:204
-                            if (hrow) hrow[j] = v;  // samples[iter, :, id] = theta utilities.jl:170-180
-                        }
+                for (int k = sl; 2 * k < D; k += lpp) {
+                    const int j0 = 2 * k;
+                    const bool has1 = j0 + 1 < D;
+                    const double v0 = acc ? th[j0] : pt[j0];
+                    const double v1 = has1 ? (acc ? th[j0 + 1] : pt[j0 + 1]) : 0.0;
+                    if (even) {
+                        if (acc) *reinterpret_cast<double2*>(trow + j0) = make_double2(v0, v1);  // utilities.jl:204
+                        if (hrow) *reinterpret_cast<double2*>(hrow + j0) = make_double2(v0, v1);  // utilities.jl:170-180
+                    } else {
+                        if (acc) { trow[j0] = v0; if (has1) trow[j0 + 1] = v1; }
+                        if (hrow) { hrow[j0] = v0; if (has1) hrow[j0 + 1] = v1; }
                     }
+                }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();  // scratch rows are reused by the same sub-group in the next pass
@@ -774,7 +892,8 @@ __global__ __launch_bounds__(256) void k_accept_store(KParams p) {
         else  // compute_posterior! utilities.jl:92-99
             wp = oob ? -INFINITY : p.prop_prior[slot] + finalize_loglike(p, slot);
         const uint32_t eslot = (uint32_t)(p.group_offset + g) * (uint32_t)p.Np + (uint32_t)pl;
-        acc = decide(p, eslot, wp, w, p.prop_adj[slot]);  // mh_update! / maximize! / minimize!
+        const U4 ra = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 3);
+        acc = decide(p, ra, wp, w, p.prop_adj[slot]);  // mh_update! / maximize! / minimize!
         w_new = acc ? wp : w;
         if (acc) p.weight[slot] = wp;
         if (p.trace) {
