@@ -104,9 +104,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible and there is no CPU fallback")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("DEMC_FORCE_DIST") == "1":  # the latter: exercise the RCCL path with one rank
         import torch.distributed as dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         dist_.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         dist = dist_
 

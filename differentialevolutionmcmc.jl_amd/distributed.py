@@ -21,7 +21,7 @@ class ShardedDriver:
         import torch
         self.torch = torch
         self.eng = engine
-        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.dist = dist if (dist is not None and dist.is_initialized()) else None
         self.world = self.dist.get_world_size() if self.dist else 1
         self.device = device if device is not None else torch.device("cpu")
         G, D = engine.cfg.n_groups, engine.cfg.D

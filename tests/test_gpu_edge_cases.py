@@ -1,0 +1,124 @@
+"""Edge cases of the hot path, HIP vs oracle (same harness as test_gpu_parity): ragged shapes (odd D, odd Np, N not a
+multiple of the 16-observation MFMA tile, d not a multiple of the 4-dim k-step, D beyond one sub-group pass), degenerate
+sampler settings, and the domain's "nulls": out-of-bounds particles (-Inf weights), NaN proposals (snooker drawing
+itself as Pz in the reference schedules, crossover.jl:241), groups whose weights are all -Inf."""
+import numpy as np
+import pytest
+
+from conftest import make_problem, setup_engine
+from test_gpu_parity import teacher_forced
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N,d", [(5, 1), (17, 3), (100, 4), (333, 7), (64, 33), (50, 64)])
+def test_mvn_full_ragged_shapes(demc, orc, N, d):
+    prob = make_problem("mvn_full", np.random.default_rng(100 + d), N=N, d=d)
+    teacher_forced(demc, orc, prob, n_iter=4, n_groups=3, Np=9, schedule=2, burnin=2, check_hist=False)
+
+
+@pytest.mark.parametrize("Np", [4, 5, 7, 33, 600])
+def test_odd_and_large_group_sizes(demc, orc, Np):
+    prob = make_problem("gaussian", np.random.default_rng(7))
+    teacher_forced(demc, orc, prob, n_iter=5, n_groups=2, Np=Np, schedule=2, burnin=3, alpha=0.5, check_hist=Np < 100)
+
+
+def test_dimension_beyond_one_subgroup_pass(demc, orc):
+    """D = 302 > 128: every lane owns several {2k,2k+1} pairs; hierarchical prior refers to theta[1]"""
+    prob = make_problem("hier_binomial", np.random.default_rng(8), S=300)
+    teacher_forced(demc, orc, prob, n_iter=4, n_groups=2, Np=6, schedule=2, burnin=2, theta_snooker=0.3, kappa=0.8,
+                   check_hist=False)
+
+
+def test_single_group_forces_alpha_zero(demc, orc):
+    prob = make_problem("mvn_iso", np.random.default_rng(9), d=3)
+    teacher_forced(demc, orc, prob, n_iter=8, n_groups=1, Np=8, schedule=1, burnin=4, alpha=0.9)
+
+
+def test_two_groups_always_swap(demc, orc):
+    prob = make_problem("binomial", np.random.default_rng(10))
+    teacher_forced(demc, orc, prob, n_iter=10, n_groups=2, Np=6, schedule=2, burnin=5, alpha=1.0)
+
+
+@pytest.mark.parametrize("kw", [dict(kappa=0.0), dict(eps=0.0), dict(beta=1.0), dict(beta=0.0, alpha=0.0),
+                                dict(theta_snooker=1.0), dict(sigma=0.0, beta=1.0)])
+def test_degenerate_sampler_settings(demc, orc, kw):
+    """kappa = 0: every scalar is reset (proposal == current, always accepted); beta = 1: mutation only;
+    theta_snooker = 1: snooker only"""
+    prob = make_problem("mvn_iso", np.random.default_rng(11), d=4)
+    teacher_forced(demc, orc, prob, n_iter=6, n_groups=3, Np=8, schedule=2, burnin=3, **kw)
+
+
+def test_snooker_drawing_itself_gives_nan_proposal_and_is_rejected(demc, orc):
+    """reference schedules draw Pz from the whole group incl. Pt (crossover.jl:241): Pd = 0 -> NaN -> out of bounds ->
+    weight -Inf -> rejected.  Np = 4 and theta_snooker = 1 makes it frequent."""
+    prob = make_problem("gaussian", np.random.default_rng(12))
+    rng = np.random.default_rng(99)
+    eng = demc.HipEngine(n_groups=8, Np=4, D=2, n_rows=6, schedule=1, theta_snooker=1.0, seed=5)
+    o = orc.Oracle(n_groups=8, Np=4, D=2, n_rows=6, schedule=1, theta_snooker=1.0, seed=5)
+    setup_engine(eng, prob)
+    setup_engine(o, prob)
+    eng.set_state(prob["init"](32))
+    n_nan = 0
+    for it in range(1, 7):
+        th, w, ids = eng.get_state()
+        o.set_state(th, w, ids)
+        eng.step(it, 1)
+        o.step(it, 1)
+        tg, to = eng.get_trace(), o.get_trace()
+        assert np.array_equal(tg["idx"], to["idx"])
+        nan_rows = np.isnan(to["proposal"]).any(1)
+        assert np.array_equal(np.isnan(tg["proposal"]).any(1), nan_rows)
+        assert np.all(tg["w_prop"][nan_rows] == -np.inf) and not tg["accepted"][nan_rows].any()
+        assert np.array_equal(tg["accepted"], to["accepted"])
+        n_nan += int(nan_rows.sum())
+    assert n_nan > 10
+    eng.close()
+
+
+def test_out_of_bounds_particles_and_all_minus_inf_group(demc, orc):
+    """particles that start out of bounds have weight -Inf (utilities.jl:92-99); a group whose weights are all -Inf makes
+    the select_base softmax degenerate (uniform fallback) and the migration pick fall back to argmin"""
+    prob = make_problem("gaussian", np.random.default_rng(13))
+    G, Np = 4, 6
+    th0 = prob["init"](G * Np)
+    th0[:Np, 1] = -1.0          # whole group 0 out of bounds (sigma < 0)
+    th0[Np + 1, 1] = -2.0       # one particle of group 1
+    cfg = dict(n_groups=G, Np=Np, D=2, n_rows=8, schedule=2, burnin=8, alpha=1.0, seed=3)
+    eng, o = demc.HipEngine(**cfg), orc.Oracle(**cfg)
+    setup_engine(eng, prob)
+    setup_engine(o, prob)
+    eng.set_state(th0)
+    _, w, _ = eng.get_state()
+    assert np.all(w[:Np] == -np.inf) and w[Np + 1] == -np.inf and np.isfinite(w[Np:]).sum() == 3 * Np - 1
+    for it in range(1, 9):
+        th, w, ids = eng.get_state()
+        o.set_state(th, w, ids)
+        eng.step(it, 1)
+        o.step(it, 1)
+        tg, to = eng.get_trace(), o.get_trace()
+        assert np.array_equal(tg["idx"], to["idx"])
+        np.testing.assert_allclose(tg["proposal"], to["proposal"], rtol=1e-11, atol=1e-13)
+        assert np.array_equal(tg["accepted"], to["accepted"])
+        sg, so = eng.get_state(), o.get_state()
+        assert np.array_equal(sg[2], so[2])
+        assert np.array_equal(np.isfinite(sg[1]), np.isfinite(so[1]))
+    # -Inf -> finite is always accepted, so the dead group comes back to life
+    assert np.isfinite(eng.get_state()[1]).all()
+    eng.close()
+
+
+def test_zero_iterations_and_history_bounds(demc):
+    prob = make_problem("gaussian", np.random.default_rng(14))
+    eng = demc.HipEngine(n_groups=2, Np=4, D=2, n_rows=3, schedule=1)
+    setup_engine(eng, prob)
+    eng.set_state(prob["init"](8))
+    eng.step(1, 0)                                    # empty run is a no-op
+    with pytest.raises(demc.DemcError):
+        eng.step(0, 1)                                # de.iter is 1-based
+    with pytest.raises(demc.DemcError):
+        eng.get_history(0, 4)                         # beyond n_rows
+    eng.step(1, 5)                                    # iterations beyond n_rows still run; their rows are not stored
+    th, acc, lp, idh = eng.get_history(0, 3)
+    assert th.shape == (3, 8, 2) and np.isfinite(lp).all()
+    eng.close()
