@@ -25,6 +25,21 @@ PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X datasheet FP64 matrix (= vector) peak; B
 PEAK_HBM_GBS = 8000.0          # MI355X HBM3E nominal; /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def measured_traffic(kernel, a):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01/*_pmc.json: FETCH_SIZE and WRITE_SIZE in KB, separate --pmc passes).  On gfx950 FETCH_SIZE counts
+    half the bytes of wide streaming reads (MI355X_MICROARCH.md, HBM section), hence the factor 2.  Only valid for
+    the default workload; otherwise None."""
+    if (a.n_groups, a.Np, a.nobs, a.dim, a.schedule) != (256, 256, 100000, 32, "two_colour"):
+        return None
+    path = os.path.join(ROOT, "profiles", "r01", f"bench_cfg3_{a.mode}_pmc.json")
+    try:
+        rec = json.load(open(path))[kernel]
+        return (2.0 * rec["FETCH_SIZE_KB_mean"] + rec["WRITE_SIZE_KB_mean"]) * 1024.0
+    except (OSError, KeyError):
+        return None
+
+
 def make_cfg3(n_groups, Np, N, d, seed=20260002):
     """Sigma = A A'/d + 0.5 I, X rows ~ N(mu*, Sigma), prior mu_j ~ N(0,1)"""
     rng = np.random.default_rng(seed)
@@ -117,7 +132,7 @@ def main():
     prob = make_cfg3(G, Np, N, d)
     eng = demc_amd.HipEngine(n_groups=G, Np=Np, D=d, n_rows=n_rows, schedule=2 if a.schedule == "two_colour" else 1,
                              group_offset=rank * G, n_groups_total=G * world, seed=20260001, device_id=local,
-                             loglike_mode=0 if a.mode == "streaming" else 1)
+                             loglike_mode=0 if a.mode == "streaming" else 1, trace=0)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     configure(eng, prob, d)
     eng.set_state(init_theta(P, d, rank))
@@ -156,7 +171,8 @@ def main():
             flops = (3.0 * N * d + 2.0 * d * d) * units  # algorithmic flops per particle-update
             ach = flops / t_launch / 1e12
             roofline = dict(bound="mfma", kernel="k_cross_mfma<8,4> (v_mfma_f64_16x16x4_f64)", achieved=ach,
-                            peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP64_MFMA_TFLOPS, traffic=None,
+                            peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP64_MFMA_TFLOPS,
+                            traffic=measured_traffic("demc::k_cross_mfma<8, 4>", a),
                             launch_ms=t_launch * 1e3, executed_tflops=2.0 * N * d * units / t_launch / 1e12)
         else:
             t_launch = (tm["propose"]["ms"] + tm["loglike_prep"]["ms"] + tm["accept_store"]["ms"]) / max(
@@ -164,7 +180,8 @@ def main():
             byts = (24.0 * d + 17.0) * units  # algorithmic bytes per particle-update
             ach = byts / t_launch / 1e9
             roofline = dict(bound="hbm", kernel="k_propose with fused prep/accept/store tail (one launch per colour phase)", achieved=ach,
-                            peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None, launch_ms=t_launch * 1e3)
+                            peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
+                            traffic=measured_traffic("demc::k_propose<true>", a), launch_ms=t_launch * 1e3)
         roofline["per_kernel_ms_per_iter"] = {n: v["ms"] / k for n, v in tm.items()}
 
     cpu = None

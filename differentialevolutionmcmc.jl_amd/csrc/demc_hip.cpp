@@ -213,7 +213,7 @@ int launch_loglike(demc_handle* h, KParams& k) {
         case FAM_HIER_BINOMIAL:
         case FAM_HIER_GAUSSIAN: {
             tick(h, 2, true);
-            hipLaunchKernelGGL(k_hier_loglike, dim3((unsigned)((n_prop + 3) / 4)), dim3(256), 0, h->stream, k);
+            hipLaunchKernelGGL(k_hier_loglike, dim3((unsigned)n_prop), dim3(256), 0, h->stream, k);
             tick(h, 2, false);
             k.n_partials = 1;
         } break;

@@ -252,11 +252,13 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
         m = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
         const int n_chunk = (Np + 15) >> 4;
         double* ctot = cdf + Np;
+        for (int i = tid; i < Np; i += 256) cdf[i] = exp(gw[i] - m);
+        __syncthreads();
         for (int c = tid; c < n_chunk; c += 256) {
             double pre = 0.0;
             const int i1 = (c * 16 + 16 < Np) ? c * 16 + 16 : Np;
             for (int i = c * 16; i < i1; ++i) {
-                pre += exp(gw[i] - m);
+                pre += cdf[i];
                 cdf[i] = pre;
             }
             ctot[c] = pre;
@@ -393,14 +395,13 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
                             if (!(total > 0.0) || !(total < INFINITY)) {
                                 b = (int)(u_base * Np);
                                 b = b < Np ? b : Np - 1;
-                            } else {  // first i with cdf[i] >= t, else Np-1
+                            } else {  // first i with cdf[i] >= t, else Np-1: cdf is monotone, so that index is the
+                                      // number of entries below t -- counted by the sub-group's lanes in parallel
                                 const double t = u_base * total;
-                                int lo = 0, hi = Np - 1;
-                                while (lo < hi) {
-                                    const int mid = (lo + hi) >> 1;
-                                    if (cdf[mid] >= t) hi = mid; else lo = mid + 1;
-                                }
-                                b = lo;
+                                int cnt = 0;
+                                for (int i = sl; i < Np; i += lpp) cnt += (cdf[i] < t) ? 1 : 0;
+                                cnt = subgroup_sum(cnt, lpp);
+                                b = cnt < Np ? cnt : Np - 1;
                             }
                             Pbase = rows + (size_t)b * D;
                             i2 = b;
@@ -820,14 +821,13 @@ __global__ __launch_bounds__(256) void k_obs_loglike(KParams p, int n_chunks) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2d: hierarchical families, cost O(D) per proposal: one wave per proposal, lanes across subjects,
-// coalesced reads of the proposal row, wave reduction (DPP shuffles).
+// K2d: hierarchical families, cost O(D) per proposal: one workgroup per proposal, lanes across subjects,
+// coalesced reads of the proposal row, wave reduction (shuffles) then a 4-way LDS combine.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_hier_loglike(KParams p) {
-    const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int n_prop = p.n_groups * p.n_act;
-    if (q >= n_prop) return;
+    __shared__ double s_part[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int q = blockIdx.x;  // one workgroup per proposal: 256 lanes across the subjects
     const size_t slot = (size_t)slot_of(p, q);
     const double* th = p.prop + slot * p.D;
     const long long S = p.N;
@@ -835,26 +835,28 @@ __global__ __launch_bounds__(256) void k_hier_loglike(KParams p) {
     if (p.family == FAM_HIER_BINOMIAL) {  // k_s ~ Binomial(n, logistic(mu_b0 + b0_s))  (BASELINE cfg4)
         const double mu0 = th[0], n = p.c0;
         const double* lgc = p.data + S;
-        for (long long s = lane; s < S; s += 64) {
+        for (long long s = tid; s < S; s += 256) {
             const double eta = mu0 + th[2 + s], k = p.data[s];
             acc += lgc[s] - k * softplus(-eta) - (n - k) * softplus(eta);
         }
     } else {  // FAM_HIER_GAUSSIAN  Hierarchical_Example.jl:36-44
         const double mu0 = th[0], sg = th[2 + S];
         const int n = p.d;
-        const double lsg = log(sg);
-        for (long long s = lane; s < S; s += 64) {
+        const double lsg = log(sg), isg = 1.0 / sg;
+        for (long long s = tid; s < S; s += 256) {
             const double mu = mu0 + th[2 + s];
             double l = 0.0;
             for (int i = 0; i < n; ++i) {
-                const double z = (p.data[s * n + i] - mu) / sg;
+                const double z = (p.data[s * n + i] - mu) * isg;
                 l += -(z * z + kLog2Pi) / 2.0 - lsg;
             }
             acc += l;
         }
     }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) p.partial[slot] = acc;
+    if (lane == 0) s_part[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) p.partial[slot] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
 }
 
 // ------------------------------------------------------------------------------------------------
