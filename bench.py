@@ -67,6 +67,7 @@ def cpu_baseline(prob, Np, N, d, seconds_target=20.0):
     OpenMP threads like p_update!, src/main.jl:135-148) on a bounded sample of the same workload."""
     from oracle import oracle as O
     from demc_amd import families as F
+    O.use_native_build()  # -O3 -march=native -fopenmp build of the same C source, compiled on this host
     # threads actually used: the process's CPU share, at most 16 (a 1-GPU box's share of the host)
     try:
         cores = len(os.sched_getaffinity(0))
@@ -90,7 +91,7 @@ def cpu_baseline(prob, Np, N, d, seconds_target=20.0):
     return dict(value=ng * Np * iters / dt, unit="particle-updates/s", cores=cores, kind="port",
                 sample=f"cfg3 shape (D={d}, N={N}, Np={Np}) on {ng} of the groups, {iters} iterations, reference "
                        f"schedule (sequential in-group sweep, one group per OpenMP thread), whitened O(N*D) "
-                       f"likelihood per proposal")
+                       f"likelihood per proposal; gcc -O3 -march=native -fopenmp")
 
 
 def main():

@@ -14,6 +14,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -240,7 +241,9 @@ int launch_phase(demc_handle* h, KParams& k) {
     k.write_prop = (!k.fuse_accept || k.trace) ? 1 : 0;
     const int ppp = 256 / k.lpp;
     const int max_split = (k.n_act + ppp - 1) / ppp;
-    int n_split = (512 + k.n_groups - 1) / k.n_groups;
+    int target_wgs = 512;
+    if (const char* e = std::getenv("DEMC_K1_WGS")) target_wgs = std::atoi(e);  // A/B experiments
+    int n_split = (target_wgs + k.n_groups - 1) / k.n_groups;
     if (n_split > max_split) n_split = max_split;
     if (n_split < 1) n_split = 1;
     k.n_split = n_split;
@@ -281,7 +284,8 @@ int migration_enqueue(demc_handle* h, long long iter, double* dev_rows, const do
     k.iter = iter;
     tick(h, 4, true);
     if (pack)
-        hipLaunchKernelGGL(k_mig_pack, dim3(h->c.n_groups), dim3(256), 0, h->stream, k, dev_rows);
+        hipLaunchKernelGGL(k_mig_pack, dim3(h->c.n_groups), dim3(256),
+                           sizeof(double) * ((size_t)h->c.Np + ((size_t)h->c.Np + 15) / 16), h->stream, k, dev_rows);
     if (apply) {
         const int ngt = h->c.n_groups_total;
         const int grid = ngt < 64 ? ngt : 64;
@@ -308,6 +312,7 @@ int size_k1_lds(demc_handle* h) {
     const size_t scr = is_mvn(h->family) ? (size_t)(256 / h->lpp) * (D + 2) * sizeof(double) : 0;
     const size_t tile = (size_t)c.Np * D * sizeof(double);
     h->tile_in_lds = (tile + cdf + ainv + scr <= 96 * 1024) ? 1 : 0;
+    if (const char* e = std::getenv("DEMC_K1_TILE")) h->tile_in_lds = (e[0] == '1') && h->tile_in_lds;  // A/B experiments
     h->k1_tile_bytes = h->tile_in_lds ? tile : 0;
     h->k1_lds = h->k1_tile_bytes + cdf + ainv + scr;
     if (h->k1_lds > 150 * 1024) return fail(h, DEMC_EINVAL, "K1 LDS budget exceeded (Np too large for this D)");

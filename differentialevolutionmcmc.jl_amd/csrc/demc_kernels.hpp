@@ -865,8 +865,17 @@ __global__ __launch_bounds__(256) void k_hier_loglike(KParams p) {
 // the history row -- one pass over the particle's D scalars, LPP lanes per particle.
 // ------------------------------------------------------------------------------------------------
 __device__ inline double finalize_loglike(const KParams& p, size_t slot) {
+    // fixed summation order (chunk 0, 1, ...); the loads are issued in batches of 8 so that their latencies overlap
     double s = 0.0;
-    for (int c = 0; c < p.n_partials; ++c) s += p.partial[(size_t)c * p.P + slot];
+    int c = 0;
+    for (; c + 8 <= p.n_partials; c += 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = p.partial[(size_t)(c + k) * p.P + slot];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; c < p.n_partials; ++c) s += p.partial[(size_t)c * p.P + slot];
     double sg = 0.0;
     if (p.family == FAM_MVN_ISO) sg = p.prop[slot * p.D + p.d];
     if (p.family == FAM_GAUSSIAN) sg = p.prop[slot * p.D + 1];
@@ -943,34 +952,77 @@ __global__ __launch_bounds__(256) void k_accept_store(KParams p) {
 // of the (i-1)-th (circshift(particles, 1)).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mig_pack(KParams p, double* __restrict__ rows) {
-    extern __shared__ double lds[];
-    __shared__ int s_pick;
+    extern __shared__ double lds[];  // [Np] cumulative weights + [ceil(Np/16)] chunk totals
+    __shared__ double s_red[4];
+    __shared__ int s_redi[4];
+    __shared__ int s_bad, s_pick;
     const int tid = threadIdx.x, g = blockIdx.x, Np = p.Np, D = p.D;
     const double* gw = p.weight + (size_t)g * Np;
-    if (tid == 0) {
-        double wmin = INFINITY;
-        int amin = 0, bad = 0;
-        for (int i = 0; i < Np; ++i) {
-            const double w = gw[i];
-            if (!(w > -INFINITY && w < INFINITY)) bad = 1;
-            if (w < wmin) { wmin = w; amin = i; }
-        }
-        int pick = amin;
-        if (!bad) {
-            const U4 r = draw_block(p.seed, S_MIG, 0, (uint64_t)p.iter, (uint32_t)(p.group_offset + g), 0);
-            const double u = u53(r.x, r.y);
-            double total = 0.0;
-            for (int i = 0; i < Np; ++i) total += exp(wmin - gw[i]);
-            const double t = u * total;
-            int i = 0;
-            double cw = exp(wmin - gw[0]);
-            while (cw < t && i < Np - 1) {
-                ++i;
-                cw += exp(wmin - gw[i]);
+    double* cdf = lds;
+    double* ctot = lds + Np;
+    // findmin(w) (first index of the minimum) and "any non-finite weight"
+    double m = INFINITY;
+    int am = 0x7fffffff, bad = 0;
+    if (tid == 0) s_bad = 0;
+    for (int i = tid; i < Np; i += 256) {
+        const double w = gw[i];
+        if (!(w > -INFINITY && w < INFINITY)) bad = 1;
+        if (w < m) { m = w; am = i; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double m2 = __shfl_xor(m, o);
+        const int a2 = __shfl_xor(am, o);
+        if (m2 < m || (m2 == m && a2 < am)) { m = m2; am = a2; }
+    }
+    __syncthreads();
+    if (bad) s_bad = 1;
+    if ((tid & 63) == 0) { s_red[tid >> 6] = m; s_redi[tid >> 6] = am; }
+    __syncthreads();
+    for (int k = 0; k < 4; ++k) {
+        const double m2 = s_red[k];
+        const int a2 = s_redi[k];
+        if (m2 < m || (m2 == m && a2 < am)) { m = m2; am = a2; }
+    }
+    if (s_bad) {
+        if (tid == 0) s_pick = am < Np ? am : 0;
+    } else {
+        // P(j) ~ exp(-(w_j - min w)); cumulative weights in the fixed two-level order shared with the oracle
+        const int n_chunk = (Np + 15) >> 4;
+        for (int i = tid; i < Np; i += 256) cdf[i] = exp(m - gw[i]);
+        __syncthreads();
+        for (int c = tid; c < n_chunk; c += 256) {
+            double pre = 0.0;
+            const int i1 = (c * 16 + 16 < Np) ? c * 16 + 16 : Np;
+            for (int i = c * 16; i < i1; ++i) {
+                pre += cdf[i];
+                cdf[i] = pre;
             }
-            pick = i;
+            ctot[c] = pre;
         }
-        s_pick = pick;
+        __syncthreads();
+        if (tid == 0) {
+            double off = 0.0;
+            for (int c = 0; c < n_chunk; ++c) {
+                const double t = ctot[c];
+                ctot[c] = off;
+                off = off + t;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < Np; i += 256) cdf[i] = ctot[i >> 4] + cdf[i];
+        __syncthreads();
+        const U4 r = draw_block(p.seed, S_MIG, 0, (uint64_t)p.iter, (uint32_t)(p.group_offset + g), 0);
+        const double t = u53(r.x, r.y) * cdf[Np - 1];
+        int cnt = 0;  // first i with cdf[i] >= t == number of entries below t (monotone)
+        for (int i = tid; i < Np; i += 256) cnt += (cdf[i] < t) ? 1 : 0;
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        __syncthreads();
+        if ((tid & 63) == 0) s_redi[tid >> 6] = cnt;
+        __syncthreads();
+        if (tid == 0) {
+            const int c = s_redi[0] + s_redi[1] + s_redi[2] + s_redi[3];
+            s_pick = c < Np ? c : Np - 1;
+        }
     }
     __syncthreads();
     const int j = s_pick;

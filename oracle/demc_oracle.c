@@ -732,16 +732,23 @@ static int32_t select_particle_stable(const double* w, int32_t n, double u) {
         if (w[i] < wmin) { wmin = w[i]; amin = i; }
     }
     if (bad) return amin;
-    double total = 0.0;
-    for (int i = 0; i < n; ++i) total += exp(wmin - w[i]);
-    const double t = u * total;
-    int32_t i = 0;
-    double cw = exp(wmin - w[0]);
-    while (cw < t && i < n - 1) {
-        ++i;
-        cw += exp(wmin - w[i]);
+    /* cumulative weights exp(wmin - w_i) in the same fixed two-level order as select_base_stable */
+    double* cdf = (double*)malloc(sizeof(double) * (size_t)n);
+    double off = 0.0;
+    for (int c0 = 0; c0 < n; c0 += ORC_CDF_CHUNK) {
+        double pre = 0.0;
+        const int c1 = c0 + ORC_CDF_CHUNK < n ? c0 + ORC_CDF_CHUNK : n;
+        for (int i = c0; i < c1; ++i) {
+            pre += exp(wmin - w[i]);
+            cdf[i] = off + pre;
+        }
+        off = off + pre;
     }
-    return i;
+    const double t = u * cdf[n - 1];
+    int32_t r = 0;
+    while (cdf[r] < t && r < n - 1) ++r;
+    free(cdf);
+    return r;
 }
 
 /* samplepair (StatsBase, recalled): i1 = rand(1:m); i2 = rand(1:m-1); i2 == i1 ? m : i2    */

@@ -11,9 +11,25 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libdemc_oracle.so")
+_lib = None
+
+
+_NATIVE = False  # use_native_build(): -O3 -march=native build, for bench.py's cpu_baseline timing only
+
+
+def use_native_build():
+    """Switch to libdemc_oracle_native.so (built ON THIS HOST with -O3 -march=native).  Must be called before the
+    first lib(); never for parity tests (FMA contraction changes the last bits of the proposal algebra)."""
+    global _LIB, _NATIVE
+    assert _lib is None, "use_native_build() must come before the library is loaded"
+    _LIB = os.path.join(_HERE, "libdemc_oracle_native.so")
+    _NATIVE = True
+    subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libdemc_oracle_native.so"])  # -B: rebuild for this CPU
 
 
 def build(force=False):
+    if _NATIVE:
+        return _LIB
     src = [os.path.join(_HERE, f) for f in ("demc_oracle.c", "demc_oracle.h", "Makefile")]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "-s", "libdemc_oracle.so"])
@@ -42,9 +58,6 @@ _up = C.POINTER(C.c_uint32)
 
 def _d(a):
     return None if a is None else a.ctypes.data_as(_dp)
-
-
-_lib = None
 
 
 def lib():

@@ -43,8 +43,8 @@ int main() {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    const int iters = 2000;
-    for (int blocks_per_cu : {1, 2}) {
+    const int iters = 40000;
+    for (int blocks_per_cu : {2, 4}) {
         const int grid = 256 * blocks_per_cu;
         for (int mode : {4, 8, 3, 1, 2}) {
             k<<<grid, 256>>>(out, 10, mode);
