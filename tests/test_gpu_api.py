@@ -131,6 +131,33 @@ def _cfg3(N=100000, d=32, G=256, Np=256, **kw):
     return eng, X, Sigma
 
 
+def test_cfg2_posterior_matches_closed_form():
+    """BASELINE cfg2 (MvNormal D=8, 32 x 64 particles, N=1e4): after burn-in the chain reproduces the conjugate
+    Gaussian posterior -- means within 1 % (L1, the metric's accuracy half) and the right spread"""
+    d, N, G, Np = 8, 10000, 32, 64
+    rng = np.random.default_rng(20260001)
+    A = rng.normal(0, 1, (d, d))
+    Sigma = A @ A.T / d + 0.5 * np.eye(d)
+    X = rng.normal(0, 1, d) + rng.normal(0, 1, (N, d)) @ np.linalg.cholesky(Sigma).T
+    burn, n_it = 300, 700
+    for schedule in (2, 1):
+        eng = D.HipEngine(n_groups=G, Np=Np, D=d, n_rows=n_it, schedule=schedule, seed=3, burnin=burn, trace=0)
+        eng.set_model(F.FAM_MVN_FULL, X, [N, d], Sigma)
+        eng.set_priors([F.PRIOR_NORMAL] * d, [0.0] * d, [1.0] * d)
+        eng.set_bounds([-np.inf] * d, [np.inf] * d)
+        eng.set_state(rng.normal(0, 1, (G * Np, d)))
+        eng.step(1, n_it)
+        th = eng.get_history(burn + 100, n_it)[0].reshape(-1, d)
+        eng.close()
+        Ainv = np.linalg.inv(Sigma)
+        cov = np.linalg.inv(N * Ainv + np.eye(d))
+        mean = cov @ (N * Ainv @ X.mean(0))
+        assert np.abs(th.mean(0) - mean).sum() / np.abs(mean).sum() < 0.01
+        np.testing.assert_allclose(th.std(0), np.sqrt(np.diag(cov)), rtol=0.1 if schedule == 2 else 0.2)
+        if schedule == 2:  # the valid schedule also reproduces the correlations
+            np.testing.assert_allclose(np.corrcoef(th.T), cov / np.sqrt(np.outer(np.diag(cov), np.diag(cov))), atol=0.05)
+
+
 def test_cfg3_full_size_properties(orc):
     """BASELINE cfg3 (D=32, N=1e5, 256 x 256 particles): properties that need no full-size oracle run"""
     d, P = 32, 65536
