@@ -240,23 +240,27 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     const double* rows = TILE ? (const double*)tile : grows;
     if (p.fuse_prep && p.Ainv)
         for (int i = tid; i < d * d; i += 256) ainv_s[i] = p.Ainv[i];
+    // select_base (crossover.jl:282-289) over the partner POOL: the whole group in the synchronous schedule, the fixed
+    // half in two_colour -- so nothing a moving particle reads (partners, base row, base weights) can change during
+    // the phase, which is what makes the fused accept tail race-free across workgroups.
+    const int n_cdf = p.pool_n;
+    const double* pw = gw + p.pool_lo;
     if (use_base) {
-        // select_base (crossover.jl:282-289), stabilised: e_j = exp(w_j - max w); cumulative weights in a fixed
-        // two-level order (same as the oracle): sequential inside chunks of 16, sequential over the chunk totals,
-        // cdf[i] = offset[chunk] + prefix[i]
+        // stabilised: e_j = exp(w_j - max w); cumulative weights in a fixed two-level order (same as the oracle):
+        // sequential inside chunks of 16, sequential over the chunk totals, cdf[i] = offset[chunk] + prefix[i]
         double m = -INFINITY;
-        for (int i = tid; i < Np; i += 256) m = fmax(m, gw[i]);
+        for (int i = tid; i < n_cdf; i += 256) m = fmax(m, pw[i]);
         for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
         if ((tid & 63) == 0) s_red[tid >> 6] = m;
         __syncthreads();
         m = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
-        const int n_chunk = (Np + 15) >> 4;
+        const int n_chunk = (n_cdf + 15) >> 4;
         double* ctot = cdf + Np;
-        for (int i = tid; i < Np; i += 256) cdf[i] = exp(gw[i] - m);
+        for (int i = tid; i < n_cdf; i += 256) cdf[i] = exp(pw[i] - m);
         __syncthreads();
         for (int c = tid; c < n_chunk; c += 256) {
             double pre = 0.0;
-            const int i1 = (c * 16 + 16 < Np) ? c * 16 + 16 : Np;
+            const int i1 = (c * 16 + 16 < n_cdf) ? c * 16 + 16 : n_cdf;
             for (int i = c * 16; i < i1; ++i) {
                 pre += cdf[i];
                 cdf[i] = pre;
@@ -273,9 +277,9 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             }
         }
         __syncthreads();
-        for (int i = tid; i < Np; i += 256) cdf[i] = ctot[i >> 4] + cdf[i];
+        for (int i = tid; i < n_cdf; i += 256) cdf[i] = ctot[i >> 4] + cdf[i];
         __syncthreads();
-        if (tid == 0) s_total = cdf[Np - 1];
+        if (tid == 0) s_total = cdf[n_cdf - 1];
     }
     __syncthreads();
 
@@ -393,16 +397,17 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
                             const double total = s_total;
                             int b;
                             if (!(total > 0.0) || !(total < INFINITY)) {
-                                b = (int)(u_base * Np);
-                                b = b < Np ? b : Np - 1;
-                            } else {  // first i with cdf[i] >= t, else Np-1: cdf is monotone, so that index is the
+                                b = (int)(u_base * n_cdf);
+                                b = b < n_cdf ? b : n_cdf - 1;
+                            } else {  // first i with cdf[i] >= t, else last: cdf is monotone, so that index is the
                                       // number of entries below t -- counted by the sub-group's lanes in parallel
                                 const double t = u_base * total;
                                 int cnt = 0;
-                                for (int i = sl; i < Np; i += lpp) cnt += (cdf[i] < t) ? 1 : 0;
+                                for (int i = sl; i < n_cdf; i += lpp) cnt += (cdf[i] < t) ? 1 : 0;
                                 cnt = subgroup_sum(cnt, lpp);
-                                b = cnt < Np ? cnt : Np - 1;
+                                b = cnt < n_cdf ? cnt : n_cdf - 1;
                             }
+                            b += p.pool_lo;
                             Pbase = rows + (size_t)b * D;
                             i2 = b;
                             base_on = true;

@@ -902,7 +902,9 @@ static void propose(orc_handle* h, int64_t iter, uint32_t sweep, int32_t g_glob,
     const int use_base = (kind == ORC_PROPOSAL_RANDOM_GAMMA) && (iter <= h->c.burnin); /* crossover.jl:164 */
     const double* Pb = NULL;
     if (use_base) {
-        const int32_t b = select_base_stable(gv->w, Np, u_base); /* crossover.jl:156, whole group */
+        /* crossover.jl:156.  The base is drawn from the partner pool: the whole group in the reference schedules;
+         * in two_colour the fixed half, so that a moving particle reads nothing that can move in the same phase */
+        const int32_t b = gv->pool_lo + select_base_stable(gv->w + gv->pool_lo, gv->pool_n, u_base);
         Pb = gv->rows + (int64_t)b * D;
         idx[3] = b;
     }

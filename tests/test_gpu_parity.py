@@ -196,6 +196,15 @@ def test_step_parity_suffstat_fused(demc, orc, family, schedule):
                    loglike_mode=1, alpha=0.5)
 
 
+def test_fused_tail_with_several_workgroups_per_group(demc, orc):
+    """Np = 200 -> two workgroups per group in the fused kernel: they write active rows / weights of the same group
+    concurrently, which is safe because everything a moving particle READS (partners, base row, base weights) lives
+    in the other colour.  Burn-in covers the base term."""
+    prob = make_problem("mvn_full", np.random.default_rng(23), N=300, d=8)
+    teacher_forced(demc, orc, prob, n_iter=6, n_groups=3, Np=200, schedule=2, burnin=6, loglike_mode=1, alpha=0.5,
+                   check_hist=False)
+
+
 def test_fused_equals_unfused(demc):
     """the fused tail is an implementation detail: same bits as K1 -> K3"""
     prob = make_problem("mvn_full", np.random.default_rng(22), N=400, d=10)
