@@ -52,7 +52,7 @@ struct demc_handle {
     int d = 0, n_acc = 0, dpad = 0;
     int n_tiles = 0;
     int ks_t = 0, n_kpass = 0;  // MFMA k-steps per pass (template) and passes over the dimensions
-    double *data = nullptr, *Ainv = nullptr, *Ypad = nullptr, *Xf = nullptr, *sx = nullptr;
+    double *data = nullptr, *Ainv = nullptr, *Ypad = nullptr, *Xf = nullptr, *sx = nullptr, *xbar = nullptr;
     size_t data2_off = 0;
     double c0 = 0, c1 = 0, c2 = 0;
     int partial_cap = 64;
@@ -149,7 +149,7 @@ KParams base_params(demc_handle* h) {
     k.partial = h->partial; k.aux = h->aux; k.data = h->data; k.data2 = h->data ? h->data + h->data2_off : nullptr;
     k.c0 = h->c0; k.c1 = h->c1; k.c2 = h->c2;
     k.n_split = 1; k.fuse_prep = 0; k.fuse_accept = 0; k.write_prop = 1; k.trace = c.trace;
-    k.Ainv = h->Ainv; k.sx = nullptr; k.Ypad = h->Ypad; k.dpad = h->dpad;
+    k.Ainv = h->Ainv; k.sx = nullptr; k.xbar = h->xbar; k.Ypad = h->Ypad; k.dpad = h->dpad;
     return k;
 }
 
@@ -309,12 +309,13 @@ int size_k1_lds(demc_handle* h) {
     const size_t D = (size_t)c.D;
     const size_t cdf = ((size_t)c.Np + ((size_t)c.Np + 15) / 16) * sizeof(double);
     const size_t ainv = (h->family == FAM_MVN_FULL) ? (size_t)h->d * h->d * sizeof(double) : 0;
+    const size_t xb = is_mvn(h->family) ? (size_t)h->d * sizeof(double) : 0;
     const size_t scr = is_mvn(h->family) ? (size_t)(256 / h->lpp) * (D + 2) * sizeof(double) : 0;
     const size_t tile = (size_t)c.Np * D * sizeof(double);
-    h->tile_in_lds = (tile + cdf + ainv + scr <= 96 * 1024) ? 1 : 0;
+    h->tile_in_lds = (tile + cdf + ainv + xb + scr <= 96 * 1024) ? 1 : 0;
     if (const char* e = std::getenv("DEMC_K1_TILE")) h->tile_in_lds = (e[0] == '1') && h->tile_in_lds;  // A/B experiments
     h->k1_tile_bytes = h->tile_in_lds ? tile : 0;
-    h->k1_lds = h->k1_tile_bytes + cdf + ainv + scr;
+    h->k1_lds = h->k1_tile_bytes + cdf + ainv + xb + scr;
     if (h->k1_lds > 150 * 1024) return fail(h, DEMC_EINVAL, "K1 LDS budget exceeded (Np too large for this D)");
     HIPCHK(hipFuncSetAttribute((const void*)k_propose<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k1_lds));
     HIPCHK(hipFuncSetAttribute((const void*)k_propose<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k1_lds));
@@ -436,7 +437,7 @@ int32_t demc_destroy(demc_handle* h) {
     void* ptrs[] = {h->theta, h->weight, h->prop, h->prop_prior, h->prop_adj, h->tr_w, h->partial, h->aux, h->lo, h->hi,
                     h->pa, h->pb, h->pc, h->dimtab, h->hist, h->lp_hist, h->mig_rows, h->scratch_theta, h->scratch_w, h->id, h->prop_oob,
                     h->tr_acc, h->masks, h->acc_hist, h->tr_idx, h->pk, h->pref, h->id_hist, h->data, h->Ainv, h->Ypad,
-                    h->Xf, h->sx};
+                    h->Xf, h->sx, h->xbar};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -465,7 +466,7 @@ int32_t demc_set_model(demc_handle* h, int32_t family, const double* data, const
     long long dm[4] = {0, 0, 0, 0};
     for (int i = 0; i < ndims; ++i) dm[i] = dims[i];
     const int D = h->c.D;
-    for (double** p : {&h->data, &h->Ainv, &h->Ypad, &h->Xf, &h->sx})
+    for (double** p : {&h->data, &h->Ainv, &h->Ypad, &h->Xf, &h->sx, &h->xbar})
         if (*p) { hipFree(*p); *p = nullptr; }
     h->family = -1; h->N = 0; h->d = 0; h->n_acc = 0; h->dpad = 0; h->n_tiles = 0; h->c0 = h->c1 = h->c2 = 0; h->data2_off = 0;
     std::vector<double> dev;  // what goes to h->data
@@ -542,7 +543,19 @@ int32_t demc_set_model(demc_handle* h, int32_t family, const double* data, const
                 ALLOC(h->Ainv, (size_t)d * d);
                 HIPCHK(hipMemcpy(h->Ainv, Ainv.data(), sizeof(double) * d * d, hipMemcpyHostToDevice));
             }
-            // data-only constants: c1 = sum_i x_i' A^-1 x_i (A = I for ISO), sx = sum_i x_i
+            // The data are CENTRED once (x~_i = x_i - xbar) and proposals are shifted the same way in K1
+            // (mu~ = theta' - xbar): (x_i - mu) = (x~_i - mu~), but every term of the expanded quadratic form
+            //   sum_i x~_i' A^-1 x~_i  -  2 y . sum_i x~_i  +  N mu~' A^-1 mu~ ,   y = A^-1 mu~
+            // is then O(N d) whatever the offset of the data, so the expansion loses no digits to cancellation.
+            // data-only constants: c1 = sum_i x~_i' A^-1 x~_i (A = I for ISO), sx = sum_i x~_i (~ 0)
+            std::vector<double> xbar(d, 0.0);
+            for (long long i = 0; i < N; ++i)
+                for (int k = 0; k < d; ++k) xbar[k] += data[i * d + k];
+            for (int k = 0; k < d; ++k) xbar[k] /= (double)N;
+            std::vector<double> xc((size_t)N * d);
+            for (long long i = 0; i < N; ++i)
+                for (int k = 0; k < d; ++k) xc[(size_t)i * d + k] = data[i * d + k] - xbar[k];
+            data = xc.data();
             std::vector<double> sx(d, 0.0), t(d);
             double c1 = 0.0;
             for (long long i = 0; i < N; ++i) {
@@ -550,9 +563,9 @@ int32_t demc_set_model(demc_handle* h, int32_t family, const double* data, const
                 double q = 0.0;
                 if (family == DEMC_FAM_MVN_FULL) {
                     for (int r = 0; r < d; ++r) {
-                        double s = 0.0;
-                        for (int k = 0; k < d; ++k) s += Ainv[r * d + k] * x[k];
-                        q += x[r] * s;
+                        double sr = 0.0;
+                        for (int k = 0; k < d; ++k) sr += Ainv[r * d + k] * x[k];
+                        q += x[r] * sr;
                     }
                 } else
                     for (int k = 0; k < d; ++k) q += x[k] * x[k];
@@ -562,6 +575,8 @@ int32_t demc_set_model(demc_handle* h, int32_t family, const double* data, const
             h->c1 = c1;
             ALLOC(h->sx, (size_t)d);
             HIPCHK(hipMemcpy(h->sx, sx.data(), sizeof(double) * d, hipMemcpyHostToDevice));
+            ALLOC(h->xbar, (size_t)d);
+            HIPCHK(hipMemcpy(h->xbar, xbar.data(), sizeof(double) * d, hipMemcpyHostToDevice));
             ALLOC(h->Ypad, (size_t)h->P * h->dpad);
             // fragment-ordered copy of X for v_mfma_f64_16x16x4_f64's B operand:
             //   Xf[tile][kstep][lane] = X[16*tile + (lane&15)][4*kstep + (lane>>4)], zero padded

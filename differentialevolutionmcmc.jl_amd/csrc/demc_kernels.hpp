@@ -76,7 +76,8 @@ struct KParams {
     int write_prop;           // K1 writes proposals to HBM (needed by K2/K3 or by the trace)
     int trace;                // keep the per-slot diagnostic trace
     const double* Ainv;       // [d][d] or null (ISO)
-    const double* sx;         // [d] sum_i x_i, non-null in SUFFSTAT mode
+    const double* sx;         // [d] sum_i (x_i - xbar), non-null in SUFFSTAT mode
+    const double* xbar;       // [d] data mean: the MvNormal families work with theta' - xbar
     double* Ypad;             // [P][dpad]
     int dpad;
     // model
@@ -218,7 +219,8 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     double* cdf = tile + (TILE ? (size_t)Np * D : 0);
     double* ainv_s = cdf + Np + ((Np + 15) >> 4);
     const int scr_stride = D + 2;
-    double* scr = ainv_s + ((p.fuse_prep && p.Ainv) ? (size_t)d * d : 0);
+    double* xb_s = ainv_s + ((p.fuse_prep && p.Ainv) ? (size_t)d * d : 0);
+    double* scr = xb_s + (p.fuse_prep ? d : 0);
 
     bool is_mut = false;
     if (p.mode == MODE_STEP) {
@@ -238,8 +240,11 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             for (int i = tid; i < Np * D; i += 256) tile[i] = grows[i];
     }
     const double* rows = TILE ? (const double*)tile : grows;
-    if (p.fuse_prep && p.Ainv)
-        for (int i = tid; i < d * d; i += 256) ainv_s[i] = p.Ainv[i];
+    if (p.fuse_prep) {
+        if (p.Ainv)
+            for (int i = tid; i < d * d; i += 256) ainv_s[i] = p.Ainv[i];
+        for (int i = tid; i < d; i += 256) xb_s[i] = p.xbar[i];
+    }
     // select_base (crossover.jl:282-289) over the partner POOL: the whole group in the synchronous schedule, the fixed
     // half in two_colour -- so nothing a moving particle reads (partners, base row, base weights) can change during
     // the phase, which is what makes the fused accept tail race-free across workgroups.
@@ -538,6 +543,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const double* th = scr + sub * scr_stride;
+            // centred proposal mu~ = theta' - xbar (the data were centred the same way at demc_set_model)
             for (int k = sl; 2 * k < d; k += lpp) {
                 const int c0 = 2 * k, c1 = 2 * k + 1;
                 double y0 = 0.0, y1 = 0.0;
@@ -545,18 +551,18 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
                     if (c1 < d) {
 #pragma unroll 4
                         for (int j = 0; j < d; ++j) {
-                            const double t = th[j];
+                            const double t = th[j] - xb_s[j];
                             y0 = fma(ainv_s[j * d + c0], t, y0);  // A^-1 is symmetric: column c == row c
                             y1 = fma(ainv_s[j * d + c1], t, y1);
                         }
                     } else
-                        for (int j = 0; j < d; ++j) y0 = fma(ainv_s[j * d + c0], th[j], y0);
+                        for (int j = 0; j < d; ++j) y0 = fma(ainv_s[j * d + c0], th[j] - xb_s[j], y0);
                 } else {
-                    y0 = th[c0];
-                    if (c1 < d) y1 = th[c1];
+                    y0 = th[c0] - xb_s[c0];
+                    if (c1 < d) y1 = th[c1] - xb_s[c1];
                 }
-                aux = fma(th[c0], y0, aux);
-                if (c1 < d) aux = fma(th[c1], y1, aux);
+                aux = fma(th[c0] - xb_s[c0], y0, aux);
+                if (c1 < d) aux = fma(th[c1] - xb_s[c1], y1, aux);
                 if (p.sx) {
                     S = fma(y0, p.sx[c0], S);
                     if (c1 < d) S = fma(y1, p.sx[c1], S);
@@ -747,10 +753,10 @@ __global__ __launch_bounds__(256) void k_obs_loglike(KParams p, int n_chunks) {
     double acc = 0.0;
     switch (p.family) {
         case FAM_GAUSSIAN: {  // sum_i ((x_i - mu)/sigma)^2   Gaussian_Example.jl:26-28
-            const double mu = th[0], sg = th[1];
+            const double mu = th[0], isg = 1.0 / th[1];
             for (long long i = i0; i < i1; ++i) {
-                const double z = (p.data[i] - mu) / sg;
-                acc += z * z;
+                const double z = (p.data[i] - mu) * isg;
+                acc = fma(z, z, acc);
             }
         } break;
         case FAM_BINOMIAL: {  // binomial_tests.jl:15-17; data=[n], data2=[k], aux table in c-terms

@@ -17,6 +17,30 @@ def test_mvn_full_ragged_shapes(demc, orc, N, d):
     teacher_forced(demc, orc, prob, n_iter=4, n_groups=3, Np=9, schedule=2, burnin=2, check_hist=False)
 
 
+@pytest.mark.parametrize("family", ["mvn_full", "mvn_iso"])
+@pytest.mark.parametrize("offset", [1e3, 1e6])
+def test_mvn_data_far_from_the_origin(demc, orc, family, offset):
+    """the expanded quadratic form sum x'Ax - 2 y.x + N mu'A mu would lose all digits for data with a large mean; the
+    library centres data and proposals, so the log-posterior keeps full precision whatever the offset"""
+    rng = np.random.default_rng(31)
+    prob = make_problem(family, rng, N=400, d=6)
+    prob["data"] = prob["data"] + offset
+    d = 6
+    eng = demc.HipEngine(n_groups=2, Np=8, D=prob["D"], schedule=1)
+    o = orc.Oracle(n_groups=2, Np=8, D=prob["D"], schedule=1)
+    setup_engine(eng, prob)
+    setup_engine(o, prob)
+    th = prob["init"](16)
+    th[:, :d] += offset + rng.normal(0, 0.05, (16, d))  # near the data, where the posterior mass is
+    for mode in (0, 1):
+        e2 = demc.HipEngine(n_groups=2, Np=8, D=prob["D"], schedule=1, loglike_mode=mode)
+        setup_engine(e2, prob)
+        # unbounded flat-ish comparison: priors are the same on both sides, so compare full log-posteriors
+        np.testing.assert_allclose(e2.logpost(th), o.logpost(th), rtol=1e-10)
+        e2.close()
+    eng.close()
+
+
 @pytest.mark.parametrize("Np", [4, 5, 7, 33, 600])
 def test_odd_and_large_group_sizes(demc, orc, Np):
     prob = make_problem("gaussian", np.random.default_rng(7))
