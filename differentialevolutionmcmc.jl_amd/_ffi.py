@@ -94,10 +94,8 @@ def load():
     L.demc_get_trace.argtypes = [H, _dp, _dp, _dp, _ip, _bp]
     L.demc_timing_enable.argtypes = [H, C.c_int32]
     L.demc_timing_read.argtypes = [H, _dp, C.c_int32]
-    for name in EXPORTS:
-        if name not in ("demc_last_error",):
-            getattr(L, name).restype = C.c_int32 if name != "demc_last_error" else C.c_char_p
-    L.demc_last_error.restype = C.c_char_p
+    for name in EXPORTS:  # every entry point returns an int32 status, except the error string
+        getattr(L, name).restype = C.c_char_p if name == "demc_last_error" else C.c_int32
     _lib = L
     return L
 

@@ -39,13 +39,13 @@ struct demc_handle {
     bool own_stream = false;
     // state
     double *theta = nullptr, *weight = nullptr, *prop = nullptr, *prop_prior = nullptr, *prop_adj = nullptr;
-    double *tr_w = nullptr, *partial = nullptr, *aux = nullptr, *lo = nullptr, *hi = nullptr, *pa = nullptr, *pb = nullptr, *pc = nullptr;
+    double *tr_w = nullptr, *partial = nullptr, *aux = nullptr;
     DimTab* dimtab = nullptr;
     std::vector<DimTab> h_tab;  // host copy: bounds and priors arrive in separate calls
     double *hist = nullptr, *lp_hist = nullptr, *mig_rows = nullptr, *scratch_theta = nullptr, *scratch_w = nullptr;
     long long* id = nullptr;
     unsigned char *prop_oob = nullptr, *tr_acc = nullptr, *masks = nullptr, *acc_hist = nullptr;
-    int *tr_idx = nullptr, *pk = nullptr, *pref = nullptr, *id_hist = nullptr;
+    int *tr_idx = nullptr, *id_hist = nullptr;
     // model
     int family = -1;
     long long N = 0;
@@ -59,7 +59,6 @@ struct demc_handle {
     int lpp = 1;
     int tile_in_lds = 0;
     size_t k1_lds = 0, k1_tile_bytes = 0;
-    bool bounds_set = false, priors_set = false;
     std::string err;
     // timing
     bool timing = false;
@@ -434,9 +433,9 @@ int32_t demc_destroy(demc_handle* h) {
     if (!h) return DEMC_OK;
     if (h->stream) hipStreamSynchronize(h->stream);
     drain_events(h);
-    void* ptrs[] = {h->theta, h->weight, h->prop, h->prop_prior, h->prop_adj, h->tr_w, h->partial, h->aux, h->lo, h->hi,
-                    h->pa, h->pb, h->pc, h->dimtab, h->hist, h->lp_hist, h->mig_rows, h->scratch_theta, h->scratch_w, h->id, h->prop_oob,
-                    h->tr_acc, h->masks, h->acc_hist, h->tr_idx, h->pk, h->pref, h->id_hist, h->data, h->Ainv, h->Ypad,
+    void* ptrs[] = {h->theta, h->weight, h->prop, h->prop_prior, h->prop_adj, h->tr_w, h->partial, h->aux,
+                    h->dimtab, h->hist, h->lp_hist, h->mig_rows, h->scratch_theta, h->scratch_w, h->id, h->prop_oob,
+                    h->tr_acc, h->masks, h->acc_hist, h->tr_idx, h->id_hist, h->data, h->Ainv, h->Ypad,
                     h->Xf, h->sx, h->xbar};
     for (void* p : ptrs)
         if (p) hipFree(p);

@@ -1,11 +1,12 @@
 // demc_kernels.hpp -- hand-written gfx950 kernels of the DE-MCMC hot path.
 //
-//   K1  k_propose        crossover!/snooker_update!/mutation!/recombination!/reset!/in_bounds + prior
+//   K1  k_propose<TILE>  crossover!/snooker_update!/mutation!/recombination!/reset!/in_bounds + prior
 //                        (crossover.jl:30-99,154-257,301-352; mutation.jl:13-25; utilities.jl:70-78)
-//       (fused tails)    MvNormal preparation y = A^-1 theta', a = theta'.y; optional accept/store
-//       k_cross_mfma     S_p = sum_i y_p . x_i over all observations on v_mfma_f64_16x16x4_f64
+//       (fused tails)    MvNormal preparation y = A^-1 (theta' - xbar), a = (theta' - xbar).y; optionally the whole
+//                        accept/store when the likelihood needs no pass over the data (SUFFSTAT, two_colour)
+//   K2  k_cross_mfma     S_p = sum_i y_p . x~_i over all observations on v_mfma_f64_16x16x4_f64
 //       k_obs_loglike    thread-per-proposal streaming likelihoods (Gaussian, Binomial, LBA, LNR, rastrigin)
-//       k_hier_loglike   wave-per-proposal likelihoods whose cost is O(D) (hierarchical families)
+//       k_hier_loglike   workgroup-per-proposal likelihoods whose cost is O(D) (hierarchical families)
 //   K3  k_accept_store   compute_posterior! finalisation + mh_update!/maximize!/minimize! + store_samples!
 //                        (utilities.jl:92-99,161-180,201-226)
 //   M   k_mig_pack / k_mig_apply   select_particle / select_groups + shift_particles! (migration.jl:31-91)
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2b: streaming cross term on the FP64 matrix cores.
+// K2 (MvNormal): streaming cross term on the FP64 matrix cores.
 //   S[p] = sum_i sum_k Y[p][k] * X[i][k]
 // v_mfma_f64_16x16x4_f64: A = 16 particles x 4 dims (lane l: row l&15, k l>>4), B = 4 dims x 16
 // observations (lane l: k l>>4, col l&15), C/D 16x16, 4 doubles per lane (row (l>>4)+4r, col l&15).
@@ -738,7 +739,7 @@ __global__ __launch_bounds__(256, 2) void k_cross_mfma(KParams p, const double* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2c: thread-per-proposal streaming likelihoods.  All lanes of a wave visit the same observation,
+// K2 (scalar-data families): thread-per-proposal streaming likelihoods.  All lanes of a wave visit the same observation,
 // so data loads are wave-uniform (scalar) and the loop is pure FP64 VALU.  grid = (proposal blocks, chunks).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_obs_loglike(KParams p, int n_chunks) {
@@ -832,7 +833,7 @@ __global__ __launch_bounds__(256) void k_obs_loglike(KParams p, int n_chunks) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2d: hierarchical families, cost O(D) per proposal: one workgroup per proposal, lanes across subjects,
+// K2 (hierarchical families): cost O(D) per proposal: one workgroup per proposal, lanes across subjects,
 // coalesced reads of the proposal row, wave reduction (shuffles) then a 4-way LDS combine.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_hier_loglike(KParams p) {

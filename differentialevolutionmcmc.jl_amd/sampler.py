@@ -4,7 +4,7 @@ import numpy as np
 
 from . import _ffi
 from .chains import Chains
-from .families import PRIOR_FLAT, PRIOR_NORMAL_REF, Priors
+from .families import PRIOR_NORMAL_REF, Priors
 from .structs import (DE, HIPBackend, LOGLIKE_MODES, MCMCThreads, SCHEDULES, DEModel, Particle, maximize)
 
 
