@@ -14,6 +14,8 @@
 
 #include <cmath>
 
+#include "demc_erfcx_table.hpp"
+
 namespace demc {
 
 constexpr double kLog2Pi = 1.8378770664093454835606594728112;
@@ -112,15 +114,45 @@ inline double prior_const(int kind, double a, double b) {
     }
 }
 
+// erfcx(y) = exp(y^2) erfc(y) for y >= 0 from the generated piecewise polynomial table (tools/gen_erfcx_table.py,
+// relative error ~1e-15): interval index = exponent and top 5 mantissa bits of z = 1 + y, polynomial in (z - centre).
+// tab points at a copy of kErfcxTable (LDS in the kernels that call this per observation).
+__device__ inline double erfcx_pos(const double* tab, double y) {
+    const double z = 1.0 + fmin(y, 30.99);  // beyond that exp(-y^2) has long underflowed
+    const long long bits = __double_as_longlong(z);
+    const int idx = (int)(bits >> 47) - (1023 << 5);
+    const double c = __longlong_as_double((bits & ~((1LL << 47) - 1)) | (1LL << 46));
+    const double dz = z - c;
+    const double* a = tab + idx * (kErfcxDeg + 1);
+    double r = a[kErfcxDeg];
+#pragma unroll
+    for (int k = kErfcxDeg - 1; k >= 0; --k) r = fma(r, dz, a[k]);
+    return r;
+}
+// phi(x) and Phi(x) from ONE exponential: Phi(-|x|) = 0.5 erfcx(|x|/sqrt2) exp(-x^2/2)
+__device__ inline void phi_Phi(const double* tab, double x, double& ph, double& Ph) {
+    const double e = exp(-0.5 * x * x);
+    ph = e * kInvSqrt2Pi;
+    const double r = 0.5 * erfcx_pos(tab, fabs(x) * kInvSqrt2) * e;
+    Ph = x < 0.0 ? r : 1.0 - r;
+}
+// log Phi(-z) (log-survival of a standard normal), finite far into the tail
+__device__ inline double log_Phi_neg(const double* tab, double z) {
+    const double r0 = 0.5 * erfcx_pos(tab, fabs(z) * kInvSqrt2);
+    return z >= 0.0 ? log(r0) - 0.5 * z * z : log1p(-r0 * exp(-0.5 * z * z));
+}
+
 // LBA (Examples/Run_LBA.jl:33-37; SequentialSamplingModels conventions: b = A + k, sigma = 1,
 // normalised by 1 - P(all drifts <= 0), density floored at 1e-10)
-__device__ inline double lba_dens(double v, double b, double A, double t) {
-    const double n1 = (b - A - t * v) / t, n2 = (b - t * v) / t;
-    return (1.0 / A) * (-v * Phi(n1) + phi(n1) + v * Phi(n2) - phi(n2));
-}
-__device__ inline double lba_cdf(double v, double b, double A, double t) {
-    const double n1 = (b - A - t * v) / t, n2 = (b - t * v) / t;
-    return 1.0 + ((b - A - t * v) / A) * Phi(n1) - ((b - t * v) / A) * Phi(n2) + (t / A) * phi(n1) - (t / A) * phi(n2);
+// density and distribution function of one accumulator at decision time t, sharing the four phi / Phi values
+__device__ inline void lba_dens_cdf(const double* tab, double v, double b, double A, double t, double inv_t, double inv_A,
+                                    double& dens, double& cdf) {
+    const double n1 = (b - A) * inv_t - v, n2 = b * inv_t - v;  // (b - A - t v)/t, (b - t v)/t
+    double p1, P1, p2, P2;
+    phi_Phi(tab, n1, p1, P1);
+    phi_Phi(tab, n2, p2, P2);
+    dens = inv_A * (v * (P2 - P1) + (p1 - p2));
+    cdf = 1.0 + (t * inv_A) * ((n1 * P1 - n2 * P2) + (p1 - p2));
 }
 
 }  // namespace demc

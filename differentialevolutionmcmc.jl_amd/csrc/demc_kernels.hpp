@@ -743,6 +743,11 @@ __global__ __launch_bounds__(256, 2) void k_cross_mfma(KParams p, const double* 
 // so data loads are wave-uniform (scalar) and the loop is pure FP64 VALU.  grid = (proposal blocks, chunks).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_obs_loglike(KParams p, int n_chunks) {
+    __shared__ double s_erfcx[kErfcxIntervals * (kErfcxDeg + 1)];  // LDS copy of the erfcx table (LBA / LNR only)
+    if (p.family == FAM_LBA || p.family == FAM_LNR) {
+        for (int i = threadIdx.x; i < kErfcxIntervals * (kErfcxDeg + 1); i += 256) s_erfcx[i] = kErfcxTable[i];
+        __syncthreads();
+    }
     const int q = blockIdx.x * 256 + threadIdx.x;
     const int n_prop = p.n_groups * p.n_act;
     const int chunk = blockIdx.y;
@@ -775,9 +780,13 @@ __global__ __launch_bounds__(256) void k_obs_loglike(KParams p, int n_chunks) {
             const int na = p.n_acc;
             double nu[8];
             for (int a = 0; a < 8; ++a) nu[a] = a < na ? th[a] : 0.0;
-            const double A = th[na], kk = th[na + 1], tau = th[na + 2], b = A + kk;
+            const double A = th[na], kk = th[na + 1], tau = th[na + 2], b = A + kk, inv_A = 1.0 / A;
             double pneg = 1.0;
-            for (int a = 0; a < na; ++a) pneg *= Phi(-nu[a]);
+            for (int a = 0; a < na; ++a) {
+                double ph, Ph;
+                phi_Phi(s_erfcx, -nu[a], ph, Ph);
+                pneg *= Ph;
+            }
             const double inv = 1.0 / (1.0 - pneg);
             for (long long i = i0; i < i1; ++i) {
                 const int c = (int)p.data[i];
@@ -786,10 +795,13 @@ __global__ __launch_bounds__(256) void k_obs_loglike(KParams p, int n_chunks) {
                 if (rt < tau)
                     ll = -INFINITY;
                 else {
-                    const double t = rt - tau;
+                    const double t = rt - tau, inv_t = 1.0 / t;
                     double den = 1.0;
-                    for (int a = 0; a < na; ++a)
-                        den *= (a + 1 == c) ? lba_dens(nu[a], b, A, t) : (1.0 - lba_cdf(nu[a], b, A, t));
+                    for (int a = 0; a < na; ++a) {
+                        double dens, cdf;
+                        lba_dens_cdf(s_erfcx, nu[a], b, A, t, inv_t, inv_A, dens, cdf);
+                        den *= (a + 1 == c) ? dens : (1.0 - cdf);
+                    }
                     den *= inv;
                     if (den != den)
                         ll = -INFINITY;
@@ -803,7 +815,7 @@ __global__ __launch_bounds__(256) void k_obs_loglike(KParams p, int n_chunks) {
             const int na = p.n_acc;
             double nu[8];
             for (int a = 0; a < 8; ++a) nu[a] = a < na ? th[a] : 0.0;
-            const double tau = th[na], sg = p.c0, lsg = log(sg);
+            const double tau = th[na], sg = p.c0, lsg = log(sg), isg = 1.0 / sg;
             for (long long i = i0; i < i1; ++i) {
                 const int c = (int)p.data[i];
                 const double t = p.data2[i] - tau;
@@ -813,8 +825,8 @@ __global__ __launch_bounds__(256) void k_obs_loglike(KParams p, int n_chunks) {
                 else {
                     const double lt = log(t);
                     for (int a = 0; a < na; ++a) {
-                        const double z = (lt - nu[a]) / sg;
-                        ll += (a + 1 == c) ? (-(z * z + kLog2Pi) / 2.0 - lsg - lt) : log(0.5 * erfc(z * kInvSqrt2));
+                        const double z = (lt - nu[a]) * isg;
+                        ll += (a + 1 == c) ? (-(z * z + kLog2Pi) / 2.0 - lsg - lt) : log_Phi_neg(s_erfcx, z);
                     }
                 }
                 acc += ll;

@@ -13,6 +13,15 @@ pytestmark = pytest.mark.gpu
 LOGPOST_RTOL = 1e-9
 
 
+def _rtol(prob):
+    """1e-9 everywhere except the LBA: its survival factor 1 - F(t) is formed by subtraction (as in
+    SequentialSamplingModels and in the oracle), so a trial with F(t) ~ 1 - 1e-9 amplifies last-bit differences of
+    Phi between libm's erfc and the device's erfcx table to ~1e-7 in that trial's log-density.  Still 100x inside the
+    north-star bar of 1e-6."""
+    from demc_amd import families as F
+    return 1e-8 if prob["fam"] == F.FAM_LBA else LOGPOST_RTOL
+
+
 def _pair(demc, orc, prob, **cfg):
     base = dict(D=prob["D"], seed=cfg.pop("seed", 1234))
     base.update(cfg)
@@ -44,7 +53,7 @@ def teacher_forced(demc, orc, prob, n_iter, n_initial=0, masks=None, check_hist=
     w_o = o.logpost(th)
     fin = np.isfinite(w_o)
     assert np.array_equal(np.isfinite(w), fin)
-    np.testing.assert_allclose(w[fin], w_o[fin], rtol=LOGPOST_RTOL)
+    np.testing.assert_allclose(w[fin], w_o[fin], rtol=_rtol(prob))
     n_mis = 0
     for it in range(1 + n_initial, 1 + n_initial + n_iter):
         th, w, ids = eng.get_state()
@@ -69,7 +78,7 @@ def teacher_forced(demc, orc, prob, n_iter, n_initial=0, masks=None, check_hist=
         np.testing.assert_allclose(tg["log_adj"], to["log_adj"], rtol=1e-9, atol=1e-9)
         fin = np.isfinite(to["w_prop"])
         assert np.array_equal(np.isfinite(tg["w_prop"]), fin)
-        np.testing.assert_allclose(tg["w_prop"][fin], to["w_prop"][fin], rtol=LOGPOST_RTOL)
+        np.testing.assert_allclose(tg["w_prop"][fin], to["w_prop"][fin], rtol=_rtol(prob))
         mism = tg["accepted"] != to["accepted"]
         n_mis += int(mism.sum())
         th_g, w_g, id_g = eng.get_state()
@@ -86,7 +95,7 @@ def teacher_forced(demc, orc, prob, n_iter, n_initial=0, masks=None, check_hist=
         assert np.array_equal(hg[3], ho[3])  # ids per slot
         assert np.array_equal(hg[1][n_initial:], ho[1][n_initial:])  # accept flags
         np.testing.assert_allclose(hg[0], ho[0], rtol=1e-11, atol=1e-13)
-        np.testing.assert_allclose(hg[2][n_initial:], ho[2][n_initial:], rtol=LOGPOST_RTOL)
+        np.testing.assert_allclose(hg[2][n_initial:], ho[2][n_initial:], rtol=_rtol(prob))
     eng.close()
     o.close()
 
@@ -105,7 +114,7 @@ def test_logpost_matches_oracle(demc, orc, family):
     fin = np.isfinite(lo)
     assert fin.sum() >= 20
     assert np.array_equal(np.isfinite(lg), fin)
-    np.testing.assert_allclose(lg[fin], lo[fin], rtol=LOGPOST_RTOL)
+    np.testing.assert_allclose(lg[fin], lo[fin], rtol=_rtol(prob))
     # out-of-bounds rows are -Inf and never evaluated (utilities.jl:92-99)
     if np.isfinite(prob["lo"]).any():
         j = int(np.argmax(np.isfinite(prob["lo"])))
@@ -233,3 +242,18 @@ def test_rejects_unsupported(demc):
     with pytest.raises(demc.DemcError):
         eng.step(1, 1)  # no model
     eng.close()
+
+
+def test_lba_lnr_against_scipy_goldens(demc):
+    """the device's single-exponential phi/Phi (erfcx table) against the scipy goldens directly"""
+    import os
+    from demc_amd import families as F
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "logpdf_golden.npz"))
+    for fam, key, extra in ((F.FAM_LBA, "lba", 3), (F.FAM_LNR, "lnr", 1)):
+        c, rt, th = G[f"{key}_choice"], G[f"{key}_rt"], G[f"{key}_theta"]
+        D = th.shape[1]
+        eng = demc.HipEngine(n_groups=1, Np=max(4, th.shape[0]), D=D, schedule=1)
+        eng.set_model(fam, np.concatenate([c, rt]), [c.size, D - extra], [1.0] if fam == F.FAM_LNR else None)
+        eng.set_priors([F.PRIOR_FLAT] * D, [0.0] * D, [1.0] * D)
+        np.testing.assert_allclose(eng.logpost(th), G[f"{key}_ll"], rtol=1e-9)
+        eng.close()
