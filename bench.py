@@ -75,20 +75,26 @@ def cpu_baseline(prob, Np, N, d, seconds_target=20.0):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 16))
     ng = max(2, cores)
-    o = O.Oracle(n_groups=ng, Np=Np, D=d, schedule=0, n_rows=0, store_history=0, seed=7, n_threads=cores)
-    o.set_model(F.FAM_MVN_FULL, prob["X"], [N, d], prob["Sigma"])
-    o.set_priors([F.PRIOR_NORMAL] * d, [0.0] * d, [1.0] * d)
-    o.set_bounds([-np.inf] * d, [np.inf] * d)
-    o.set_state(init_theta(ng * Np, d, 1234))
-    t0 = time.time()
-    o.step(1, 1)
-    t1 = time.time() - t0
-    iters = int(max(1, min(20, seconds_target / max(t1, 1e-3))))
-    t0 = time.time()
-    o.step(2, iters)
-    dt = time.time() - t0
-    o.close()
-    return dict(value=ng * Np * iters / dt, unit="particle-updates/s", cores=cores, kind="port",
+    def run(n_groups, threads, seconds):
+        o = O.Oracle(n_groups=n_groups, Np=Np, D=d, schedule=0, n_rows=0, store_history=0, seed=7, n_threads=threads)
+        o.set_model(F.FAM_MVN_FULL, prob["X"], [N, d], prob["Sigma"])
+        o.set_priors([F.PRIOR_NORMAL] * d, [0.0] * d, [1.0] * d)
+        o.set_bounds([-np.inf] * d, [np.inf] * d)
+        o.set_state(init_theta(n_groups * Np, d, 1234))
+        t0 = time.time()
+        o.step(1, 1)
+        t1 = time.time() - t0
+        iters = int(max(1, min(20, seconds / max(t1, 1e-3))))
+        t0 = time.time()
+        o.step(2, iters)
+        dt = time.time() - t0
+        o.close()
+        return n_groups * Np * iters / dt, iters
+
+    one_thread, _ = run(1, 1, 3.0)  # one group on one thread, ~3 s
+    value, iters = run(ng, cores, seconds_target)
+    dt = ng * Np * iters / value
+    return dict(value=value, unit="particle-updates/s", cores=cores, kind="port", value_single_thread=one_thread,
                 sample=f"cfg3 shape (D={d}, N={N}, Np={Np}) on {ng} of the groups, {iters} iterations, reference "
                        f"schedule (sequential in-group sweep, one group per OpenMP thread), whitened O(N*D) "
                        f"likelihood per proposal; gcc -O3 -march=native -fopenmp")
