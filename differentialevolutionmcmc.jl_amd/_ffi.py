@@ -176,7 +176,7 @@ class HipEngine:
         self._ck(self.L.demc_set_bounds(self.h, _d(lo), _d(hi)))
 
     def set_blocks(self, masks):
-        masks = np.ascontiguousarray(masks, dtype=np.uint8).reshape(-1, self.D)
+        masks = np.ascontiguousarray(masks, dtype=np.uint8).reshape(-1, self.D)  # zero rows: blocking off
         self._ck(self.L.demc_set_blocks(self.h, masks.ctypes.data_as(_bp), masks.shape[0]))
 
     def set_state(self, theta, weight=None, ids=None):

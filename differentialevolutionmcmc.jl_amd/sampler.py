@@ -60,8 +60,10 @@ def _flat_layout(model, de, theta0):
                 if sizes[j] != 1:
                     raise _ffi.DemcError(_ffi.EINVAL, "hierarchical scale must be a scalar parameter")
                 ref[sl] = offs[j]
+    # de.blocks -> byte masks.  Whether blocking is ON is asked per iteration (de.blocking_on(de), main.jl:137,162),
+    # see _blocking_schedule(); the masks are built whenever de.blocks holds real blocks.
     masks = None
-    if de.blocking_on(de):
+    if _has_blocks(de.blocks):
         rows = []
         for blk in de.blocks:
             m = np.zeros(D, np.uint8)
@@ -71,6 +73,32 @@ def _flat_layout(model, de, theta0):
             rows.append(m)
         masks = np.stack(rows)
     return dict(shapes=shapes, sizes=sizes, offs=offs, D=D, lo=lo, hi=hi, kind=kind, a=a, b=b_, ref=ref, masks=masks)
+
+
+def _has_blocks(blocks):
+    """DE's default is blocks = [false] (structs.jl:99): a placeholder, not a block list"""
+    try:
+        return len(blocks) > 0 and not isinstance(blocks[0], (bool, np.bool_))
+    except TypeError:
+        return False
+
+
+def _blocking_schedule(de, n_iter):
+    """de.blocking_on(de) is a user hook evaluated on every iteration with de.iter set (main.jl:34,137,162).  It runs on
+    the host; consecutive iterations with the same answer become one engine call.  -> list of (first_iter, count, on)"""
+    saved = de.iter
+    flags = []
+    for it in range(1, n_iter + 1):
+        de.iter = it + de.n_initial
+        flags.append(bool(de.blocking_on(de)))
+    de.iter = saved
+    runs = []
+    for i, f in enumerate(flags):
+        if runs and runs[-1][2] == f:
+            runs[-1][1] += 1
+        else:
+            runs.append([i + 1, 1, f])
+    return runs
 
 
 def engine_config(de, lay, n_iter, backend, n_groups_local=None, group_offset=0, store_history=True, n_initial=None):
@@ -90,8 +118,6 @@ def configure_engine(eng, model, lay):
     eng.set_model(model.loglike.family, data, dims, hyper)
     eng.set_priors(lay["kind"], lay["a"], lay["b"], lay["ref"])
     eng.set_bounds(lay["lo"], lay["hi"])
-    if lay["masks"] is not None:
-        eng.set_blocks(lay["masks"])
 
 
 def sample_init(model, de, n_iter, lay, P):
@@ -169,14 +195,21 @@ def _run(model, de, n_iter, backend, progress, engine_factory):
             eng.set_history_rows(0, init_rows)
         eng.set_state(theta)  # weights: evaluate_fitness! on device (utilities.jl:19)
         # for iter in 1:n_iter: de.iter = iter + n_initial; groups = stepfun(model, de, groups)  (main.jl:33-38)
-        chunk = max(1, n_iter // 20) if progress else n_iter
-        it = 1
-        while it <= n_iter:
-            n = min(chunk, n_iter - it + 1)
-            eng.step(it + de.n_initial, n)
-            it += n
-            if progress:
-                print(f"\rDE-MCMC {it - 1}/{n_iter}", end="", flush=True)
+        no_blocks = np.zeros((0, lay["D"]), np.uint8)
+        done = 0
+        for first, count, on in _blocking_schedule(de, n_iter):
+            if on and lay["masks"] is None:
+                raise _ffi.DemcError(_ffi.EINVAL, "blocking_on(de) is true but de.blocks holds no blocks")
+            eng.set_blocks(lay["masks"] if on else no_blocks)
+            chunk = max(1, n_iter // 20) if progress else count
+            it = first
+            while it < first + count:
+                n = min(chunk, first + count - it)
+                eng.step(it + de.n_initial, n)
+                it += n
+                done += n
+                if progress:
+                    print(f"\rDE-MCMC {done}/{n_iter}", end="", flush=True)
         if progress:
             print()
         de.iter = n_iter + de.n_initial

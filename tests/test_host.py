@@ -66,6 +66,34 @@ def test_nested_theta_layout_names_bounds_blocks():
                                                  "B[2,2]", "acceptance", "lp"]
 
 
+def test_blocking_on_is_evaluated_per_iteration(orc):
+    """de.blocking_on(de) is called on every iteration with de.iter set (main.jl:34,137): here blocks are used on even
+    iterations only; the run must equal the same schedule driven by hand on the engine"""
+    rng = np.random.default_rng(1)
+    data = rng.normal(0, 1, 40)
+    th_init = [list(x) for x in np.stack([rng.normal(0, 1, 24), rng.uniform(0.5, 2, 24)], 1)]
+    it = iter(th_init)
+    sp = lambda: next(it)
+    model = D.DEModel(sample_prior=sp, prior_loglike=D.Priors(μ=D.Normal(0, 10), σ=D.TruncatedCauchy(0, 1)),
+                      loglike=D.GaussianLikelihood(), data=data, names=("μ", "σ"))
+    de = D.DE(sample_prior=sp, bounds=((-np.inf, np.inf), (0.0, np.inf)), burnin=5, Np=6, discard_burnin=False,
+              blocking_on=lambda de: de.iter % 2 == 0, blocks=[[True, False], [False, True]])
+    assert S._blocking_schedule(de, 5) == [[1, 1, False], [2, 1, True], [3, 1, False], [4, 1, True], [5, 1, False]]
+    it = iter([th_init[0]] + th_init)  # sample() draws one extra prior sample to learn the layout
+    ch = D.sample(model, de, D.HIPBackend(seed=4), 12, engine_factory=oracle_factory(orc))
+    o = orc.Oracle(n_groups=4, Np=6, D=2, burnin=5, n_rows=12, schedule=2, seed=4)
+    o.set_model(0, data, [40])
+    o.set_priors([1, 2], [0, 0], [10, 1])
+    o.set_bounds([-np.inf, 0], [np.inf, np.inf])
+    o.set_state(np.array(th_init))
+    for i in range(1, 13):
+        o.set_blocks(np.array([[1, 0], [0, 1]], np.uint8) if i % 2 == 0 else np.zeros((0, 2), np.uint8))
+        o.step(i, 1)
+    th, acc, lp, idh = o.get_history(0, 12)
+    exp_th, _, _ = S.rekey_by_id(th, acc, lp, idh)
+    np.testing.assert_array_equal(np.transpose(ch.value[:, :2, :], (0, 2, 1)), exp_th)
+
+
 def test_hierarchical_prior_reference_resolves_to_flat_index():
     th0 = [1.0, 1.0, np.zeros(5)]
     model = D.DEModel(sample_prior=lambda: th0, names=("mu_b0", "sd_b0", "b0"), data=np.zeros(5),
