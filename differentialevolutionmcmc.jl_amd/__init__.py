@@ -9,7 +9,8 @@ from ._ffi import DemcError, HipEngine
 from .chains import Chains
 from .families import (Beta, BinomialLikelihood, Flat, GaussianLikelihood, HierBinomialLikelihood,
                        HierGaussianLikelihood, LBALikelihood, LNRLikelihood, MvNormalFullLikelihood,
-                       MvNormalIsoLikelihood, Normal, Priors, RastriginObjective, TruncatedCauchy, Uniform)
+                       MvNormalIsoLikelihood, Normal, Priors, RastriginObjective, SourceLikelihood, TruncatedCauchy,
+                       Uniform)
 from .sampler import get_optimal, optimize, sample
 from .structs import (DE, DEModel, HIPBackend, MCMCThreads, Particle, as_union, compute_posterior, evaluate_fun,
                       fixed_gamma, maximize, mh_update, minimize, project, random_gamma, resample, sample_current,

@@ -16,7 +16,7 @@ _CODE = {1: "DEMC_EINVAL", 2: "DEMC_EHIP", 3: "DEMC_ENOMEM", 4: "DEMC_ERCCL", 5:
 
 EXPORTS = [
     "demc_version", "demc_create", "demc_destroy", "demc_last_error", "demc_set_stream", "demc_set_model",
-    "demc_set_priors", "demc_set_bounds", "demc_set_blocks", "demc_set_state", "demc_get_state",
+    "demc_set_model_source", "demc_set_priors", "demc_set_bounds", "demc_set_blocks", "demc_set_state", "demc_get_state",
     "demc_set_history_rows", "demc_get_history", "demc_step", "demc_update", "demc_migration_due",
     "demc_migration_pack", "demc_migration_apply", "demc_logpost", "demc_get_trace", "demc_timing_enable",
     "demc_timing_read",
@@ -78,6 +78,7 @@ def load():
     L.demc_last_error.restype = C.c_char_p
     L.demc_set_stream.argtypes = [H, C.c_void_p]
     L.demc_set_model.argtypes = [H, C.c_int32, _dp, _lp, C.c_int32, _dp, C.c_int32]
+    L.demc_set_model_source.argtypes = [H, C.c_char_p, _dp, _lp, C.c_int32, _dp, C.c_int32]
     L.demc_set_priors.argtypes = [H, _ip, _dp, _dp, _ip]
     L.demc_set_bounds.argtypes = [H, _dp, _dp]
     L.demc_set_blocks.argtypes = [H, _bp, C.c_int32]
@@ -162,6 +163,14 @@ class HipEngine:
         hyper = None if hyper is None else np.ascontiguousarray(np.asarray(hyper, dtype=np.float64).ravel())
         self._ck(self.L.demc_set_model(self.h, family, _d(data), dims.ctypes.data_as(_lp), dims.size, _d(hyper),
                                        0 if hyper is None else hyper.size))
+
+    def set_model_source(self, source, data, dims, hyper=None):
+        """user log-density plug-in: HIP source defining demc_user_obs(...) (include/demc.h), JIT-compiled for gfx950"""
+        data = np.ascontiguousarray(np.asarray(data, dtype=np.float64).ravel())
+        dims = np.ascontiguousarray(np.asarray(dims, dtype=np.int64).ravel())
+        hyper = None if hyper is None else np.ascontiguousarray(np.asarray(hyper, dtype=np.float64).ravel())
+        self._ck(self.L.demc_set_model_source(self.h, source.encode(), _d(data), dims.ctypes.data_as(_lp), dims.size,
+                                              _d(hyper), 0 if hyper is None else hyper.size))
 
     def set_priors(self, kind, a, b, ref=None):
         kind = np.ascontiguousarray(kind, dtype=np.int32)

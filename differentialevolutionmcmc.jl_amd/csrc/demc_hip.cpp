@@ -11,6 +11,7 @@
 #include "../../include/demc.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
 
 #include <cmath>
 #include <cstdio>
@@ -54,6 +55,11 @@ struct demc_handle {
     int ks_t = 0, n_kpass = 0;  // MFMA k-steps per pass (template) and passes over the dimensions
     double *data = nullptr, *Ainv = nullptr, *Ypad = nullptr, *Xf = nullptr, *sx = nullptr, *xbar = nullptr;
     size_t data2_off = 0;
+    // user plug-in (demc_set_model_source): JIT-compiled module, kernel and its hyper-parameters
+    hipModule_t user_module = nullptr;
+    hipFunction_t user_kernel = nullptr;
+    double* user_hyper = nullptr;
+    int user_nhyper = 0;
     double c0 = 0, c1 = 0, c2 = 0;
     int partial_cap = 64;
     int lpp = 1;
@@ -158,6 +164,44 @@ void launch_cross(demc_handle* h, const KParams& k, int grid, int k0, int n_chun
                        h->n_tiles, n_chunks, part0);
 }
 
+// Kernarg of the JIT-compiled user-likelihood kernel; the same text is prepended to the user's source.
+struct UserKParams {
+    int n_groups, Np, D, a_lo, n_act, n_chunks, nhyper, pad;
+    long long N, P;
+    const double* prop;
+    double* partial;
+    const double* data;
+    const double* hyper;
+};
+const char* kUserPrologue = R"SRC(
+struct UserKParams {
+    int n_groups, Np, D, a_lo, n_act, n_chunks, nhyper, pad;
+    long long N, P;
+    const double* prop;
+    double* partial;
+    const double* data;
+    const double* hyper;
+};
+__device__ double demc_user_obs(const double* theta, int D, const double* data, long long N, long long i,
+                                const double* hyper, int nhyper);
+)SRC";
+// thread per proposal x observation chunks: same mapping as k_obs_loglike
+const char* kUserKernel = R"SRC(
+extern "C" __global__ __launch_bounds__(256) void k_user_loglike(UserKParams p) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int chunk = blockIdx.y;
+    if (q >= p.n_groups * p.n_act) return;
+    const int g = q / p.n_act;
+    const size_t slot = (size_t)g * p.Np + p.a_lo + (q - g * p.n_act);
+    const double* th = p.prop + slot * p.D;
+    const long long per = (p.N + p.n_chunks - 1) / p.n_chunks;
+    const long long i0 = chunk * per, i1 = (i0 + per < p.N) ? i0 + per : p.N;
+    double acc = 0.0;
+    for (long long i = i0; i < i1; ++i) acc += demc_user_obs(th, p.D, p.data, p.N, i, p.hyper, p.nhyper);
+    p.partial[(size_t)chunk * p.P + slot] = acc;
+}
+)SRC";
+
 // K2 dispatch for the active set described by k.  Sets k.n_partials.
 int launch_loglike(demc_handle* h, KParams& k) {
     const long long n_prop = (long long)k.n_groups * k.n_act;
@@ -209,6 +253,25 @@ int launch_loglike(demc_handle* h, KParams& k) {
                                h->stream, k, n_chunks);
             tick(h, 2, false);
             k.n_partials = n_chunks;
+        } break;
+        case FAM_USER: {
+            long long want = (262144 + n_prop - 1) / n_prop;
+            long long cap = h->N / 32;
+            if (cap < 1) cap = 1;
+            if (want > cap) want = cap;
+            if (want > h->partial_cap) want = h->partial_cap;
+            UserKParams u;
+            u.n_groups = k.n_groups; u.Np = k.Np; u.D = k.D; u.a_lo = k.a_lo; u.n_act = k.n_act; u.n_chunks = (int)want;
+            u.nhyper = h->user_nhyper; u.pad = 0; u.N = h->N; u.P = h->P; u.prop = k.prop; u.partial = k.partial;
+            u.data = h->data; u.hyper = h->user_hyper;
+            size_t sz = sizeof u;
+            void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &u, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+            tick(h, 2, true);
+            hipError_t e = hipModuleLaunchKernel(h->user_kernel, (unsigned)((n_prop + 255) / 256), (unsigned)want, 1, 256, 1, 1, 0,
+                                                 h->stream, nullptr, cfg);
+            tick(h, 2, false);
+            if (e != hipSuccess) return fail(h, DEMC_EHIP, std::string("hipModuleLaunchKernel: ") + hipGetErrorString(e));
+            k.n_partials = (int)want;
         } break;
         case FAM_HIER_BINOMIAL:
         case FAM_HIER_GAUSSIAN: {
@@ -439,6 +502,8 @@ int32_t demc_destroy(demc_handle* h) {
                     h->Xf, h->sx, h->xbar};
     for (void* p : ptrs)
         if (p) hipFree(p);
+    if (h->user_module) hipModuleUnload(h->user_module);
+    if (h->user_hyper) hipFree(h->user_hyper);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
     return DEMC_OK;
@@ -599,6 +664,51 @@ int32_t demc_set_model(demc_handle* h, int32_t family, const double* data, const
         HIPCHK(hipMemcpy(h->data, dev.data(), sizeof(double) * dev.size(), hipMemcpyHostToDevice));
     }
     h->family = family;
+    return size_k1_lds(h);
+}
+
+int32_t demc_set_model_source(demc_handle* h, const char* hip_source, const double* data, const int64_t* dims, int32_t ndims,
+                              const double* hyper, int32_t nhyper) {
+    if (!h || !hip_source) return DEMC_EINVAL;
+    if (ndims < 1 || !dims || dims[0] < 1 || !data) return fail(h, DEMC_EINVAL, "user model: dims[0] = number of observations, data required");
+    long long n_data = 1;
+    for (int i = 0; i < ndims; ++i) n_data *= dims[i];
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (double** p : {&h->data, &h->Ainv, &h->Ypad, &h->Xf, &h->sx, &h->xbar, &h->user_hyper})
+        if (*p) { hipFree(*p); *p = nullptr; }
+    if (h->user_module) { hipModuleUnload(h->user_module); h->user_module = nullptr; h->user_kernel = nullptr; }
+    h->family = -1; h->d = 0; h->n_acc = 0; h->dpad = 0; h->n_tiles = 0; h->c0 = h->c1 = h->c2 = 0; h->data2_off = 0;
+    // compile prologue + user source + kernel for gfx950
+    const std::string src = std::string(kUserPrologue) + hip_source + kUserKernel;
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "demc_user_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+        return fail(h, DEMC_EHIP, "hiprtcCreateProgram failed");
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+    const hiprtcResult cr = hiprtcCompileProgram(prog, 3, opts);
+    if (cr != HIPRTC_SUCCESS) {
+        size_t ls = 0;
+        hiprtcGetProgramLogSize(prog, &ls);
+        std::string log(ls, '\0');
+        if (ls) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        return fail(h, DEMC_EINVAL, std::string("user model does not compile: ") + hiprtcGetErrorString(cr) + "\n" + log);
+    }
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    std::vector<char> code(cs);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    HIPCHK(hipModuleLoadData(&h->user_module, code.data()));
+    HIPCHK(hipModuleGetFunction(&h->user_kernel, h->user_module, "k_user_loglike"));
+    h->N = dims[0];
+    ALLOC(h->data, (size_t)n_data);
+    HIPCHK(hipMemcpy(h->data, data, sizeof(double) * (size_t)n_data, hipMemcpyHostToDevice));
+    h->user_nhyper = nhyper > 0 ? nhyper : 0;
+    if (h->user_nhyper) {
+        ALLOC(h->user_hyper, (size_t)h->user_nhyper);
+        HIPCHK(hipMemcpy(h->user_hyper, hyper, sizeof(double) * (size_t)h->user_nhyper, hipMemcpyHostToDevice));
+    }
+    h->family = FAM_USER;
     return size_k1_lds(h);
 }
 

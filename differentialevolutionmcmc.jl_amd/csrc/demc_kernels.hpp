@@ -22,7 +22,7 @@ namespace demc {
 
 enum Family : int {
     FAM_GAUSSIAN = 0, FAM_MVN_ISO = 1, FAM_MVN_FULL = 2, FAM_BINOMIAL = 3, FAM_HIER_BINOMIAL = 4,
-    FAM_HIER_GAUSSIAN = 5, FAM_LBA = 6, FAM_LNR = 7, FAM_RASTRIGIN = 8
+    FAM_HIER_GAUSSIAN = 5, FAM_LBA = 6, FAM_LNR = 7, FAM_RASTRIGIN = 8, FAM_USER = 100
 };
 enum Mode : int { MODE_STEP = 0, MODE_IDENT = 1 };  // IDENT: theta' = theta, always accepted (init / logpost)
 

@@ -10,6 +10,7 @@ import numpy as np
 # likelihood family ids (include/demc.h)
 FAM_GAUSSIAN, FAM_MVN_ISO, FAM_MVN_FULL, FAM_BINOMIAL, FAM_HIER_BINOMIAL, FAM_HIER_GAUSSIAN, FAM_LBA, FAM_LNR, \
     FAM_RASTRIGIN = range(9)
+FAM_USER = 100
 PRIOR_FLAT, PRIOR_NORMAL, PRIOR_HALFCAUCHY, PRIOR_UNIFORM, PRIOR_BETA, PRIOR_NORMAL_REF = range(6)
 
 
@@ -167,3 +168,23 @@ class RastriginObjective(Likelihood):
 
     def pack(self, data, shapes):
         return None, [], None
+
+
+class SourceLikelihood(Likelihood):
+    """Plug-in for models outside the registered family.  The reference's `loglike(data, theta...)` closures are sums
+    of per-observation log-densities (e.g. Examples/Gaussian_Example.jl:26-28); a Julia closure cannot run in a kernel,
+    but the same term written as a HIP device function can:
+
+        __device__ double demc_user_obs(const double* theta, int D, const double* data, long long N, long long i,
+                                        const double* hyper, int nhyper);   // log-density of observation i
+
+    `data` is flattened row-major with shape (N, ...) (observations first); the source is JIT-compiled for gfx950 by
+    demc_set_model_source (include/demc.h)."""
+    family = FAM_USER
+
+    def __init__(self, source, hyper=None):
+        self.source, self.hyper = source, hyper
+
+    def pack(self, data, shapes):
+        x = np.ascontiguousarray(np.asarray(data, dtype=np.float64))
+        return x, list(x.shape), self.hyper

@@ -4,7 +4,7 @@ import numpy as np
 
 from . import _ffi
 from .chains import Chains
-from .families import PRIOR_NORMAL_REF, Priors
+from .families import PRIOR_NORMAL_REF, Priors, SourceLikelihood
 from .structs import (DE, HIPBackend, LOGLIKE_MODES, MCMCThreads, SCHEDULES, DEModel, Particle, maximize)
 
 
@@ -115,7 +115,10 @@ def engine_config(de, lay, n_iter, backend, n_groups_local=None, group_offset=0,
 
 def configure_engine(eng, model, lay):
     data, dims, hyper = model.loglike.pack(model.data, lay["shapes"])
-    eng.set_model(model.loglike.family, data, dims, hyper)
+    if isinstance(model.loglike, SourceLikelihood):
+        eng.set_model_source(model.loglike.source, data, dims, hyper)
+    else:
+        eng.set_model(model.loglike.family, data, dims, hyper)
     eng.set_priors(lay["kind"], lay["a"], lay["b"], lay["ref"])
     eng.set_bounds(lay["lo"], lay["hi"])
 

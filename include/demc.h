@@ -75,7 +75,8 @@ enum {
     DEMC_FAM_HIER_GAUSSIAN = 5,  /* theta=(mu_b0,sd_b0,b0[S],sigma); data Y[S][n]; dims=[S,n]  Examples/Hierarchical_Example.jl:36-44 */
     DEMC_FAM_LBA = 6,            /* theta=(nu[A],A,k,tau); data=[choice[N], rt[N]]; dims=[N,A] Examples/Run_LBA.jl:33-37 */
     DEMC_FAM_LNR = 7,            /* theta=(nu[A],tau); data=[choice[N], rt[N]]; dims=[N,A]; hyper=[sigma] test/lognormal_race_tests.jl:9-12 */
-    DEMC_FAM_RASTRIGIN = 8       /* objective only; dims=[]                                test/optimization_tests.jl:15-23 */
+    DEMC_FAM_RASTRIGIN = 8,      /* objective only; dims=[]                                test/optimization_tests.jl:15-23 */
+    DEMC_FAM_USER = 100          /* per-observation log-density supplied as HIP source, see demc_set_model_source */
 };
 
 /* Per-scalar prior table = the registered form of model.prior_loglike (structs.jl:185). */
@@ -130,6 +131,16 @@ int32_t demc_set_stream(demc_handle* h, void* hip_stream);
 /* replaces the closure pair built by DEModel(...) (structs.jl:176-189) */
 int32_t demc_set_model(demc_handle* h, int32_t family, const double* host_data, const int64_t* dims, int32_t ndims,
                        const double* host_hyper, int32_t nhyper);
+/* Plug-in for models outside the registered family: the reference's `loglike(data, theta...)` closures are, in every
+ * test and example, sums of per-observation log-densities (e.g. `sum(logpdf.(Normal(mu, sigma), data))`,
+ * Examples/Gaussian_Example.jl:26-28).  `hip_source` must define
+ *     __device__ double demc_user_obs(const double* theta, int D, const double* data, long long N, long long i,
+ *                                     const double* hyper, int nhyper);
+ * = the log-density of observation i (data is the flat host_data array, N = dims[0]); log-likelihood = sum over i.
+ * The source is compiled for gfx950 at this call (hiprtc) into the same thread-per-proposal streaming kernel the
+ * registered scalar-data families use; compile errors are returned through demc_last_error. */
+int32_t demc_set_model_source(demc_handle* h, const char* hip_source, const double* host_data, const int64_t* dims,
+                              int32_t ndims, const double* host_hyper, int32_t nhyper);
 int32_t demc_set_priors(demc_handle* h, const int32_t* kind, const double* a, const double* b, const int32_t* ref);
 /* de.bounds flattened to one (lo,hi) per scalar; +-Inf allowed (utilities.jl:70-78) */
 int32_t demc_set_bounds(demc_handle* h, const double* lo, const double* hi);
