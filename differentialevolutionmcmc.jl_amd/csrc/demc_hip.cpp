@@ -486,6 +486,10 @@ int32_t demc_create(const demc_config* cfg, demc_handle** out) {
     // lanes per particle: every lane owns dim pairs {2k,2k+1}
     h->lpp = pow2_ceil((c.D + 1) / 2);
     if (h->lpp > 64) h->lpp = 64;
+    if (const char* e = std::getenv("DEMC_LPP")) {  // A/B experiments: fewer lanes per particle = less replicated scalar work
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 64 && (v & (v - 1)) == 0 && v <= h->lpp) h->lpp = v;
+    }
     int rc_lds = size_k1_lds(h);
     if (rc_lds != DEMC_OK) return rc_lds;
     if ((size_t)c.n_groups_total * sizeof(int) > 48 * 1024) return fail(h, DEMC_EINVAL, "n_groups_total too large");
