@@ -234,9 +234,17 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
 
     if (TILE) {
         if (even) {
-            const double2* src = reinterpret_cast<const double2*>(grows);
-            double2* dst = reinterpret_cast<double2*>(tile);
-            for (int i = tid; i < (Np * D) >> 1; i += 256) dst[i] = src[i];
+            // LDS-DMA (global_load_lds_dwordx4): 16 B per lane straight into LDS, no VGPR round trip; the destination of
+            // one wave-instruction is a wave-uniform LDS base + lane*16, i.e. exactly a linear copy of the tile.  The
+            // loads stay in flight while the workgroup computes its coins and softmax weights below.
+            const int n16 = (Np * D) >> 1;  // 16-byte pieces
+            const int wave = tid >> 6, lane = tid & 63;
+            for (int c0 = wave * 64; c0 < n16; c0 += 256) {
+                if (c0 + lane < n16)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(grows + 2 * (size_t)(c0 + lane)),
+                        (__attribute__((address_space(3))) void*)(tile + 2 * (size_t)c0), 16, 0, 0);
+            }
         } else
             for (int i = tid; i < Np * D; i += 256) tile[i] = grows[i];
     }
@@ -287,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
         __syncthreads();
         if (tid == 0) s_total = cdf[n_cdf - 1];
     }
+    if (TILE && even) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA pieces have landed
     __syncthreads();
 
     const int sub = tid / lpp, sl = tid % lpp;
