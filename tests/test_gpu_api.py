@@ -341,3 +341,19 @@ def test_user_source_model_end_to_end():
     d = ch.describe()["rate"]
     assert abs(d["mean"] - 201 / x.sum()) < 0.02 * 201 / x.sum()
     assert abs(d["std"] - np.sqrt(201) / x.sum()) < 0.05 * np.sqrt(201) / x.sum()
+
+
+def test_plain_c_caller_of_the_abi(tmp_path):
+    """tools/demc_cdriver.c: a host with no Python in it (what a Julia @ccall shim or any FFI does) runs
+    Examples/Gaussian_Example.jl through include/demc.h"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "differentialevolutionmcmc.jl_amd")
+    exe = str(tmp_path / "demc_cdriver")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "tools", "demc_cdriver.c"), "-o", exe,
+                           "-L", libdir, "-ldemc_hip", "-lm", "-Wl,-rpath-link,/opt/rocm/lib"])
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "C-ABI driver OK" in out.stdout
