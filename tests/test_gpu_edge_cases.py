@@ -146,3 +146,20 @@ def test_zero_iterations_and_history_bounds(demc):
     th, acc, lp, idh = eng.get_history(0, 3)
     assert th.shape == (3, 8, 2) and np.isfinite(lp).all()
     eng.close()
+
+
+def test_cfg4_shape_parity(demc, orc):
+    """BASELINE cfg4's shape at full width: hierarchical Binomial with S = 1e4 subjects (D = 10 002), the two blocks
+    [hyper ; subjects] of Examples/Hierarchical_Example.jl:88-92, snooker on -- a few groups instead of 128"""
+    prob = make_problem("hier_binomial", np.random.default_rng(44), S=10000)
+    D_ = prob["D"]
+    m0 = np.zeros(D_, np.uint8)
+    m0[:2] = 1
+    teacher_forced(demc, orc, prob, n_iter=3, n_groups=2, Np=6, schedule=2, burnin=2, theta_snooker=0.2, alpha=1.0,
+                   masks=np.stack([m0, 1 - m0]), exact_de=False)
+
+
+def test_cfg5_shape_parity(demc, orc):
+    """BASELINE cfg5's shape with fewer trials/groups: LBA, 3 accumulators (6 parameters), snooker on"""
+    prob = make_problem("lba", np.random.default_rng(45), N=2000, na=3)
+    teacher_forced(demc, orc, prob, n_iter=6, n_groups=4, Np=16, schedule=2, burnin=3, theta_snooker=0.1)
