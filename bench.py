@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--np", type=int, default=256, dest="Np")
     ap.add_argument("--nobs", type=int, default=100000)
     ap.add_argument("--dim", type=int, default=32)
+    ap.add_argument("--burnin", type=int, default=1000, help="DE burnin (reference default 1000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -138,7 +139,7 @@ def main():
     n_rows = a.warmup + a.steps
     prob = make_cfg3(G, Np, N, d)
     eng = demc_amd.HipEngine(n_groups=G, Np=Np, D=d, n_rows=n_rows, schedule=2 if a.schedule == "two_colour" else 1,
-                             group_offset=rank * G, n_groups_total=G * world, seed=20260001, device_id=local,
+                             group_offset=rank * G, n_groups_total=G * world, seed=20260001, device_id=local, burnin=a.burnin,
                              loglike_mode=0 if a.mode == "streaming" else 1, trace=0)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     configure(eng, prob, d)

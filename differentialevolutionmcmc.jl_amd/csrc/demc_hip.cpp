@@ -153,7 +153,7 @@ KParams base_params(demc_handle* h) {
     k.family = h->family; k.N = h->N; k.d = h->d; k.n_acc = h->n_acc; k.n_partials = 1;
     k.partial = h->partial; k.aux = h->aux; k.data = h->data; k.data2 = h->data ? h->data + h->data2_off : nullptr;
     k.c0 = h->c0; k.c1 = h->c1; k.c2 = h->c2;
-    k.n_split = 1; k.fuse_prep = 0; k.fuse_accept = 0; k.write_prop = 1; k.trace = c.trace;
+    k.n_split = 1; k.fuse_prep = 0; k.prep_mfma = 0; k.fuse_accept = 0; k.write_prop = 1; k.trace = c.trace;
     k.Ainv = h->Ainv; k.sx = nullptr; k.xbar = h->xbar; k.Ypad = h->Ypad; k.dpad = h->dpad;
     return k;
 }
@@ -296,6 +296,8 @@ int launch_phase(demc_handle* h, KParams& k) {
     // K1 tails: MvNormal preparation always; the whole update when the likelihood is O(D^2) given data-only
     // statistics and a phase writes only rows that no other workgroup reads (two_colour, or the identity pass)
     k.fuse_prep = is_mvn(h->family) ? 1 : 0;
+    k.prep_mfma = (h->family == FAM_MVN_FULL && k.lpp == 16 && h->d <= 32) ? 1 : 0;
+    if (const char* e = std::getenv("DEMC_PREP_MFMA")) k.prep_mfma = k.prep_mfma && e[0] == '1';  // A/B experiments
     k.sx = (k.fuse_prep && suff) ? h->sx : nullptr;
     k.Ainv = (h->family == FAM_MVN_FULL) ? h->Ainv : nullptr;
     k.fuse_accept = (k.fuse_prep && suff && c.fuse != 1 &&

@@ -73,6 +73,7 @@ struct KParams {
     int tile_in_lds;          // K1: stage the group tile in LDS
     int n_split;              // K1: workgroups per group
     int fuse_prep;            // K1 computes y = A^-1 theta', a = theta'.y (MvNormal families)
+    int prep_mfma;            // ... on the matrix cores (full Sigma, d <= 32, 16 lanes per particle)
     int fuse_accept;          // K1 finishes the update (cheap likelihoods, two_colour)
     int write_prop;           // K1 writes proposals to HBM (needed by K2/K3 or by the trace)
     int trace;                // keep the per-slot diagnostic trace
@@ -94,6 +95,8 @@ struct KParams {
     double c0, c1, c2;        // family constants
 };
 
+typedef double d4 __attribute__((ext_vector_type(4)));  // C/D fragment of v_mfma_f64_16x16x4_f64
+
 // q-th active particle of the phase -> (group, particle-in-group, local slot); 32-bit on purpose (P < 2^31)
 __device__ inline int slot_of(const KParams& p, int q, int& g, int& pl) {
     g = q / p.n_act;
@@ -105,10 +108,43 @@ __device__ inline int slot_of(const KParams& p, int q) {
     return slot_of(p, q, g, pl);
 }
 
+// ---- cross-lane data movement inside a sub-group, on the DPP path (VALU speed) instead of ds_bpermute (LDS round trip).
+// hip's __shfl* always lower to ds_bpermute_b32 (~100 cycles of latency each); a sub-group of up to 16 lanes lives inside one
+// DPP row, where quad_perm / row_half_mirror / row_mirror give an all-reduce in four VALU-rate steps.
+template <int CTRL>
+__device__ inline int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ inline double dpp_mov(double v) {
+    return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v)));
+}
+template <int CTRL>
+__device__ inline int dpp_mov(int v) {
+    return dpp_i32<CTRL>(v);
+}
+constexpr int kDppXor1 = 0xB1;         // quad_perm:[1,0,3,2]
+constexpr int kDppXor2 = 0x4E;         // quad_perm:[2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;  // row_half_mirror: lane i <-> 7-i inside each 8
+constexpr int kDppMirror = 0x140;      // row_mirror: lane i <-> 15-i inside each 16
+
+// all-reduce over the lpp lanes of a sub-group (lpp = power of two <= 64, sub-groups aligned)
 template <typename T>
 __device__ inline T subgroup_sum(T v, int lpp) {
-    for (int o = lpp >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lpp >= 2) v += dpp_mov<kDppXor1>(v);
+    if (lpp >= 4) v += dpp_mov<kDppXor2>(v);
+    if (lpp >= 8) v += dpp_mov<kDppHalfMirror>(v);
+    if (lpp >= 16) v += dpp_mov<kDppMirror>(v);
+    if (lpp >= 32) v += __shfl_xor(v, 16);
+    if (lpp >= 64) v += __shfl_xor(v, 32);
     return v;
+}
+// value held by lane B of the sub-group (B < lpp): row_newbcast inside a 16-lane row, quad_perm inside a quad
+template <int B>
+__device__ inline uint32_t subgroup_bcast(uint32_t v, int lpp, int sub_base) {
+    if (lpp == 16) return (uint32_t)dpp_i32<0x150 + B>((int)v);
+    if (lpp == 4 && B < 4) return (uint32_t)dpp_i32<(B & 3) * 0x55>((int)v);  // quad_perm:[B,B,B,B]
+    return (uint32_t)__shfl((int)v, sub_base + B);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -163,12 +199,13 @@ __device__ inline int decide(const KParams& p, const U4& ra, double wp, double w
 //               whole update -- prior + loglike, Metropolis accept, theta/weight write-back and the history
 //               row -- so that one launch per colour phase is the entire DE-MCMC sweep.
 // ------------------------------------------------------------------------------------------------
-__device__ inline U4 shfl_u4(const U4& v, int src) {
+template <int B>
+__device__ inline U4 bcast_u4(const U4& v, int lpp, int sub_base) {
     U4 r;
-    r.x = (uint32_t)__shfl((int)v.x, src);
-    r.y = (uint32_t)__shfl((int)v.y, src);
-    r.z = (uint32_t)__shfl((int)v.z, src);
-    r.w = (uint32_t)__shfl((int)v.w, src);
+    r.x = subgroup_bcast<B>(v.x, lpp, sub_base);
+    r.y = subgroup_bcast<B>(v.y, lpp, sub_base);
+    r.z = subgroup_bcast<B>(v.z, lpp, sub_base);
+    r.w = subgroup_bcast<B>(v.w, lpp, sub_base);
     return r;
 }
 
@@ -306,6 +343,21 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     const int n_pass = (q_hi - q_lo + ppp - 1) / ppp;
     const double eps = p.eps, eps2 = p.eps - (-p.eps);
     const int nblk = hist_partners ? 6 : 4;
+    // MFMA preparation (prep_mfma): y[4 particles x d] = theta~[4 x d] . A^-1[d x d] as one 16x16x4 tile product per
+    // 16 columns; the wave's four sub-groups are rows 0..3 of the A operand (rows 4..15 are zero), and the C layout
+    // (row = (lane>>4) + 4r, col = lane&15) hands every lane the y of ITS OWN particle at columns sl and sl+16 in
+    // register r = 0.  B fragments (A^-1, lane: k = 4ks + (lane>>4), col = 16nt + (lane&15)) are loaded once per workgroup.
+    double bfrag[2][8];
+    if (p.prep_mfma) {
+        const int kq = (tid & 63) >> 4, col = tid & 15;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int k = 4 * ks + kq, c = 16 * nt + col;
+                bfrag[nt][ks] = (k < d && c < d) ? ainv_s[k * d + c] : 0.0;
+            }
+    }
 
     for (int pass = 0; pass < n_pass; ++pass) {
         const int q = q_lo + pass * ppp + sub;
@@ -320,13 +372,13 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
         if (p.mode == MODE_STEP) {
             if (lpp >= nblk) {
                 const U4 mine = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)(sl < nblk ? sl : 0));
-                r0 = shfl_u4(mine, sub_base + 0);
-                ri = shfl_u4(mine, sub_base + 1);
-                rg = shfl_u4(mine, sub_base + 2);
-                ra = shfl_u4(mine, sub_base + 3);
+                r0 = bcast_u4<0>(mine, lpp, sub_base);
+                ri = bcast_u4<1>(mine, lpp, sub_base);
+                rg = bcast_u4<2>(mine, lpp, sub_base);
+                ra = bcast_u4<3>(mine, lpp, sub_base);
                 if (hist_partners) {
-                    h4 = shfl_u4(mine, sub_base + 4);
-                    h5 = shfl_u4(mine, sub_base + 5);
+                    h4 = bcast_u4<4>(mine, lpp, sub_base);
+                    h5 = bcast_u4<5>(mine, lpp, sub_base);
                 }
             } else {
                 r0 = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 0);
@@ -554,6 +606,29 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             __builtin_amdgcn_wave_barrier();
             const double* th = scr + sub * scr_stride;
             // centred proposal mu~ = theta' - xbar (the data were centred the same way at demc_set_model)
+            if (p.prep_mfma) {
+                const int lane = tid & 63, kq = lane >> 4, row = lane & 15;
+                const double* trow = scr + ((tid >> 6) * 4 + (row & 3)) * scr_stride;  // rows 0..3 = this wave's particles
+                d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const int k = 4 * ks + kq;
+                    const double a = (row < 4 && k < d) ? trow[k] - xb_s[k] : 0.0;
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[0][ks], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[1][ks], acc1, 0, 0, 0);
+                }
+                const int c0 = sl, c1 = sl + 16;  // this lane's two columns of its own particle's y
+                const double y0 = acc0[0], y1 = acc1[0];
+                if (c0 < d) aux = fma(th[c0] - xb_s[c0], y0, aux);
+                if (c1 < d) aux = fma(th[c1] - xb_s[c1], y1, aux);
+                if (p.sx) {
+                    if (c0 < d) S = fma(y0, p.sx[c0], S);
+                    if (c1 < d) S = fma(y1, p.sx[c1], S);
+                } else if (valid) {
+                    if (c0 < p.dpad) p.Ypad[slot * p.dpad + c0] = (c0 < d) ? y0 : 0.0;
+                    if (c1 < p.dpad) p.Ypad[slot * p.dpad + c1] = (c1 < d) ? y1 : 0.0;
+                }
+            } else
             for (int k = sl; 2 * k < d; k += lpp) {
                 const int c0 = 2 * k, c1 = 2 * k + 1;
                 double y0 = 0.0, y1 = 0.0;
@@ -581,7 +656,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
                     if (c1 < p.dpad) p.Ypad[slot * p.dpad + c1] = (c1 < d) ? y1 : 0.0;
                 }
             }
-            if (!p.sx && valid)  // zero the k-step padding beyond d
+            if (!p.sx && valid && !p.prep_mfma)  // zero the k-step padding beyond d
                 for (int c = 2 * ((d + 1) / 2) + sl; c < p.dpad; c += lpp) p.Ypad[slot * p.dpad + c] = 0.0;
             aux = subgroup_sum(aux, lpp);
             S = subgroup_sum(S, lpp);
@@ -669,8 +744,6 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
 // four shuffles at the end.  blockIdx -> (chunk = b % n_chunks, particle tile = b / n_chunks):
 // workgroups that share an XCD (b % 8) stream the same chunk(s) of X, so a chunk stays in that XCD's L2.
 // ------------------------------------------------------------------------------------------------
-typedef double d4 __attribute__((ext_vector_type(4)));
-
 template <int KS, int MT>
 __global__ __launch_bounds__(256, 2) void k_cross_mfma(KParams p, const double* __restrict__ Ypad, int dpad, int k0,
                                                        const double* __restrict__ Xf, int n_tiles, int n_chunks,
@@ -953,7 +1026,7 @@ __global__ __launch_bounds__(256) void k_accept_store(KParams p) {
             p.id_hist[hrow] = (int)p.id[slot];
         }
     }
-    acc = __shfl(acc, (tid & 63) & ~(lpp - 1));
+    acc = (int)subgroup_bcast<0>((uint32_t)acc, lpp, (tid & 63) & ~(lpp - 1));
     if (!valid) return;
     double* trow = p.theta + slot * D;
     const double* prow = p.prop + slot * D;
