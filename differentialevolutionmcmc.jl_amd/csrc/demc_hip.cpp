@@ -140,7 +140,7 @@ KParams base_params(demc_handle* h) {
     const demc_config& c = h->c;
     k.n_groups = c.n_groups; k.Np = c.Np; k.D = c.D; k.group_offset = c.group_offset;
     k.a_lo = 0; k.n_act = c.Np; k.pool_lo = 0; k.pool_n = c.Np; k.exclude_self = 1;
-    k.lpp = h->lpp; k.mode = MODE_STEP;
+    k.lpp = h->lpp; k.lpp3 = h->lpp; k.mode = MODE_STEP;
     k.iter = 0; k.burnin = c.burnin; k.sweep = 0; k.seed = c.seed;
     k.beta = c.beta; k.eps = c.eps; k.sigma = c.sigma; k.kappa = c.kappa; k.theta_snooker = c.theta_snooker;
     k.proposal_kind = c.proposal_kind; k.partner_kind = c.partner_kind; k.update_kind = c.update_kind;
@@ -303,7 +303,7 @@ int launch_phase(demc_handle* h, KParams& k) {
     k.fuse_accept = (k.fuse_prep && suff && c.fuse != 1 &&
                      (c.schedule == DEMC_SCHED_TWO_COLOUR || k.mode == MODE_IDENT)) ? 1 : 0;
     k.write_prop = (!k.fuse_accept || k.trace) ? 1 : 0;
-    const int ppp = 256 / k.lpp;
+    const int ppp = 256 / k.lpp, ppp3 = 256 / k.lpp3;
     const int max_split = (k.n_act + ppp - 1) / ppp;
     int target_wgs = 512;
     if (const char* e = std::getenv("DEMC_K1_WGS")) target_wgs = std::atoi(e);  // A/B experiments
@@ -322,7 +322,7 @@ int launch_phase(demc_handle* h, KParams& k) {
     int rc = launch_loglike(h, k);
     if (rc != DEMC_OK) return rc;
     tick(h, 3, true);
-    hipLaunchKernelGGL(k_accept_store, dim3((unsigned)((n_prop + ppp - 1) / ppp)), dim3(256), 0, h->stream, k);
+    hipLaunchKernelGGL(k_accept_store, dim3((unsigned)((n_prop + ppp3 - 1) / ppp3)), dim3(256), 0, h->stream, k);
     tick(h, 3, false);
     return DEMC_OK;
 }
@@ -487,10 +487,10 @@ int32_t demc_create(const demc_config* cfg, demc_handle** out) {
     }
     // lanes per particle: every lane owns dim pairs {2k,2k+1}
     h->lpp = pow2_ceil((c.D + 1) / 2);
-    if (h->lpp > 64) h->lpp = 64;
+    if (h->lpp > 64) h->lpp = (c.D >= 2048) ? 256 : 64;  // very long rows: a whole workgroup per particle
     if (const char* e = std::getenv("DEMC_LPP")) {  // A/B experiments: fewer lanes per particle = less replicated scalar work
         const int v = std::atoi(e);
-        if (v >= 1 && v <= 64 && (v & (v - 1)) == 0 && v <= h->lpp) h->lpp = v;
+        if (v >= 1 && v <= 256 && v != 128 && (v & (v - 1)) == 0 && (v <= h->lpp || v == 256)) h->lpp = v;
     }
     int rc_lds = size_k1_lds(h);
     if (rc_lds != DEMC_OK) return rc_lds;

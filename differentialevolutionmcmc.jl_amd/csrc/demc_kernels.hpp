@@ -42,7 +42,8 @@ struct KParams {
     int n_groups, Np, D, group_offset;
     int a_lo, n_act;                  // active particles of each group in this phase: [a_lo, a_lo+n_act)
     int pool_lo, pool_n, exclude_self;  // partner pool of each group
-    int lpp;                          // lanes per particle
+    int lpp;                          // lanes per particle in K1 (256 = one workgroup per particle, very large D)
+    int lpp3;                         // lanes per particle in K3
     int mode;
     // sampler
     long long iter, burnin;
@@ -138,6 +139,17 @@ __device__ inline T subgroup_sum(T v, int lpp) {
     if (lpp >= 32) v += __shfl_xor(v, 16);
     if (lpp >= 64) v += __shfl_xor(v, 32);
     return v;
+}
+// lpp == 256: one particle spans the whole workgroup (very large D); the sum crosses the four waves through LDS.
+// Must be called by every thread of the workgroup (the particle -- hence the control flow -- is workgroup-uniform then).
+template <typename T>
+__device__ inline T group_sum(T v, int lpp, T* s4) {
+    if (lpp <= 64) return subgroup_sum(v, lpp);
+    v = subgroup_sum(v, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (s4[0] + s4[1]) + (s4[2] + s4[3]);
 }
 // value held by lane B of the sub-group (B < lpp): row_newbcast inside a 16-lane row, quad_perm inside a quad
 template <int B>
@@ -243,6 +255,8 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     extern __shared__ double lds[];
     __shared__ double s_red[4];
     __shared__ double s_total;
+    __shared__ double s_gsum[4];
+    __shared__ int s_gsumi[4];
     const int tid = threadIdx.x;
     const int g = blockIdx.x / p.n_split, sp = blockIdx.x % p.n_split;
     const int g_glob = p.group_offset + g;
@@ -370,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
         // per-particle Philox blocks: lane b of the sub-group evaluates block b (when the sub-group is wide enough)
         U4 r0 = {0, 0, 0, 0}, ri = r0, rg = r0, ra = r0, h4 = r0, h5 = r0;
         if (p.mode == MODE_STEP) {
-            if (lpp >= nblk) {
+            if (lpp >= nblk && lpp <= 64) {
                 const U4 mine = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)(sl < nblk ? sl : 0));
                 r0 = bcast_u4<0>(mine, lpp, sub_base);
                 ri = bcast_u4<1>(mine, lpp, sub_base);
@@ -454,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
                                 vm += Pb2[j] * dj; vn += Pc[j] * dj; vd += dj * dj;
                             }
                         }
-                    vm = subgroup_sum(vm, lpp); vn = subgroup_sum(vn, lpp); vd = subgroup_sum(vd, lpp);
+                    vm = group_sum(vm, lpp, s_gsum); vn = group_sum(vn, lpp, s_gsum); vd = group_sum(vd, lpp, s_gsum);
                     cm = vm / vd; cn = vn / vd;
                 } else {
                     if (p.proposal_kind == 0) {
@@ -471,7 +485,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
                                 const double t = u_base * total;
                                 int cnt = 0;
                                 for (int i = sl; i < n_cdf; i += lpp) cnt += (cdf[i] < t) ? 1 : 0;
-                                cnt = subgroup_sum(cnt, lpp);
+                                cnt = group_sum(cnt, lpp, s_gsumi);
                                 b = cnt < n_cdf ? cnt : n_cdf - 1;
                             }
                             b += p.pool_lo;
@@ -588,12 +602,12 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
                 if (has1) scr[sub * scr_stride + j0 + 1] = v1;
             }
         }
-        prior = subgroup_sum(prior, lpp);
-        oob = subgroup_sum(oob, lpp);
+        prior = group_sum(prior, lpp, s_gsum);
+        oob = group_sum(oob, lpp, s_gsumi);
         double adj = 0.0;
         if (kind == 1) {  // (d-1)(log|a| - log|b|): stable form of log(|a|^(d-1)/|b|^(d-1))  crossover.jl:268-273
-            s1 = subgroup_sum(s1, lpp);
-            s2 = subgroup_sum(s2, lpp);
+            s1 = group_sum(s1, lpp, s_gsum);
+            s2 = group_sum(s2, lpp, s_gsum);
             adj = (double)(D - 1) * (0.5 * log(s1) - 0.5 * log(s2));
         }
 
@@ -658,8 +672,8 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             }
             if (!p.sx && valid && !p.prep_mfma)  // zero the k-step padding beyond d
                 for (int c = 2 * ((d + 1) / 2) + sl; c < p.dpad; c += lpp) p.Ypad[slot * p.dpad + c] = 0.0;
-            aux = subgroup_sum(aux, lpp);
-            S = subgroup_sum(S, lpp);
+            aux = group_sum(aux, lpp, s_gsum);
+            S = group_sum(S, lpp, s_gsum);
         }
 
         if (!p.fuse_accept) {
@@ -990,7 +1004,7 @@ __device__ inline double finalize_loglike(const KParams& p, size_t slot) {
 
 __global__ __launch_bounds__(256) void k_accept_store(KParams p) {
     const int tid = threadIdx.x;
-    const int lpp = p.lpp, ppp = 256 / lpp;
+    const int lpp = p.lpp3, ppp = 256 / lpp;
     const int sub = tid / lpp, sl = tid % lpp;
     const int n_prop = p.n_groups * p.n_act;
     const int q = blockIdx.x * ppp + sub;
@@ -1026,7 +1040,13 @@ __global__ __launch_bounds__(256) void k_accept_store(KParams p) {
             p.id_hist[hrow] = (int)p.id[slot];
         }
     }
-    acc = (int)subgroup_bcast<0>((uint32_t)acc, lpp, (tid & 63) & ~(lpp - 1));
+    if (lpp > 64) {  // one particle per workgroup: hand the decision over through LDS
+        __shared__ int s_acc;
+        if (tid == 0) s_acc = acc;
+        __syncthreads();
+        acc = s_acc;
+    } else
+        acc = (int)subgroup_bcast<0>((uint32_t)acc, lpp, (tid & 63) & ~(lpp - 1));
     if (!valid) return;
     double* trow = p.theta + slot * D;
     const double* prow = p.prop + slot * D;
