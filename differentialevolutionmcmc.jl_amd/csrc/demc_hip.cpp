@@ -153,7 +153,7 @@ KParams base_params(demc_handle* h) {
     k.family = h->family; k.N = h->N; k.d = h->d; k.n_acc = h->n_acc; k.n_partials = 1;
     k.partial = h->partial; k.aux = h->aux; k.data = h->data; k.data2 = h->data ? h->data + h->data2_off : nullptr;
     k.c0 = h->c0; k.c1 = h->c1; k.c2 = h->c2;
-    k.n_split = 1; k.fuse_prep = 0; k.prep_mfma = 0; k.fuse_accept = 0; k.write_prop = 1; k.trace = c.trace;
+    k.n_split = 1; k.fuse_prep = 0; k.prep_mfma = 0; k.fuse_obs = 0; k.fuse_accept = 0; k.write_prop = 1; k.trace = c.trace;
     k.Ainv = h->Ainv; k.sx = nullptr; k.xbar = h->xbar; k.Ypad = h->Ypad; k.dpad = h->dpad;
     return k;
 }
@@ -300,8 +300,12 @@ int launch_phase(demc_handle* h, KParams& k) {
     if (const char* e = std::getenv("DEMC_PREP_MFMA")) k.prep_mfma = k.prep_mfma && e[0] == '1';  // A/B experiments
     k.sx = (k.fuse_prep && suff) ? h->sx : nullptr;
     k.Ainv = (h->family == FAM_MVN_FULL) ? h->Ainv : nullptr;
-    k.fuse_accept = (k.fuse_prep && suff && c.fuse != 1 &&
-                     (c.schedule == DEMC_SCHED_TWO_COLOUR || k.mode == MODE_IDENT)) ? 1 : 0;
+    // small-N scalar-data families: the sub-group of a particle sums the per-observation terms itself
+    const bool cheap_obs = (h->family == FAM_GAUSSIAN || h->family == FAM_BINOMIAL || h->family == FAM_RASTRIGIN) &&
+                           h->N / k.lpp <= 512;
+    const bool phase_private = c.schedule == DEMC_SCHED_TWO_COLOUR || k.mode == MODE_IDENT;  // nothing read can move
+    k.fuse_obs = (cheap_obs && phase_private && c.fuse != 1) ? 1 : 0;
+    k.fuse_accept = (((k.fuse_prep && suff) || k.fuse_obs) && c.fuse != 1 && phase_private) ? 1 : 0;
     k.write_prop = (!k.fuse_accept || k.trace) ? 1 : 0;
     const int ppp = 256 / k.lpp, ppp3 = 256 / k.lpp3;
     const int max_split = (k.n_act + ppp - 1) / ppp;
@@ -374,7 +378,8 @@ int size_k1_lds(demc_handle* h) {
     const size_t cdf = ((size_t)c.Np + ((size_t)c.Np + 15) / 16) * sizeof(double);
     const size_t ainv = (h->family == FAM_MVN_FULL) ? (size_t)h->d * h->d * sizeof(double) : 0;
     const size_t xb = is_mvn(h->family) ? (size_t)h->d * sizeof(double) : 0;
-    const size_t scr = is_mvn(h->family) ? (size_t)(256 / h->lpp) * (D + 2) * sizeof(double) : 0;
+    const bool scr_fam = is_mvn(h->family) || h->family == FAM_GAUSSIAN || h->family == FAM_BINOMIAL || h->family == FAM_RASTRIGIN;
+    const size_t scr = scr_fam ? (size_t)(256 / (h->lpp > 256 ? 256 : h->lpp)) * (D + 2) * sizeof(double) : 0;
     const size_t tile = (size_t)c.Np * D * sizeof(double);
     h->tile_in_lds = (tile + cdf + ainv + xb + scr <= 96 * 1024) ? 1 : 0;
     if (const char* e = std::getenv("DEMC_K1_TILE")) h->tile_in_lds = (e[0] == '1') && h->tile_in_lds;  // A/B experiments

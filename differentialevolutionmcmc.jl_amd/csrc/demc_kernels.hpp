@@ -75,6 +75,7 @@ struct KParams {
     int n_split;              // K1: workgroups per group
     int fuse_prep;            // K1 computes y = A^-1 theta', a = theta'.y (MvNormal families)
     int prep_mfma;            // ... on the matrix cores (full Sigma, d <= 32, 16 lanes per particle)
+    int fuse_obs;             // K1 sums the per-observation terms itself (small N, scalar-data families)
     int fuse_accept;          // K1 finishes the update (cheap likelihoods, two_colour)
     int write_prop;           // K1 writes proposals to HBM (needed by K2/K3 or by the trace)
     int trace;                // keep the per-slot diagnostic trace
@@ -179,6 +180,99 @@ __device__ inline double loglike_from_stats(const KParams& p, double s, double a
     }
 }
 
+// Sum over observations i = i0, i0+stride, ... < i1 of the per-observation statistic of one proposal `th`
+// (Gaussian: z^2; Binomial / LBA / LNR: the log-density; rastrigin: the objective on i == 0).  tab = erfcx table (LDS)
+// or nullptr for the families that do not need it.
+__device__ inline double obs_range_sum(const KParams& p, const double* th, long long i0, long long i1, int stride,
+                                       const double* tab) {
+    double acc = 0.0;
+    switch (p.family) {
+        case FAM_GAUSSIAN: {  // sum_i ((x_i - mu)/sigma)^2   Gaussian_Example.jl:26-28
+            const double mu = th[0], isg = 1.0 / th[1];
+            for (long long i = i0; i < i1; i += stride) {
+                const double z = (p.data[i] - mu) * isg;
+                acc = fma(z, z, acc);
+            }
+        } break;
+        case FAM_BINOMIAL: {  // binomial_tests.jl:15-17; data=[n], data2=[k], then the log binomial coefficients
+            const double pr = th[0];
+            const double lp = log(pr), l1p = log1p(-pr);
+            const double* lgc = p.data2 + p.N;
+            for (long long i = i0; i < i1; i += stride) {
+                const double n = p.data[i], k = p.data2[i];
+                const double t1 = (k == 0.0) ? 0.0 : k * lp;
+                const double t2 = (n - k == 0.0) ? 0.0 : (n - k) * l1p;
+                acc += lgc[i] + t1 + t2;
+            }
+        } break;
+        case FAM_LBA: {  // Run_LBA.jl:33-37
+            const int na = p.n_acc;
+            double nu[8];
+            for (int a = 0; a < 8; ++a) nu[a] = a < na ? th[a] : 0.0;
+            const double A = th[na], kk = th[na + 1], tau = th[na + 2], b = A + kk, inv_A = 1.0 / A;
+            double pneg = 1.0;
+            for (int a = 0; a < na; ++a) {
+                double ph, Ph;
+                phi_Phi(tab, -nu[a], ph, Ph);
+                pneg *= Ph;
+            }
+            const double inv = 1.0 / (1.0 - pneg);
+            for (long long i = i0; i < i1; i += stride) {
+                const int c = (int)p.data[i];
+                const double rt = p.data2[i];
+                double ll;
+                if (rt < tau)
+                    ll = -INFINITY;
+                else {
+                    const double t = rt - tau, inv_t = 1.0 / t;
+                    double den = 1.0;
+                    for (int a = 0; a < na; ++a) {
+                        double dens, cdf;
+                        lba_dens_cdf(tab, nu[a], b, A, t, inv_t, inv_A, dens, cdf);
+                        den *= (a + 1 == c) ? dens : (1.0 - cdf);
+                    }
+                    den *= inv;
+                    if (den != den)
+                        ll = -INFINITY;
+                    else
+                        ll = log(den < 1e-10 ? 1e-10 : den);
+                }
+                acc += ll;
+            }
+        } break;
+        case FAM_LNR: {  // lognormal_race_tests.jl:9-12
+            const int na = p.n_acc;
+            double nu[8];
+            for (int a = 0; a < 8; ++a) nu[a] = a < na ? th[a] : 0.0;
+            const double tau = th[na], sg = p.c0, lsg = log(sg), isg = 1.0 / sg;
+            for (long long i = i0; i < i1; i += stride) {
+                const int c = (int)p.data[i];
+                const double t = p.data2[i] - tau;
+                double ll = 0.0;
+                if (!(t > 0.0))
+                    ll = -INFINITY;
+                else {
+                    const double lt = log(t);
+                    for (int a = 0; a < na; ++a) {
+                        const double z = (lt - nu[a]) * isg;
+                        ll += (a + 1 == c) ? (-(z * z + kLog2Pi) / 2.0 - lsg - lt) : log_Phi_neg(tab, z);
+                    }
+                }
+                acc += ll;
+            }
+        } break;
+        case FAM_RASTRIGIN: {  // optimization_tests.jl:15-23
+            if (i0 == 0) {
+                acc = 10.0 * p.D;
+                for (int j = 0; j < p.D; ++j) acc += th[j] * th[j] - 10.0 * cos(2.0 * kPi * th[j]);
+            }
+        } break;
+        default:
+            break;
+    }
+    return acc;
+}
+
 // mh_update! / maximize! / minimize! decision for one particle (utilities.jl:55-58, 201-226)
 // ra = Philox block 3 of the particle's PART stream (the accept uniform)
 __device__ inline int decide(const KParams& p, const U4& ra, double wp, double w, double adj) {
@@ -273,6 +367,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     const int scr_stride = D + 2;
     double* xb_s = ainv_s + ((p.fuse_prep && p.Ainv) ? (size_t)d * d : 0);
     double* scr = xb_s + (p.fuse_prep ? d : 0);
+    const bool use_scr = p.fuse_prep || p.fuse_obs;  // theta' of the pass kept in LDS for the fused tails
 
     bool is_mut = false;
     if (p.mode == MODE_STEP) {
@@ -597,7 +692,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
                     if (has1) p.prop[slot * D + j0 + 1] = v1;
                 }
             }
-            if (p.fuse_prep) {
+            if (use_scr) {
                 scr[sub * scr_stride + j0] = v0;
                 if (has1) scr[sub * scr_stride + j0 + 1] = v1;
             }
@@ -676,6 +771,13 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             S = group_sum(S, lpp, s_gsum);
         }
 
+        if (p.fuse_obs) {
+            // small-N scalar-data families: the sub-group visits every observation itself (lanes stride over them)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            S = group_sum(obs_range_sum(p, scr + sub * scr_stride, sl, p.N, lpp, nullptr), lpp, s_gsum);
+        }
+
         if (!p.fuse_accept) {
             if (sl == 0 && valid) {
                 p.prop_prior[slot] = prior;
@@ -699,7 +801,8 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
 
         // ---- fused tail: compute_posterior! + mh_update! + store_samples! for this particle ----
         const double w = gw[pl];
-        const double sg = (p.family == FAM_MVN_ISO) ? scr[sub * scr_stride + d] : 0.0;
+        const double sg = (p.family == FAM_MVN_ISO) ? scr[sub * scr_stride + d]
+                          : (p.family == FAM_GAUSSIAN) ? scr[sub * scr_stride + 1] : 0.0;
         double wp;
         if (p.fitness_kind == 1)
             wp = oob ? (p.update_kind == 1 ? -INFINITY : INFINITY) : loglike_from_stats(p, S, aux, sg);
@@ -852,91 +955,7 @@ __global__ __launch_bounds__(256) void k_obs_loglike(KParams p, int n_chunks) {
     const double* th = p.prop + slot * p.D;
     const long long per = (p.N + n_chunks - 1) / n_chunks;
     const long long i0 = chunk * per, i1 = (i0 + per < p.N) ? i0 + per : p.N;
-    double acc = 0.0;
-    switch (p.family) {
-        case FAM_GAUSSIAN: {  // sum_i ((x_i - mu)/sigma)^2   Gaussian_Example.jl:26-28
-            const double mu = th[0], isg = 1.0 / th[1];
-            for (long long i = i0; i < i1; ++i) {
-                const double z = (p.data[i] - mu) * isg;
-                acc = fma(z, z, acc);
-            }
-        } break;
-        case FAM_BINOMIAL: {  // binomial_tests.jl:15-17; data=[n], data2=[k], aux table in c-terms
-            const double pr = th[0];
-            const double lp = log(pr), l1p = log1p(-pr);
-            const double* lgc = p.data2 + p.N;
-            for (long long i = i0; i < i1; ++i) {
-                const double n = p.data[i], k = p.data2[i];
-                const double t1 = (k == 0.0) ? 0.0 : k * lp;
-                const double t2 = (n - k == 0.0) ? 0.0 : (n - k) * l1p;
-                acc += lgc[i] + t1 + t2;
-            }
-        } break;
-        case FAM_LBA: {  // Run_LBA.jl:33-37
-            const int na = p.n_acc;
-            double nu[8];
-            for (int a = 0; a < 8; ++a) nu[a] = a < na ? th[a] : 0.0;
-            const double A = th[na], kk = th[na + 1], tau = th[na + 2], b = A + kk, inv_A = 1.0 / A;
-            double pneg = 1.0;
-            for (int a = 0; a < na; ++a) {
-                double ph, Ph;
-                phi_Phi(s_erfcx, -nu[a], ph, Ph);
-                pneg *= Ph;
-            }
-            const double inv = 1.0 / (1.0 - pneg);
-            for (long long i = i0; i < i1; ++i) {
-                const int c = (int)p.data[i];
-                const double rt = p.data2[i];
-                double ll;
-                if (rt < tau)
-                    ll = -INFINITY;
-                else {
-                    const double t = rt - tau, inv_t = 1.0 / t;
-                    double den = 1.0;
-                    for (int a = 0; a < na; ++a) {
-                        double dens, cdf;
-                        lba_dens_cdf(s_erfcx, nu[a], b, A, t, inv_t, inv_A, dens, cdf);
-                        den *= (a + 1 == c) ? dens : (1.0 - cdf);
-                    }
-                    den *= inv;
-                    if (den != den)
-                        ll = -INFINITY;
-                    else
-                        ll = log(den < 1e-10 ? 1e-10 : den);
-                }
-                acc += ll;
-            }
-        } break;
-        case FAM_LNR: {  // lognormal_race_tests.jl:9-12
-            const int na = p.n_acc;
-            double nu[8];
-            for (int a = 0; a < 8; ++a) nu[a] = a < na ? th[a] : 0.0;
-            const double tau = th[na], sg = p.c0, lsg = log(sg), isg = 1.0 / sg;
-            for (long long i = i0; i < i1; ++i) {
-                const int c = (int)p.data[i];
-                const double t = p.data2[i] - tau;
-                double ll = 0.0;
-                if (!(t > 0.0))
-                    ll = -INFINITY;
-                else {
-                    const double lt = log(t);
-                    for (int a = 0; a < na; ++a) {
-                        const double z = (lt - nu[a]) * isg;
-                        ll += (a + 1 == c) ? (-(z * z + kLog2Pi) / 2.0 - lsg - lt) : log_Phi_neg(s_erfcx, z);
-                    }
-                }
-                acc += ll;
-            }
-        } break;
-        case FAM_RASTRIGIN: {  // optimization_tests.jl:15-23
-            if (chunk == 0) {
-                acc = 10.0 * p.D;
-                for (int j = 0; j < p.D; ++j) acc += th[j] * th[j] - 10.0 * cos(2.0 * kPi * th[j]);
-            }
-        } break;
-        default:
-            break;
-    }
+    const double acc = obs_range_sum(p, th, i0, i1, 1, s_erfcx);
     p.partial[(size_t)chunk * p.P + slot] = acc;
 }
 
@@ -984,18 +1003,19 @@ __global__ __launch_bounds__(256) void k_hier_loglike(KParams p) {
 // Metropolis accept with one uniform per particle, then move the accepted row into theta and write
 // the history row -- one pass over the particle's D scalars, LPP lanes per particle.
 // ------------------------------------------------------------------------------------------------
-__device__ inline double finalize_loglike(const KParams& p, size_t slot) {
-    // fixed summation order (chunk 0, 1, ...); the loads are issued in batches of 8 so that their latencies overlap
+// Sum of the per-chunk partial sums of one proposal, in a fixed (deterministic) order: every lane of the sub-group adds
+// the chunks c = sl, sl+lpp, ... in increasing order, then the lanes are combined by the DPP tree -- the chunk loads of
+// the sub-group go out together instead of one dependent load after another on a single lane.
+__device__ inline double sum_partials(const KParams& p, size_t slot, int sl, int lpp) {
     double s = 0.0;
-    int c = 0;
-    for (; c + 8 <= p.n_partials; c += 8) {
-        double v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = p.partial[(size_t)(c + k) * p.P + slot];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s += v[k];
+    if (lpp > 64) {  // one particle per workgroup (very large D): few chunks, lane 0 adds them
+        for (int c = 0; c < p.n_partials; ++c) s += p.partial[(size_t)c * p.P + slot];
+        return s;
     }
-    for (; c < p.n_partials; ++c) s += p.partial[(size_t)c * p.P + slot];
+    for (int c = sl; c < p.n_partials; c += lpp) s += p.partial[(size_t)c * p.P + slot];
+    return subgroup_sum(s, lpp);
+}
+__device__ inline double finalize_loglike(const KParams& p, size_t slot, double s) {
     double sg = 0.0;
     if (p.family == FAM_MVN_ISO) sg = p.prop[slot * p.D + p.d];
     if (p.family == FAM_GAUSSIAN) sg = p.prop[slot * p.D + 1];
@@ -1014,14 +1034,15 @@ __global__ __launch_bounds__(256) void k_accept_store(KParams p) {
     const int D = p.D;
     int acc = 0;
     double w_new = 0.0;
+    const double s_sum = sum_partials(p, slot, sl, lpp);
     if (sl == 0 && valid) {
         const double w = p.weight[slot];
         const bool oob = p.prop_oob[slot] != 0;
         double wp;
         if (p.fitness_kind == 1)  // evaluate_fun! utilities.jl:113-120
-            wp = oob ? (p.update_kind == 1 ? -INFINITY : INFINITY) : finalize_loglike(p, slot);
+            wp = oob ? (p.update_kind == 1 ? -INFINITY : INFINITY) : finalize_loglike(p, slot, s_sum);
         else  // compute_posterior! utilities.jl:92-99
-            wp = oob ? -INFINITY : p.prop_prior[slot] + finalize_loglike(p, slot);
+            wp = oob ? -INFINITY : p.prop_prior[slot] + finalize_loglike(p, slot, s_sum);
         const uint32_t eslot = (uint32_t)(p.group_offset + g) * (uint32_t)p.Np + (uint32_t)pl;
         const U4 ra = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 3);
         acc = decide(p, ra, wp, w, p.prop_adj[slot]);  // mh_update! / maximize! / minimize!

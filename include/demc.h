@@ -116,7 +116,8 @@ typedef struct demc_config {
     int32_t device_id;
     int32_t loglike_mode;
     int32_t trace;           /* 1: keep the per-slot diagnostic trace readable by demc_get_trace (tests) */
-    int32_t fuse;            /* 0: auto (one fused kernel per colour phase when the likelihood allows); 1: never */
+    int32_t fuse;            /* 0: auto (one fused kernel per colour phase when the likelihood allows: MvNormal in
+                                SUFFSTAT mode, Gaussian / Binomial with few observations); 1: never */
 } demc_config;
 
 typedef struct demc_handle demc_handle;
