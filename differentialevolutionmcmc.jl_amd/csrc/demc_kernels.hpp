@@ -344,9 +344,28 @@ __device__ inline double prior_term(const DimTab& t, double x, double inv_sref, 
     }
 }
 
+// In-kernel stamps (diagnostic build only: make STAMPS=1; tools/k1_stamps.py reads them back through the trace).
+// Thread 0 of every workgroup stores the s_memtime delta since kernel start into tr_w[16*blockIdx.x + i]; the
+// product build compiles them away.
+#ifdef DEMC_STAMPS
+#define DEMC_STAMP(i)                                                                                              \
+    do {                                                                                                           \
+        if (threadIdx.x == 0) p.tr_w[blockIdx.x * 16 + (i)] = (double)(__builtin_amdgcn_s_memtime() - t_start__); \
+    } while (0)
+#define DEMC_STAMP_INIT() const unsigned long long t_start__ = __builtin_amdgcn_s_memtime()
+#else
+#define DEMC_STAMP(i) \
+    do {              \
+    } while (0)
+#define DEMC_STAMP_INIT() \
+    do {                  \
+    } while (0)
+#endif
+
 template <bool TILE>
 __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     extern __shared__ double lds[];
+    DEMC_STAMP_INIT();
     __shared__ double s_red[4];
     __shared__ double s_total;
     __shared__ double s_gsum[4];
@@ -441,8 +460,10 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
         __syncthreads();
         if (tid == 0) s_total = cdf[n_cdf - 1];
     }
+    DEMC_STAMP(0);  // prologue done except for the tile
     if (TILE && even) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA pieces have landed
     __syncthreads();
+    DEMC_STAMP(1);  // tile visible
 
     const int sub = tid / lpp, sl = tid % lpp;
     const int sub_base = (tid & 63) & ~(lpp - 1);  // lane 0 of this sub-group inside its wave
@@ -477,6 +498,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
         const double* pt = rows + (size_t)pl * D;
 
         // per-particle Philox blocks: lane b of the sub-group evaluates block b (when the sub-group is wide enough)
+        if (pass == 1 || n_pass == 1) DEMC_STAMP(2);  // top of the steady-state pass
         U4 r0 = {0, 0, 0, 0}, ri = r0, rg = r0, ra = r0, h4 = r0, h5 = r0;
         if (p.mode == MODE_STEP) {
             if (lpp >= nblk && lpp <= 64) {
@@ -501,6 +523,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             }
         }
 
+        if (pass == 1 || n_pass == 1) DEMC_STAMP(3);  // particle Philox blocks handed out
         int kind = 3;  // 0 DE, 1 snooker, 2 mutation, 3 identity
         int i0 = -1, i1 = -1, i2 = -1;
         const double *Pa = pt, *Pb2 = pt, *Pc = pt, *Pbase = pt;
@@ -650,6 +673,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             }
         };
 
+        if (pass == 1 || n_pass == 1) DEMC_STAMP(4);  // indices, gammas, base picked
         int oob = 0;
         double prior = 0.0, s1 = 0.0, s2 = 0.0;
         int ref_cached = -1;
@@ -697,6 +721,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
                 if (has1) scr[sub * scr_stride + j0 + 1] = v1;
             }
         }
+        if (pass == 1 || n_pass == 1) DEMC_STAMP(5);  // per-dimension loop done
         prior = group_sum(prior, lpp, s_gsum);
         oob = group_sum(oob, lpp, s_gsumi);
         double adj = 0.0;
@@ -706,6 +731,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             adj = (double)(D - 1) * (0.5 * log(s1) - 0.5 * log(s2));
         }
 
+        if (pass == 1 || n_pass == 1) DEMC_STAMP(6);  // reductions done
         double aux = 0.0, S = 0.0;
         if (p.fuse_prep) {
             // y = A^-1 theta' (FULL) or theta' (ISO) for the data dimensions; each lane owns output columns {2k, 2k+1}.
@@ -771,6 +797,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             S = group_sum(S, lpp, s_gsum);
         }
 
+        if (pass == 1 || n_pass == 1) DEMC_STAMP(7);  // MvNormal preparation done
         if (p.fuse_obs) {
             // small-N scalar-data families: the sub-group visits every observation itself (lanes stride over them)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -799,6 +826,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             continue;
         }
 
+        if (pass == 1 || n_pass == 1) DEMC_STAMP(8);  // in-kernel observation loop done
         // ---- fused tail: compute_posterior! + mh_update! + store_samples! for this particle ----
         const double w = gw[pl];
         const double sg = (p.family == FAM_MVN_ISO) ? scr[sub * scr_stride + d]
@@ -846,7 +874,9 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();  // scratch rows are reused by the same sub-group in the next pass
+        if (pass == 1 || n_pass == 1) DEMC_STAMP(9);  // accept + row moves done
     }
+    DEMC_STAMP(10);  // kernel end
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Where K1 spends its cycles: runs a workload on the DIAGNOSTIC build of the library (in-kernel s_memtime stamps,
+`make -C differentialevolutionmcmc.jl_amd/csrc STAMPS=1 OUT=../libdemc_hip_stamps.so`) and prints, per workgroup,
+the median cycle count at each stamp of the fused propose kernel.  Never quote this build's run time: read shares."""
+import argparse
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+csrc = os.path.join(ROOT, "differentialevolutionmcmc.jl_amd", "csrc")
+subprocess.check_call(["make", "-C", csrc, "-s", "STAMPS=1", "OUT=../libdemc_hip_stamps.so"])
+import demc_amd  # noqa: E402
+demc_amd._ffi.LIB_PATH = os.path.join(ROOT, "differentialevolutionmcmc.jl_amd", "libdemc_hip_stamps.so")
+import bench  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n-groups", type=int, default=256)
+ap.add_argument("--np", type=int, default=256, dest="Np")
+ap.add_argument("--dim", type=int, default=32)
+ap.add_argument("--nobs", type=int, default=100000)
+ap.add_argument("--mode", default="suffstat")
+a = ap.parse_args()
+prob = bench.make_cfg3(a.n_groups, a.Np, a.nobs, a.dim)
+eng = demc_amd.HipEngine(n_groups=a.n_groups, Np=a.Np, D=a.dim, n_rows=40, schedule=2, seed=1,
+                         loglike_mode=1 if a.mode == "suffstat" else 0, trace=0)
+bench.configure(eng, prob, a.dim)
+eng.set_state(bench.init_theta(a.n_groups * a.Np, a.dim, 0))
+eng.step(1, 30)
+n_wg = min(512, (a.n_groups * a.Np) // 16)
+t = eng.get_trace()["w_prop"][: n_wg * 16].reshape(n_wg, 16)[:, :11]
+t = t[t[:, 10] > 0]
+names = ["prologue (coin, softmax prefix sums; tile in flight)", "tile landed (LDS-DMA wait + barrier)",
+         "top of steady-state pass (passes before it)", "particle Philox blocks + broadcast", "indices / gammas / base pick",
+         "per-dimension loop (noise, proposal, bounds, prior)", "sub-group reductions", "MvNormal preparation",
+         "in-kernel observation loop", "accept + row moves", "kernel end (remaining passes)"]
+med = np.median(t, 0)
+prev = 0.0
+print(f"{len(t)} workgroups; cycles since kernel start (median), and the step")
+for n, m in zip(names, med):
+    print(f"  {n:55s} {m:9.0f}  (+{m - prev:7.0f})")
+    prev = m
