@@ -163,3 +163,36 @@ def test_cfg5_shape_parity(demc, orc):
     """BASELINE cfg5's shape with fewer trials/groups: LBA, 3 accumulators (6 parameters), snooker on"""
     prob = make_problem("lba", np.random.default_rng(45), N=2000, na=3)
     teacher_forced(demc, orc, prob, n_iter=6, n_groups=4, Np=16, schedule=2, burnin=3, theta_snooker=0.1)
+
+
+def _fuzz_cases(n, seed=20261003):
+    rng = np.random.default_rng(seed)
+    fams = ["gaussian", "binomial", "mvn_iso", "mvn_full", "hier_binomial", "hier_gaussian", "lba", "lnr"]
+    out = []
+    for i in range(n):
+        fam = fams[i % len(fams)]
+        schedule = int(rng.integers(1, 3))
+        snooker = float(rng.choice([0.0, 0.0, 0.3, 1.0]))
+        Np = int(rng.integers(6, 40))
+        cfg = dict(n_groups=int(rng.integers(1, 7)), Np=Np, schedule=schedule, burnin=int(rng.integers(0, 4)),
+                   theta_snooker=snooker, kappa=float(rng.choice([1.0, 1.0, 0.6])), beta=float(rng.choice([0.1, 0.5])),
+                   alpha=float(rng.choice([0.1, 1.0])), proposal_kind=int(rng.integers(0, 3)), seed=int(rng.integers(1, 2**31)),
+                   loglike_mode=int(rng.integers(0, 2)))
+        kw = {}
+        if fam in ("mvn_iso", "mvn_full"):
+            kw = dict(N=int(rng.integers(3, 400)), d=int(rng.integers(1, 40)))
+        elif fam in ("gaussian", "binomial", "lba", "lnr"):
+            kw = dict(N=int(rng.integers(1, 300)))
+        elif fam == "hier_binomial":
+            kw = dict(S=int(rng.integers(2, 200)))
+        elif fam == "hier_gaussian":
+            kw = dict(S=int(rng.integers(2, 40)), n=int(rng.integers(1, 9)))
+        out.append(pytest.param(fam, kw, cfg, id=f"{i}-{fam}-s{schedule}"))
+    return out
+
+
+@pytest.mark.parametrize("fam,kw,cfg", _fuzz_cases(int(__import__("os").environ.get("DEMC_FUZZ_CASES", "32")), int(__import__("os").environ.get("DEMC_FUZZ_SEED", "20261003"))))
+def test_randomised_configurations(demc, orc, fam, kw, cfg):
+    """seeded sweep over families x shapes x sampler settings x schedules x likelihood modes"""
+    prob = make_problem(fam, np.random.default_rng(cfg["seed"]), **kw)
+    teacher_forced(demc, orc, prob, n_iter=4, exact_de=False, **cfg)
