@@ -371,6 +371,8 @@ int evaluate_rows(demc_handle* h, double* theta_dev, double* weight_dev) {
     return launch_phase(h, k);
 }
 
+constexpr size_t kMaxDynLds = 150 * 1024;  // of the 160 KB per CU; the rest covers the kernels' static __shared__
+
 // K1 LDS carve-up (must match k_propose): group tile (if it fits) | Np prefix sums | A^-1 [d][d] | theta' scratch
 int size_k1_lds(demc_handle* h) {
     const demc_config& c = h->c;
@@ -385,9 +387,12 @@ int size_k1_lds(demc_handle* h) {
     if (const char* e = std::getenv("DEMC_K1_TILE")) h->tile_in_lds = (e[0] == '1') && h->tile_in_lds;  // A/B experiments
     h->k1_tile_bytes = h->tile_in_lds ? tile : 0;
     h->k1_lds = h->k1_tile_bytes + cdf + ainv + xb + scr;
-    if (h->k1_lds > 150 * 1024) return fail(h, DEMC_EINVAL, "K1 LDS budget exceeded (Np too large for this D)");
-    HIPCHK(hipFuncSetAttribute((const void*)k_propose<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k1_lds));
-    HIPCHK(hipFuncSetAttribute((const void*)k_propose<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k1_lds));
+    if (h->k1_lds > kMaxDynLds) return fail(h, DEMC_EINVAL, "K1 LDS budget exceeded (Np too large for this D)");
+    // the attribute is per function, not per handle: always raise it to the same ceiling so that handles of different
+    // sizes in one process do not lower each other's limit
+    HIPCHK(hipFuncSetAttribute((const void*)k_propose<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
+    HIPCHK(hipFuncSetAttribute((const void*)k_propose<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
+    HIPCHK(hipFuncSetAttribute((const void*)k_mig_pack, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
     return DEMC_OK;
 }
 
