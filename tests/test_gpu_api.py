@@ -357,3 +357,22 @@ def test_plain_c_caller_of_the_abi(tmp_path):
     out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "C-ABI driver OK" in out.stdout
+
+
+def test_handles_of_different_sizes_coexist():
+    """the dynamic-LDS ceiling of a kernel is per function, not per handle: a small handle created after a large one
+    must not break the large one"""
+    big = make_problem("mvn_full", np.random.default_rng(51), N=200, d=32)
+    small = make_problem("gaussian", np.random.default_rng(52))
+    a = D.HipEngine(n_groups=2, Np=256, D=32, n_rows=4, schedule=2, seed=1)   # 64 KB group tile in LDS
+    setup_engine(a, big)
+    a.set_state(big["init"](512))
+    b = D.HipEngine(n_groups=2, Np=6, D=2, n_rows=4, schedule=2, seed=1)      # a few hundred bytes
+    setup_engine(b, small)
+    b.set_state(small["init"](12))
+    for it in range(1, 4):
+        a.step(it, 1)
+        b.step(it, 1)
+    assert np.isfinite(a.get_state()[1]).all() and np.isfinite(b.get_state()[1]).all()
+    a.close()
+    b.close()
