@@ -87,6 +87,9 @@ int fail(demc_handle* h, int code, const std::string& msg) {
             return fail(h, DEMC_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));                    \
     } while (0)
 
+// A handle belongs to one GPU; a host that drives several handles from one thread may have another device current.
+#define USE_DEVICE(h) HIPCHK(hipSetDevice((h)->c.device_id))
+
 template <typename T>
 int dev_alloc(demc_handle* h, T** p, size_t n) {
     if (n == 0) n = 1;
@@ -527,6 +530,7 @@ int32_t demc_destroy(demc_handle* h) {
 
 int32_t demc_set_stream(demc_handle* h, void* hip_stream) {
     if (!h) return DEMC_EINVAL;
+    USE_DEVICE(h);
     HIPCHK(hipStreamSynchronize(h->stream));
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     h->own_stream = false;
@@ -542,6 +546,7 @@ int32_t demc_set_stream(demc_handle* h, void* hip_stream) {
 int32_t demc_set_model(demc_handle* h, int32_t family, const double* data, const int64_t* dims, int32_t ndims,
                        const double* hyper, int32_t nhyper) {
     if (!h) return DEMC_EINVAL;
+    USE_DEVICE(h);
     if (ndims < 0 || ndims > 4 || (ndims > 0 && !dims)) return fail(h, DEMC_EINVAL, "bad dims");
     long long dm[4] = {0, 0, 0, 0};
     for (int i = 0; i < ndims; ++i) dm[i] = dims[i];
@@ -686,6 +691,7 @@ int32_t demc_set_model(demc_handle* h, int32_t family, const double* data, const
 int32_t demc_set_model_source(demc_handle* h, const char* hip_source, const double* data, const int64_t* dims, int32_t ndims,
                               const double* hyper, int32_t nhyper) {
     if (!h || !hip_source) return DEMC_EINVAL;
+    USE_DEVICE(h);
     if (ndims < 1 || !dims || dims[0] < 1 || !data) return fail(h, DEMC_EINVAL, "user model: dims[0] = number of observations, data required");
     long long n_data = 1;
     for (int i = 0; i < ndims; ++i) n_data *= dims[i];
@@ -730,6 +736,7 @@ int32_t demc_set_model_source(demc_handle* h, const char* hip_source, const doub
 
 int32_t demc_set_priors(demc_handle* h, const int32_t* kind, const double* a, const double* b, const int32_t* ref) {
     if (!h || !kind) return DEMC_EINVAL;
+    USE_DEVICE(h);
     const size_t D = (size_t)h->c.D;
     for (size_t j = 0; j < D; ++j) {
         if (kind[j] < 0 || kind[j] > DEMC_PRIOR_NORMAL_REF) return fail(h, DEMC_EUNSUPPORTED, "prior kind not registered");
@@ -753,6 +760,7 @@ int32_t demc_set_priors(demc_handle* h, const int32_t* kind, const double* a, co
 
 int32_t demc_set_bounds(demc_handle* h, const double* lo, const double* hi) {
     if (!h || !lo || !hi) return DEMC_EINVAL;
+    USE_DEVICE(h);
     const size_t D = (size_t)h->c.D;
     for (size_t j = 0; j < D; ++j) {
         h->h_tab[j].lo = lo[j];
@@ -765,6 +773,7 @@ int32_t demc_set_bounds(demc_handle* h, const double* lo, const double* hi) {
 
 int32_t demc_set_blocks(demc_handle* h, const uint8_t* masks, int32_t n_blocks) {
     if (!h || n_blocks < 0 || (n_blocks > 0 && !masks)) return DEMC_EINVAL;
+    USE_DEVICE(h);
     if (h->masks) { hipFree(h->masks); h->masks = nullptr; }
     h->c.n_blocks = n_blocks;
     if (n_blocks > 0) {
@@ -776,6 +785,7 @@ int32_t demc_set_blocks(demc_handle* h, const uint8_t* masks, int32_t n_blocks) 
 
 int32_t demc_set_state(demc_handle* h, const double* theta, const double* weight, const int64_t* id) {
     if (!h || !theta) return DEMC_EINVAL;
+    USE_DEVICE(h);
     const size_t P = (size_t)h->P, D = (size_t)h->c.D;
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(h->theta, theta, P * D * sizeof(double), hipMemcpyHostToDevice));
@@ -794,6 +804,7 @@ int32_t demc_set_state(demc_handle* h, const double* theta, const double* weight
 
 int32_t demc_get_state(demc_handle* h, double* theta, double* weight, int64_t* id) {
     if (!h) return DEMC_EINVAL;
+    USE_DEVICE(h);
     const size_t P = (size_t)h->P, D = (size_t)h->c.D;
     HIPCHK(hipStreamSynchronize(h->stream));
     if (theta) HIPCHK(hipMemcpy(theta, h->theta, P * D * sizeof(double), hipMemcpyDeviceToHost));
@@ -804,6 +815,7 @@ int32_t demc_get_state(demc_handle* h, double* theta, double* weight, int64_t* i
 
 int32_t demc_set_history_rows(demc_handle* h, int64_t row0, int64_t nrows, const double* rows) {
     if (!h || !rows) return DEMC_EINVAL;
+    USE_DEVICE(h);
     if (!h->hist) return fail(h, DEMC_EINVAL, "history is not stored on this handle");
     if (row0 < 0 || nrows < 0 || row0 + nrows > h->c.n_rows) return fail(h, DEMC_EINVAL, "history rows out of range");
     const size_t PD = (size_t)h->P * h->c.D;
@@ -814,6 +826,7 @@ int32_t demc_set_history_rows(demc_handle* h, int64_t row0, int64_t nrows, const
 
 int32_t demc_get_history(demc_handle* h, int64_t row0, int64_t row1, double* th, uint8_t* acc, double* lp, int64_t* idh) {
     if (!h) return DEMC_EINVAL;
+    USE_DEVICE(h);
     if (!h->hist) return fail(h, DEMC_EINVAL, "history is not stored on this handle");
     if (row0 < 0 || row1 < row0 || row1 > h->c.n_rows) return fail(h, DEMC_EINVAL, "history rows out of range");
     const size_t P = (size_t)h->P, D = (size_t)h->c.D, n = (size_t)(row1 - row0);
@@ -831,6 +844,7 @@ int32_t demc_get_history(demc_handle* h, int64_t row0, int64_t row1, double* th,
 
 static int32_t step_impl(demc_handle* h, int64_t iter0, int32_t n_iters, bool with_migration) {
     if (!h) return DEMC_EINVAL;
+    USE_DEVICE(h);
     if (h->family < 0) return fail(h, DEMC_EINVAL, "demc_set_model has not been called");
     if (iter0 < 1 || n_iters < 0) return fail(h, DEMC_EINVAL, "iter0 is 1-based (de.iter, main.jl:34)");
     const demc_config& c = h->c;
@@ -869,6 +883,7 @@ int32_t demc_migration_due(const demc_config* cfg, int64_t iter) {
 
 int32_t demc_migration_pack(demc_handle* h, int64_t iter, double* dev_rows) {
     if (!h) return DEMC_EINVAL;
+    USE_DEVICE(h);
     migration_enqueue(h, iter, dev_rows ? dev_rows : h->mig_rows, nullptr, true, false);
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
@@ -877,6 +892,7 @@ int32_t demc_migration_pack(demc_handle* h, int64_t iter, double* dev_rows) {
 
 int32_t demc_migration_apply(demc_handle* h, int64_t iter, const double* dev_all_rows) {
     if (!h) return DEMC_EINVAL;
+    USE_DEVICE(h);
     if (!dev_all_rows && h->c.n_groups_total != h->c.n_groups)
         return fail(h, DEMC_EINVAL, "sharded handle needs the all-gathered rows");
     migration_enqueue(h, iter, nullptr, dev_all_rows ? dev_all_rows : h->mig_rows, false, true);
@@ -887,6 +903,7 @@ int32_t demc_migration_apply(demc_handle* h, int64_t iter, const double* dev_all
 
 int32_t demc_logpost(demc_handle* h, const double* theta, int64_t n, double* out) {
     if (!h || !theta || !out || n < 0) return DEMC_EINVAL;
+    USE_DEVICE(h);
     if (h->family < 0) return fail(h, DEMC_EINVAL, "demc_set_model has not been called");
     const size_t P = (size_t)h->P, D = (size_t)h->c.D;
     std::vector<double> w(P);
@@ -907,6 +924,7 @@ int32_t demc_logpost(demc_handle* h, const double* theta, int64_t n, double* out
 
 int32_t demc_get_trace(demc_handle* h, double* proposal, double* w_prop, double* log_adj, int32_t* idx, uint8_t* accepted) {
     if (!h) return DEMC_EINVAL;
+    USE_DEVICE(h);
     const size_t P = (size_t)h->P, D = (size_t)h->c.D;
     HIPCHK(hipStreamSynchronize(h->stream));
     if (proposal) HIPCHK(hipMemcpy(proposal, h->prop, P * D * sizeof(double), hipMemcpyDeviceToHost));
@@ -919,6 +937,7 @@ int32_t demc_get_trace(demc_handle* h, double* proposal, double* w_prop, double*
 
 int32_t demc_timing_enable(demc_handle* h, int32_t on) {
     if (!h) return DEMC_EINVAL;
+    USE_DEVICE(h);
     HIPCHK(hipStreamSynchronize(h->stream));
     drain_events(h);
     h->timing = on != 0;
@@ -927,6 +946,7 @@ int32_t demc_timing_enable(demc_handle* h, int32_t on) {
 
 int32_t demc_timing_read(demc_handle* h, double* out10, int32_t reset) {
     if (!h || !out10) return DEMC_EINVAL;
+    USE_DEVICE(h);
     HIPCHK(hipStreamSynchronize(h->stream));
     drain_events(h);
     for (int i = 0; i < 5; ++i) {
