@@ -17,7 +17,7 @@ _CODE = {1: "DEMC_EINVAL", 2: "DEMC_EHIP", 3: "DEMC_ENOMEM", 4: "DEMC_ERCCL", 5:
 EXPORTS = [
     "demc_version", "demc_create", "demc_destroy", "demc_last_error", "demc_set_stream", "demc_set_model",
     "demc_set_model_source", "demc_set_priors", "demc_set_bounds", "demc_set_blocks", "demc_set_state", "demc_get_state",
-    "demc_set_history_rows", "demc_get_history", "demc_step", "demc_update", "demc_migration_due",
+    "demc_set_history_rows", "demc_get_history", "demc_export_chains", "demc_step", "demc_update", "demc_migration_due",
     "demc_migration_pack", "demc_migration_apply", "demc_logpost", "demc_get_trace", "demc_timing_enable",
     "demc_timing_read",
 ]
@@ -86,6 +86,7 @@ def load():
     L.demc_get_state.argtypes = [H, _dp, _dp, _lp]
     L.demc_set_history_rows.argtypes = [H, C.c_int64, C.c_int64, _dp]
     L.demc_get_history.argtypes = [H, C.c_int64, C.c_int64, _dp, _bp, _dp, _lp]
+    L.demc_export_chains.argtypes = [H, C.c_int64, C.c_int64, C.c_int32, _dp]
     L.demc_step.argtypes = [H, C.c_int64, C.c_int32]
     L.demc_update.argtypes = [H, C.c_int64, C.c_int32]
     L.demc_migration_due.argtypes = [C.POINTER(DemcConfig), C.c_int64]
@@ -214,6 +215,13 @@ class HipEngine:
         self._ck(self.L.demc_get_history(self.h, row0, row1, _d(th), acc.ctypes.data_as(_bp), _d(lp),
                                          idh.ctypes.data_as(_lp)))
         return th, acc, lp, idh
+
+    def export_chains(self, row0, row1):
+        """history rows [row0,row1) re-keyed by particle id on the device, as the Chains value array [n][D+2][P]
+        (parameters, acceptance, lp) -- bundle_samples' gather (main.jl:232-241) without a host-side scatter"""
+        out = np.empty((row1 - row0, self.D + 2, self.P))
+        self._ck(self.L.demc_export_chains(self.h, row0, row1, 1, _d(out)))
+        return out
 
     def step(self, iter0, n_iters=1):
         self._ck(self.L.demc_step(self.h, iter0, n_iters))

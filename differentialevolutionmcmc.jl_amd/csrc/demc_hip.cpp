@@ -842,6 +842,30 @@ int32_t demc_get_history(demc_handle* h, int64_t row0, int64_t row1, double* th,
     return DEMC_OK;
 }
 
+int32_t demc_export_chains(demc_handle* h, int64_t row0, int64_t row1, int32_t layout, double* out) {
+    if (!h || !out) return DEMC_EINVAL;
+    USE_DEVICE(h);
+    if (!h->hist) return fail(h, DEMC_EINVAL, "history is not stored on this handle");
+    if (row0 < 0 || row1 < row0 || row1 > h->c.n_rows || (layout != 0 && layout != 1)) return fail(h, DEMC_EINVAL, "bad rows / layout");
+    if (h->c.n_groups_total != h->c.n_groups)
+        return fail(h, DEMC_EINVAL, "sharded handle: gather demc_get_history from every rank and re-key on the host");
+    const long long n = row1 - row0;
+    if (n == 0) return DEMC_OK;
+    const size_t elems = (size_t)n * (size_t)h->P * (size_t)(h->c.D + 2);
+    double* dev = nullptr;
+    ALLOC(dev, elems);
+    KParams k = base_params(h);
+    const long long blocks = (long long)((elems + 255) / 256);
+    hipLaunchKernelGGL(k_export_chains, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, h->stream, k, (long long)row0, n,
+                       (int)layout, (long long)h->c.group_offset * h->c.Np, dev);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(out, dev, elems * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(dev);
+    if (e != hipSuccess) return fail(h, DEMC_EHIP, std::string("demc_export_chains: ") + hipGetErrorString(e));
+    return DEMC_OK;
+}
+
 static int32_t step_impl(demc_handle* h, int64_t iter0, int32_t n_iters, bool with_migration) {
     if (!h) return DEMC_EINVAL;
     USE_DEVICE(h);

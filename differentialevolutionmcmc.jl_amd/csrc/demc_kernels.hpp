@@ -1247,4 +1247,25 @@ __global__ __launch_bounds__(256) void k_mig_apply(KParams p, const double* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Chains export (bundle_samples, main.jl:222-250): re-key the slot-keyed history by particle id and lay it out as the
+// value array (parameters, acceptance, lp).  One thread per (row, slot, j); reads are contiguous in j.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_export_chains(KParams p, long long row0, long long n, int layout, long long id0,
+                                                       double* __restrict__ out) {
+    const long long D2 = p.D + 2;
+    const long long total = n * p.P * D2;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const long long j = t % D2, rs = t / D2;
+        const long long slot = rs % p.P, r = rs / p.P;
+        const size_t hrow = (size_t)(row0 + r) * p.P + slot;
+        const long long id = (long long)p.id_hist[hrow] - id0;
+        const double v = j < p.D ? p.hist[hrow * p.D + j] : (j == p.D ? (double)p.acc_hist[hrow] : p.lp_hist[hrow]);
+        if (layout == 0)
+            out[(size_t)((id * D2 + j) * n + r)] = v;
+        else
+            out[(size_t)((r * D2 + j) * p.P + id)] = v;
+    }
+}
+
 }  // namespace demc

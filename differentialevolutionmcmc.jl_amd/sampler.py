@@ -155,17 +155,14 @@ def rekey_by_id(th, acc, lp, idh, id0=0, P_total=None):
     return oth, oacc, olp
 
 
-def bundle_samples(model, de, lay, hist_by_id, acc_by_id, lp_by_id, n_iter):
+def bundle_samples(model, de, lay, full, n_iter):
     """main.jl:222-250, including its row selection: rows offset+1 .. offset+Ns of the history with
     offset = burnin (or 0), which ignores the n_initial offset.  Deviation (q2): accept/lp are
-    paired with Theta by particle id rather than by final slot."""
+    paired with Theta by particle id rather than by final slot.  `full` is [rows][D+2][P] by particle id."""
     Ns = n_iter - de.burnin if de.discard_burnin else n_iter
     offset = de.burnin if de.discard_burnin else 0
     names = get_names(model, lay["shapes"])
-    th = hist_by_id[offset:offset + Ns]  # [Ns][P][D]
-    v = np.concatenate([th, acc_by_id[offset:offset + Ns, :, None].astype(np.float64),
-                        lp_by_id[offset:offset + Ns, :, None]], axis=2)  # [Ns][P][D+2]
-    return Chains(np.transpose(v, (0, 2, 1)), names, parameters=names[:-2])
+    return Chains(full[offset:offset + Ns], names, parameters=names[:-2])
 
 
 def _parse(args):
@@ -216,20 +213,25 @@ def _run(model, de, n_iter, backend, progress, engine_factory):
         if progress:
             print()
         de.iter = n_iter + de.n_initial
-        th, acc, lp, idh = eng.get_history(0, n_iter + de.n_initial)
+        n_rows = n_iter + de.n_initial
+        if hasattr(eng, "export_chains"):  # device-side re-key + layout (demc_export_chains)
+            full = eng.export_chains(0, n_rows)  # [n_rows][D+2][P] by particle id
+        else:  # engines without it (the CPU oracle injected by tests): re-key on the host
+            th, acc, lp = rekey_by_id(*eng.get_history(0, n_rows))
+            full = np.concatenate([np.transpose(th, (0, 2, 1)), acc[:, None, :].astype(np.float64), lp[:, None, :]], axis=1)
         state = eng.get_state()
     finally:
         eng.close()
-    return lay, rekey_by_id(th, acc, lp, idh), state
+    return lay, full, state
 
 
 def sample(model, de, *args, progress=False, engine_factory=None, **kwargs):
     """sample(model, de, n_iter) / sample(model, de, MCMCThreads(), n_iter) (main.jl:19-20, 62-71) and
     sample(model, de, HIPBackend(...), n_iter).  Every form runs on the MI355X; there is no CPU path."""
     backend, n_iter = _parse(args)
-    lay, (th, acc, lp), _ = _run(model, de, n_iter, backend, progress, engine_factory)
-    de.samples = th
-    return bundle_samples(model, de, lay, th, acc, lp, n_iter)
+    lay, full, _ = _run(model, de, n_iter, backend, progress, engine_factory)
+    de.samples = full[:, :lay["D"], :]  # the reference's de.samples: (rows, parameters, particle id)
+    return bundle_samples(model, de, lay, full, n_iter)
 
 
 def optimize(model, de, *args, progress=False, engine_factory=None, **kwargs):

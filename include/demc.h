@@ -159,6 +159,13 @@ int32_t demc_set_history_rows(demc_handle* h, int64_t row0, int64_t nrows, const
 int32_t demc_get_history(demc_handle* h, int64_t row0, int64_t row1, double* theta_hist, uint8_t* accept_hist,
                          double* lp_hist, int64_t* id_hist);
 
+/* bundle_samples' gather (main.jl:232-241) done on the device: history rows [row0,row1) re-keyed by particle id and laid
+ * out as the value array of the Chains object, n = row1 - row0, j < D: parameter j, j = D: acceptance, j = D+1: lp.
+ *   layout 0: out[(id*(D+2) + j)*n + (row-row0)]   = Julia Array{Float64,3}(n, D+2, P), column-major (iteration fastest)
+ *   layout 1: out[((row-row0)*(D+2) + j)*P + id]   = C order [n][D+2][P]
+ * One kernel + one device-to-host copy; single-shard handles only (ids must be local). */
+int32_t demc_export_chains(demc_handle* h, int64_t row0, int64_t row1, int32_t layout, double* host_out);
+
 /* n_iters of step!/pstep! (main.jl:84-107) starting at de.iter == iter0 (1-based, n_initial included):
  * migration coin + exchange (single shard only), update of every group, store. */
 int32_t demc_step(demc_handle* h, int64_t iter0, int32_t n_iters);

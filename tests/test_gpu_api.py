@@ -376,3 +376,25 @@ def test_handles_of_different_sizes_coexist():
     assert np.isfinite(a.get_state()[1]).all() and np.isfinite(b.get_state()[1]).all()
     a.close()
     b.close()
+
+
+def test_device_chain_export_equals_host_rekey():
+    """demc_export_chains (both layouts) against the slot-keyed history re-keyed with numpy; alpha = 1 so that particle
+    ids move between slots on every iteration"""
+    import ctypes as C
+    from demc_amd import sampler as S
+    prob = make_problem("mvn_iso", np.random.default_rng(61), d=5)
+    G, Np, Dd, n = 5, 8, 6, 12
+    eng = D.HipEngine(n_groups=G, Np=Np, D=Dd, n_rows=n, schedule=2, seed=6, alpha=1.0)
+    setup_engine(eng, prob)
+    eng.set_state(prob["init"](G * Np))
+    eng.step(1, n)
+    th, acc, lp = S.rekey_by_id(*eng.get_history(2, n))
+    exp = np.concatenate([np.transpose(th, (0, 2, 1)), acc[:, None, :].astype(float), lp[:, None, :]], axis=1)
+    got = eng.export_chains(2, n)
+    assert np.array_equal(got, exp)
+    assert not np.array_equal(eng.get_history(0, n)[3][0], eng.get_history(0, n)[3][-1])  # ids really moved
+    julia = np.empty((G * Np, Dd + 2, n - 2))  # Array{Float64,3}(n, D+2, P) column-major == C array [P][D+2][n]
+    eng._ck(eng.L.demc_export_chains(eng.h, 2, n, 0, julia.ctypes.data_as(C.POINTER(C.c_double))))
+    assert np.array_equal(np.transpose(julia, (2, 1, 0)), exp)
+    eng.close()
