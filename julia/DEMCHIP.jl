@@ -121,16 +121,14 @@ function sample(model::DEModel, de::DE, b::HIPBackend, n_iter::Int; model_spec::
         check(h, @ccall LIB.demc_step(h::Ptr{Cvoid}, Int64(1 + de.n_initial)::Int64, Int32(n_iter)::Int32)::Int32)
         de.iter = n_iter + de.n_initial
         n_rows = n_iter + de.n_initial
-        th = Array{Float64}(undef, D, P, n_rows); acc = Array{UInt8}(undef, P, n_rows)
-        lp = Array{Float64}(undef, P, n_rows); idh = Array{Int64}(undef, P, n_rows)
-        check(h, @ccall LIB.demc_get_history(h::Ptr{Cvoid}, 0::Int64, Int64(n_rows)::Int64, th::Ptr{Float64}, acc::Ptr{UInt8},
-            lp::Ptr{Float64}, idh::Ptr{Int64})::Int32)
-        # re-key by particle id: samples[iter, :, p.id] (utilities.jl:170-180); accept/lp live on the Particle
-        for r = 1:n_rows, s = 1:P
-            id = idh[s, r] + 1
-            de.samples[r, :, id] = th[:, s, r]            # flat parameters; un-flatten here for nested Θ
-            particles[id].accept[r] = acc[s, r] != 0
-            particles[id].lp[r] = lp[s, r]
+        # bundle_samples' gather (src/main.jl:232-241) on the device: layout 0 IS Array{Float64,3}(n_rows, D+2, P) in
+        # Julia's column-major order, already keyed by particle id (parameters, then "acceptance", then "lp")
+        v = Array{Float64,3}(undef, n_rows, D + 2, P)
+        check(h, @ccall LIB.demc_export_chains(h::Ptr{Cvoid}, 0::Int64, Int64(n_rows)::Int64, 0::Int32, v::Ptr{Float64})::Int32)
+        for id = 1:P
+            de.samples[:, :, id] = v[:, 1:D, id]          # flat parameters; un-flatten here for nested Θ
+            particles[id].accept .= v[:, D + 1, id] .!= 0
+            particles[id].lp .= v[:, D + 2, id]
         end
     finally
         h != C_NULL && @ccall LIB.demc_destroy(h::Ptr{Cvoid})::Int32
