@@ -94,7 +94,14 @@ def cpu_baseline(prob, Np, N, d, seconds_target=20.0):
     one_thread, _ = run(1, 1, 3.0)  # one group on one thread, ~3 s
     value, iters = run(ng, cores, seconds_target)
     dt = ng * Np * iters / value
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next(ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
     return dict(value=value, unit="particle-updates/s", cores=cores, kind="port", value_single_thread=one_thread,
+                cpu_model=cpu_model,
                 sample=f"cfg3 shape (D={d}, N={N}, Np={Np}) on {ng} of the groups, {iters} iterations, reference "
                        f"schedule (sequential in-group sweep, one group per OpenMP thread), whitened O(N*D) "
                        f"likelihood per proposal; gcc -O3 -march=native -fopenmp")
