@@ -7,7 +7,7 @@ any sampling call raises -- there is no CPU fallback.
 from . import _ffi, families
 from ._ffi import DemcError, HipEngine
 from .chains import Chains
-from .families import (Beta, BinomialLikelihood, Flat, GaussianLikelihood, HierBinomialLikelihood,
+from .families import (Beta, BinomialLikelihood, Cauchy, Exponential, Flat, Gamma, GaussianLikelihood, LogNormal, HierBinomialLikelihood,
                        HierGaussianLikelihood, LBALikelihood, LNRLikelihood, MvNormalFullLikelihood,
                        MvNormalIsoLikelihood, Normal, Priors, RastriginObjective, SourceLikelihood, TruncatedCauchy,
                        Uniform)

@@ -96,7 +96,10 @@ __device__ inline double Phi(double x) { return 0.5 * erfc(-x * kInvSqrt2); }
 __device__ inline double phi(double x) { return exp(-0.5 * x * x) * kInvSqrt2Pi; }
 __device__ inline double softplus(double x) { return x > 0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
 
-enum Prior : int { PR_FLAT = 0, PR_NORMAL = 1, PR_HALFCAUCHY = 2, PR_UNIFORM = 3, PR_BETA = 4, PR_NORMAL_REF = 5 };
+enum Prior : int {
+    PR_FLAT = 0, PR_NORMAL = 1, PR_HALFCAUCHY = 2, PR_UNIFORM = 3, PR_BETA = 4, PR_NORMAL_REF = 5, PR_GAMMA = 6,
+    PR_EXPONENTIAL = 7, PR_LOGNORMAL = 8, PR_CAUCHY = 9
+};
 
 // x-independent part of a scalar's log-prior, computed on the host (keeps lgamma / atan out of the kernels)
 inline double prior_const(int kind, double a, double b) {
@@ -109,6 +112,14 @@ inline double prior_const(int kind, double a, double b) {
             return -std::log(b - a);
         case PR_BETA:
             return -(std::lgamma(a) + std::lgamma(b) - std::lgamma(a + b));
+        case PR_GAMMA:
+            return -a * std::log(b) - std::lgamma(a);
+        case PR_EXPONENTIAL:
+            return -std::log(b);
+        case PR_LOGNORMAL:
+            return -std::log(b) - 0.5 * kLog2Pi;
+        case PR_CAUCHY:
+            return -kLogPi - std::log(b);
         default:
             return 0.0;
     }

@@ -739,7 +739,7 @@ int32_t demc_set_priors(demc_handle* h, const int32_t* kind, const double* a, co
     USE_DEVICE(h);
     const size_t D = (size_t)h->c.D;
     for (size_t j = 0; j < D; ++j) {
-        if (kind[j] < 0 || kind[j] > DEMC_PRIOR_NORMAL_REF) return fail(h, DEMC_EUNSUPPORTED, "prior kind not registered");
+        if (kind[j] < 0 || kind[j] > DEMC_PRIOR_CAUCHY) return fail(h, DEMC_EUNSUPPORTED, "prior kind not registered");
         if (kind[j] == DEMC_PRIOR_NORMAL_REF && (!ref || ref[j] < 0 || ref[j] >= (int)D))
             return fail(h, DEMC_EINVAL, "prior ref out of range");
     }
@@ -750,7 +750,9 @@ int32_t demc_set_priors(demc_handle* h, const int32_t* kind, const double* a, co
         t.ref = ref ? ref[j] : 0;
         t.a = aj;
         // reciprocal scale for the location-scale families: no FP64 division per scalar in the kernels
-        t.b = (kind[j] == PR_NORMAL || kind[j] == PR_HALFCAUCHY) ? 1.0 / bj : bj;
+        const bool recip = kind[j] == PR_NORMAL || kind[j] == PR_HALFCAUCHY || kind[j] == PR_GAMMA ||
+                           kind[j] == PR_EXPONENTIAL || kind[j] == PR_LOGNORMAL || kind[j] == PR_CAUCHY;
+        t.b = recip ? 1.0 / bj : bj;
         t.c = prior_const(kind[j], aj, bj);
     }
     HIPCHK(hipStreamSynchronize(h->stream));

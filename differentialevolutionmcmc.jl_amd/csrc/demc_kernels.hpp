@@ -339,6 +339,19 @@ __device__ inline double prior_term(const DimTab& t, double x, double inv_sref, 
             const double t2 = (t.b == 1.0) ? 0.0 : (t.b - 1.0) * log1p(-x);
             return t1 + t2 + t.c;
         }
+        case PR_GAMMA:  // a = shape, b = 1/scale
+            return x > 0.0 ? (t.a - 1.0) * log(x) - x * t.b + t.c : -INFINITY;
+        case PR_EXPONENTIAL:  // b = 1/scale
+            return x >= 0.0 ? t.c - x * t.b : -INFINITY;
+        case PR_LOGNORMAL: {  // b = 1/sigma
+            if (!(x > 0.0)) return -INFINITY;
+            const double lx = log(x), z = (lx - t.a) * t.b;
+            return t.c - lx - 0.5 * (z * z);
+        }
+        case PR_CAUCHY: {  // b = 1/scale
+            const double z = (x - t.a) * t.b;
+            return t.c - log1p(z * z);
+        }
         default:
             return 0.0;
     }

@@ -11,7 +11,8 @@ import numpy as np
 FAM_GAUSSIAN, FAM_MVN_ISO, FAM_MVN_FULL, FAM_BINOMIAL, FAM_HIER_BINOMIAL, FAM_HIER_GAUSSIAN, FAM_LBA, FAM_LNR, \
     FAM_RASTRIGIN = range(9)
 FAM_USER = 100
-PRIOR_FLAT, PRIOR_NORMAL, PRIOR_HALFCAUCHY, PRIOR_UNIFORM, PRIOR_BETA, PRIOR_NORMAL_REF = range(6)
+PRIOR_FLAT, PRIOR_NORMAL, PRIOR_HALFCAUCHY, PRIOR_UNIFORM, PRIOR_BETA, PRIOR_NORMAL_REF, PRIOR_GAMMA, \
+    PRIOR_EXPONENTIAL, PRIOR_LOGNORMAL, PRIOR_CAUCHY = range(10)
 
 
 # ---- priors: named like Distributions.jl -------------------------------------------------------
@@ -57,6 +58,36 @@ class Beta(Prior):
 
     def __init__(self, a=1.0, b=1.0):
         self.a, self.b = float(a), float(b)
+
+
+class Gamma(Prior):
+    """Gamma(shape, scale) (Distributions.jl parameterisation)"""
+    kind = PRIOR_GAMMA
+
+    def __init__(self, shape=1.0, scale=1.0):
+        self.a, self.b = float(shape), float(scale)
+
+
+class Exponential(Prior):
+    """Exponential(scale)"""
+    kind = PRIOR_EXPONENTIAL
+
+    def __init__(self, scale=1.0):
+        self.a, self.b = 0.0, float(scale)
+
+
+class LogNormal(Prior):
+    kind = PRIOR_LOGNORMAL
+
+    def __init__(self, mu=0.0, sigma=1.0):
+        self.a, self.b = float(mu), float(sigma)
+
+
+class Cauchy(Prior):
+    kind = PRIOR_CAUCHY
+
+    def __init__(self, loc=0.0, scale=1.0):
+        self.a, self.b = float(loc), float(scale)
 
 
 class Priors:

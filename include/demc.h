@@ -86,7 +86,11 @@ enum {
     DEMC_PRIOR_HALFCAUCHY = 2,  /* truncated(Cauchy(a, b), 0, Inf) */
     DEMC_PRIOR_UNIFORM = 3,     /* Uniform(a, b) */
     DEMC_PRIOR_BETA = 4,        /* Beta(a, b) */
-    DEMC_PRIOR_NORMAL_REF = 5   /* Normal(a, theta[ref]) */
+    DEMC_PRIOR_NORMAL_REF = 5,  /* Normal(a, theta[ref]) */
+    DEMC_PRIOR_GAMMA = 6,       /* Gamma(shape a, scale b) */
+    DEMC_PRIOR_EXPONENTIAL = 7, /* Exponential(scale b)      (Distributions.jl parameterisation) */
+    DEMC_PRIOR_LOGNORMAL = 8,   /* LogNormal(a, b) */
+    DEMC_PRIOR_CAUCHY = 9       /* Cauchy(a, b) */
 };
 
 /* POD mirror of the DE keyword constructor (structs.jl:80-131). */

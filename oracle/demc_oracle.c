@@ -326,6 +326,21 @@ static double prior_scalar(int kind, double a, double b, double sref, double x) 
         }
         case ORC_PRIOR_UNIFORM:
             return (x >= a && x <= b) ? -log(b - a) : -INFINITY;
+        case ORC_PRIOR_GAMMA: /* Distributions.jl Gamma(shape, scale) */
+            if (!(x > 0.0)) return -INFINITY;
+            return (a - 1.0) * log(x) - x / b - a * log(b) - lgamma(a);
+        case ORC_PRIOR_EXPONENTIAL: /* Exponential(scale) */
+            if (x < 0.0) return -INFINITY;
+            return -log(b) - x / b;
+        case ORC_PRIOR_LOGNORMAL: {
+            if (!(x > 0.0)) return -INFINITY;
+            const double z = (log(x) - a) / b;
+            return -log(x) - log(b) - 0.5 * LOG_2PI - 0.5 * z * z;
+        }
+        case ORC_PRIOR_CAUCHY: {
+            const double z = (x - a) / b;
+            return -LOG_PI - log(b) - log1p(z * z);
+        }
         case ORC_PRIOR_BETA: {
             if (x < 0.0 || x > 1.0) return -INFINITY;
             const double lbeta = lgamma(a) + lgamma(b) - lgamma(a + b);

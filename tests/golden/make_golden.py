@@ -24,6 +24,10 @@ with np.errstate(divide="ignore"):
     out["prior_uniform_m1_2"] = stats.uniform(-1, 3).logpdf(xs)
     out["prior_beta_2_3"] = stats.beta(2, 3).logpdf(xs)
     out["prior_beta_1_1"] = stats.beta(1, 1).logpdf(xs)
+    out["prior_gamma_2p5_1p5"] = stats.gamma(2.5, scale=1.5).logpdf(xs)
+    out["prior_exponential_0p7"] = stats.expon(scale=0.7).logpdf(xs)
+    out["prior_lognormal_0p3_0p8"] = np.where(xs > 0, stats.lognorm(s=0.8, scale=np.exp(0.3)).logpdf(np.where(xs > 0, xs, 1.0)), -np.inf)
+    out["prior_cauchy_m1_2"] = stats.cauchy(-1.0, 2.0).logpdf(xs)
 
 # ---- Gaussian (Examples/Gaussian_Example.jl:26-28) ---------------------------------------------------------
 x = rng.normal(0.2, 1.1, 50)

@@ -258,3 +258,21 @@ def test_lba_lnr_against_scipy_goldens(demc):
         eng.set_priors([F.PRIOR_FLAT] * D, [0.0] * D, [1.0] * D)
         np.testing.assert_allclose(eng.logpost(th), G[f"{key}_ll"], rtol=1e-9)
         eng.close()
+
+
+@pytest.mark.parametrize("kind,a,b", [(6, 2.5, 1.5), (7, 0.0, 0.7), (8, 0.3, 0.8), (9, -1.0, 2.0), (4, 2.0, 3.0), (3, 0.1, 5.0)])
+def test_prior_kinds_match_oracle_and_goldens(demc, orc, kind, a, b):
+    """every registered prior (Gamma, Exponential, LogNormal, Cauchy, Beta, Uniform) on the sigma slot of the Gaussian
+    model: device log-posterior vs oracle, including points outside the prior's support (-Inf)"""
+    prob = make_problem("gaussian", np.random.default_rng(71))
+    prob = dict(prob, pk=[1, kind], pa=[0.0, a], pb=[10.0, b], lo=[-np.inf, -np.inf], hi=[np.inf, np.inf])
+    eng, o = _pair(demc, orc, prob, n_groups=2, Np=8, schedule=1)
+    th = prob["init"](16)
+    th[:4, 1] = [0.05, 0.5, 0.999, 4.0]
+    th[4, 1] = -0.3   # outside the support of the positive-only priors; sigma < 0 also makes the likelihood NaN/odd
+    lg, lo_ = eng.logpost(th), o.logpost(th)
+    fin = np.isfinite(lo_)
+    assert fin.sum() >= 3
+    assert np.array_equal(np.isfinite(lg), fin)
+    np.testing.assert_allclose(lg[fin], lo_[fin], rtol=1e-10)
+    eng.close()

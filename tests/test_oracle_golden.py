@@ -19,7 +19,9 @@ def _orc(orc, D):
 @pytest.mark.parametrize("kind,a,b,key", [
     (F.PRIOR_NORMAL, 1.0, 2.0, "prior_normal_1_2"), (F.PRIOR_HALFCAUCHY, 0.0, 1.0, "prior_halfcauchy_0_1"),
     (F.PRIOR_HALFCAUCHY, 0.0, 2.5, "prior_halfcauchy_0_2p5"), (F.PRIOR_UNIFORM, -1.0, 2.0, "prior_uniform_m1_2"),
-    (F.PRIOR_BETA, 2.0, 3.0, "prior_beta_2_3"), (F.PRIOR_BETA, 1.0, 1.0, "prior_beta_1_1")])
+    (F.PRIOR_BETA, 2.0, 3.0, "prior_beta_2_3"), (F.PRIOR_BETA, 1.0, 1.0, "prior_beta_1_1"),
+    (F.PRIOR_GAMMA, 2.5, 1.5, "prior_gamma_2p5_1p5"), (F.PRIOR_EXPONENTIAL, 0.0, 0.7, "prior_exponential_0p7"),
+    (F.PRIOR_LOGNORMAL, 0.3, 0.8, "prior_lognormal_0p3_0p8"), (F.PRIOR_CAUCHY, -1.0, 2.0, "prior_cauchy_m1_2")])
 def test_priors(orc, kind, a, b, key):
     o = _orc(orc, 1)
     o.set_priors([kind], [a], [b])
