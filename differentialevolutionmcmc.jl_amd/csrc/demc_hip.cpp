@@ -24,6 +24,8 @@
 
 using namespace demc;
 
+constexpr size_t kMaxDynLds = 150 * 1024;  // of the 160 KB per CU; the rest covers the kernels' static __shared__
+
 namespace {
 
 struct Timed {
@@ -64,7 +66,7 @@ struct demc_handle {
     int partial_cap = 64;
     int lpp = 1;
     int tile_in_lds = 0;
-    size_t k1_lds = 0, k1_tile_bytes = 0;
+    size_t k1_lds = 0, k1_tile_bytes = 0, k1_scr_bytes = 0;
     std::string err;
     // timing
     bool timing = false;
@@ -156,7 +158,8 @@ KParams base_params(demc_handle* h) {
     k.family = h->family; k.N = h->N; k.d = h->d; k.n_acc = h->n_acc; k.n_partials = 1;
     k.partial = h->partial; k.aux = h->aux; k.data = h->data; k.data2 = h->data ? h->data + h->data2_off : nullptr;
     k.c0 = h->c0; k.c1 = h->c1; k.c2 = h->c2;
-    k.n_split = 1; k.fuse_prep = 0; k.prep_mfma = 0; k.fuse_obs = 0; k.fuse_accept = 0; k.write_prop = 1; k.trace = c.trace;
+    k.n_split = 1; k.fuse_prep = 0; k.prep_mfma = 0; k.fuse_obs = 0; k.fuse_accept = 0; k.plan = 0;
+    k.scr_doubles = (int)(h->k1_scr_bytes / sizeof(double)); k.write_prop = 1; k.trace = c.trace;
     k.Ainv = h->Ainv; k.sx = nullptr; k.xbar = h->xbar; k.Ypad = h->Ypad; k.dpad = h->dpad;
     return k;
 }
@@ -319,9 +322,19 @@ int launch_phase(demc_handle* h, KParams& k) {
     if (n_split < 1) n_split = 1;
     k.n_split = n_split;
     const bool tile = k.tile_in_lds && c.partner_kind == DEMC_PARTNER_CURRENT;
+    // plan stage (per-particle scalars once per workgroup): 3 doubles + 4 ints per particle of the workgroup's slice
+    const size_t per_split = (size_t)(k.n_act + n_split - 1) / n_split;
+    const size_t plan_bytes = per_split * (3 * sizeof(double) + 4 * sizeof(int));
+    // tile = the partner pool, plus the workgroup's own slice of moving rows when those lie outside the pool
+    k.own_in_pool = (k.a_lo >= k.pool_lo && k.a_lo + k.n_act <= k.pool_lo + k.pool_n) ? 1 : 0;
+    k.tile_rows = k.pool_n + (k.own_in_pool ? 0 : (int)per_split);
+    const size_t lds_tile = h->k1_lds - h->k1_tile_bytes + (size_t)k.tile_rows * c.D * sizeof(double);  // <= k1_lds
+    k.plan = (tile && k.mode == MODE_STEP && k.lpp >= 4 && k.lpp <= 64 && lds_tile + plan_bytes <= kMaxDynLds) ? 1 : 0;
+    if (const char* e = std::getenv("DEMC_K1_PLAN")) k.plan = k.plan && e[0] == '1';  // A/B experiments
     tick(h, 0, true);
     if (tile)
-        hipLaunchKernelGGL(k_propose<true>, dim3(k.n_groups * n_split), dim3(256), h->k1_lds, h->stream, k);
+        hipLaunchKernelGGL(k_propose<true>, dim3(k.n_groups * n_split), dim3(256), lds_tile + (k.plan ? plan_bytes : 0),
+                           h->stream, k);
     else
         hipLaunchKernelGGL(k_propose<false>, dim3(k.n_groups * n_split), dim3(256), h->k1_lds - h->k1_tile_bytes, h->stream, k);
     tick(h, 0, false);
@@ -374,8 +387,6 @@ int evaluate_rows(demc_handle* h, double* theta_dev, double* weight_dev) {
     return launch_phase(h, k);
 }
 
-constexpr size_t kMaxDynLds = 150 * 1024;  // of the 160 KB per CU; the rest covers the kernels' static __shared__
-
 // K1 LDS carve-up (must match k_propose): group tile (if it fits) | Np prefix sums | A^-1 [d][d] | theta' scratch
 int size_k1_lds(demc_handle* h) {
     const demc_config& c = h->c;
@@ -389,6 +400,7 @@ int size_k1_lds(demc_handle* h) {
     h->tile_in_lds = (tile + cdf + ainv + xb + scr <= 96 * 1024) ? 1 : 0;
     if (const char* e = std::getenv("DEMC_K1_TILE")) h->tile_in_lds = (e[0] == '1') && h->tile_in_lds;  // A/B experiments
     h->k1_tile_bytes = h->tile_in_lds ? tile : 0;
+    h->k1_scr_bytes = scr;
     h->k1_lds = h->k1_tile_bytes + cdf + ainv + xb + scr;
     if (h->k1_lds > kMaxDynLds) return fail(h, DEMC_EINVAL, "K1 LDS budget exceeded (Np too large for this D)");
     // the attribute is per function, not per handle: always raise it to the same ceiling so that handles of different

@@ -75,6 +75,10 @@ struct KParams {
     int n_split;              // K1: workgroups per group
     int fuse_prep;            // K1 computes y = A^-1 theta', a = theta'.y (MvNormal families)
     int prep_mfma;            // ... on the matrix cores (full Sigma, d <= 32, 16 lanes per particle)
+    int tile_rows;            // K1: rows of the LDS tile = the partner pool (+ the workgroup's own rows if outside it)
+    int own_in_pool;          // K1: the moving particles are themselves pool rows (synchronous schedule)
+    int plan;                 // K1: per-particle scalars (coins, indices, gammas) computed once per workgroup, 4 lanes each
+    int scr_doubles;          // K1: size of the theta' scratch region in LDS (doubles)
     int fuse_obs;             // K1 sums the per-observation terms itself (small N, scalar-data families)
     int fuse_accept;          // K1 finishes the update (cheap likelihoods, two_colour)
     int write_prop;           // K1 writes proposals to HBM (needed by K2/K3 or by the trace)
@@ -274,12 +278,11 @@ __device__ inline double obs_range_sum(const KParams& p, const double* th, long 
 }
 
 // mh_update! / maximize! / minimize! decision for one particle (utilities.jl:55-58, 201-226)
-// ra = Philox block 3 of the particle's PART stream (the accept uniform)
-__device__ inline int decide(const KParams& p, const U4& ra, double wp, double w, double adj) {
+// u = the particle's accept uniform (Philox block 3 of its PART stream)
+__device__ inline int decide(const KParams& p, double u, double wp, double w, double adj) {
     if (p.mode == MODE_IDENT) return 1;
     if (p.update_kind == 1) return wp > w;
     if (p.update_kind == 2) return wp < w;
-    const double u = u53(ra.x, ra.y);
     const double e = exp(wp - w + adj);  // min(1, NaN) = NaN in Julia -> `rand() <= NaN` is false -> reject
     return (e >= 1.0) || (u <= e);
 }
@@ -360,6 +363,9 @@ __device__ inline double prior_term(const DimTab& t, double x, double inv_sref, 
 // In-kernel stamps (diagnostic build only: make STAMPS=1; tools/k1_stamps.py reads them back through the trace).
 // Thread 0 of every workgroup stores the s_memtime delta since kernel start into tr_w[16*blockIdx.x + i]; the
 // product build compiles them away.
+#ifndef DEMC_STAMP_PASS
+#define DEMC_STAMP_PASS 1  // which pass of the workgroup the per-pass stamps sample (0 = the cold first pass)
+#endif
 #ifdef DEMC_STAMPS
 #define DEMC_STAMP(i)                                                                                              \
     do {                                                                                                           \
@@ -374,6 +380,25 @@ __device__ inline double prior_term(const DimTab& t, double x, double inv_sref, 
     do {                  \
     } while (0)
 #endif
+
+// One LDS-DMA instruction: every active lane moves 16 bytes from its own global address to (wave-uniform LDS address) +
+// lane*16.  Written as assembly rather than __builtin_amdgcn_global_load_lds so that the compiler does not track it:
+// with the builtin, the first LDS access after the copy (which "may alias" its destination) gets an s_waitcnt vmcnt(0),
+// i.e. the prologue would stall on the copy it is meant to overlap.  The kernel waits for the copy itself (vmcnt(0) +
+// barrier) before the first read of the tile; compiler-inserted vmcnt waits in between can only be stricter than needed,
+// because a wave's memory operations retire in issue order.
+__device__ inline void lds_dma16(const double* g, double* l) {
+    const uint32_t lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) void*)l);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory", "m0");
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global-memory counter, which
+// would make every barrier of the prologue wait for the tile copy (LDS-DMA) the prologue is supposed to overlap with.
+__device__ inline void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 template <bool TILE>
 __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
@@ -392,100 +417,212 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     const double* gw = p.weight + (size_t)g * Np;
     const int lpp = p.lpp;
     const int ppp = 256 / lpp;  // particles per pass
-    // LDS carve-up (host computes the same sizes): tile | cdf + chunk totals | A^-1 | theta' scratch
+    const int per_split = (p.n_act + p.n_split - 1) / p.n_split;
+    const int q_lo = sp * per_split;
+    const int q_hi = (q_lo + per_split < p.n_act) ? q_lo + per_split : p.n_act;
+    // LDS carve-up (host computes the same sizes): tile | cdf + chunk totals | A^-1 | theta' scratch | plan
     double* tile = lds;
-    double* cdf = tile + (TILE ? (size_t)Np * D : 0);
+    double* cdf = tile + (TILE ? (size_t)p.tile_rows * D : 0);
     double* ainv_s = cdf + Np + ((Np + 15) >> 4);
     const int scr_stride = D + 2;
     double* xb_s = ainv_s + ((p.fuse_prep && p.Ainv) ? (size_t)d * d : 0);
     double* scr = xb_s + (p.fuse_prep ? d : 0);
     const bool use_scr = p.fuse_prep || p.fuse_obs;  // theta' of the pass kept in LDS for the fused tails
+    double* plan_d = scr + p.scr_doubles;                              // [per_split][3]: g1, g2, accept uniform
+    int* plan_i = reinterpret_cast<int*>(plan_d + 3 * (size_t)per_split);  // [per_split][4]
 
-    bool is_mut = false;
-    if (p.mode == MODE_STEP) {
-        const U4 r = draw_block(p.seed, S_GROUP, p.sweep, (uint64_t)p.iter, (uint32_t)g_glob, 0);
-        is_mut = u53(r.x, r.y) <= p.beta;  // mutate_or_crossover! main.jl:199-207
-    }
-    const bool de_any = (p.mode == MODE_STEP) && !is_mut;
-    const bool use_base = de_any && p.proposal_kind == 0 && p.iter <= p.burnin;  // crossover.jl:164
-    const bool hist_partners = !TILE && p.partner_kind == 1;
-
-    if (TILE) {
-        if (even) {
-            // LDS-DMA (global_load_lds_dwordx4): 16 B per lane straight into LDS, no VGPR round trip; the destination of
-            // one wave-instruction is a wave-uniform LDS base + lane*16, i.e. exactly a linear copy of the tile.  The
-            // loads stay in flight while the workgroup computes its coins and softmax weights below.
-            const int n16 = (Np * D) >> 1;  // 16-byte pieces
-            const int wave = tid >> 6, lane = tid & 63;
-            for (int c0 = wave * 64; c0 < n16; c0 += 256) {
-                if (c0 + lane < n16)
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void*)(grows + 2 * (size_t)(c0 + lane)),
-                        (__attribute__((address_space(3))) void*)(tile + 2 * (size_t)c0), 16, 0, 0);
-            }
-        } else
-            for (int i = tid; i < Np * D; i += 256) tile[i] = grows[i];
-    }
-    const double* rows = TILE ? (const double*)tile : grows;
-    if (p.fuse_prep) {
-        if (p.Ainv)
-            for (int i = tid; i < d * d; i += 256) ainv_s[i] = p.Ainv[i];
-        for (int i = tid; i < d; i += 256) xb_s[i] = p.xbar[i];
-    }
     // select_base (crossover.jl:282-289) over the partner POOL: the whole group in the synchronous schedule, the fixed
     // half in two_colour -- so nothing a moving particle reads (partners, base row, base weights) can change during
     // the phase, which is what makes the fused accept tail race-free across workgroups.
     const int n_cdf = p.pool_n;
     const double* pw = gw + p.pool_lo;
+    // Order of the prologue: a wave's memory results return in issue order, so the few global reads the prologue itself
+    // consumes (pool weights, A^-1, xbar) are issued FIRST, all at once, and the bulk tile copy after them; the copy
+    // then stays in flight under the softmax prefix sums and the plan stage, none of which touch global memory.
+    const bool maybe_base = p.mode == MODE_STEP && p.proposal_kind == 0 && p.iter <= p.burnin;  // crossover.jl:164
+    const bool ld_ainv = p.fuse_prep && p.Ainv;
+    const int dd = d * d;
+    double w0 = -INFINITY, av[4], xv = 0.0;
+    if (maybe_base && tid < n_cdf) w0 = pw[tid];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) av[k] = (ld_ainv && tid + 256 * k < dd) ? p.Ainv[tid + 256 * k] : 0.0;
+    if (p.fuse_prep && tid < d) xv = p.xbar[tid];
+
+    bool is_mut = false;  // the group's coin, drawn while those loads are in flight
+    if (p.mode == MODE_STEP) {
+        const U4 r = draw_block(p.seed, S_GROUP, p.sweep, (uint64_t)p.iter, (uint32_t)g_glob, 0);
+        is_mut = u53(r.x, r.y) <= p.beta;  // mutate_or_crossover! main.jl:199-207
+    }
+    const bool de_any = (p.mode == MODE_STEP) && !is_mut;
+    const bool use_base = de_any && maybe_base;
+    const bool hist_partners = !TILE && p.partner_kind == 1;
+    DEMC_STAMP(12);  // group coin drawn
+
+    double m = w0;
+    if (maybe_base) {
+        if (tid < n_cdf) cdf[tid] = w0;
+        for (int i = tid + 256; i < n_cdf; i += 256) {
+            const double w = pw[i];
+            cdf[i] = w;
+            m = fmax(m, w);
+        }
+    }
+    if (p.fuse_prep) {
+        if (ld_ainv) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (tid + 256 * k < dd) ainv_s[tid + 256 * k] = av[k];
+            for (int i = tid + 1024; i < dd; i += 256) ainv_s[i] = p.Ainv[i];
+        }
+        if (tid < d) xb_s[tid] = xv;
+        for (int i = tid + 256; i < d; i += 256) xb_s[i] = p.xbar[i];
+    }
+    DEMC_STAMP(14);  // pool weights, A^-1, xbar parked in LDS
+    // The tile holds what this workgroup can read: the partner pool (all partner / base rows come from it) and, when
+    // the moving particles are not pool rows (two_colour), its own slice of them -- two linear pieces of theta.
+    double* own = tile + (size_t)p.pool_n * D;
+    if (TILE) {
+        const double* src[2] = {grows + (size_t)p.pool_lo * D, grows + (size_t)(p.a_lo + q_lo) * D};
+        double* dst[2] = {tile, own};
+        const int cnt[2] = {p.pool_n * D, p.own_in_pool ? 0 : (q_hi - q_lo) * D};
+#pragma unroll
+        for (int piece = 0; piece < 2; ++piece) {
+            if (even) {
+                // LDS-DMA (global_load_lds_dwordx4): 16 B per lane straight into LDS, no VGPR round trip; the destination
+                // of one wave-instruction is a wave-uniform LDS base + lane*16, i.e. exactly a linear copy.
+                const int n16 = cnt[piece] >> 1;  // 16-byte pieces
+                const int wave = tid >> 6, lane = tid & 63;
+                for (int c0 = wave * 64; c0 < n16; c0 += 256) {
+                    if (c0 + lane < n16) lds_dma16(src[piece] + 2 * (size_t)(c0 + lane), dst[piece] + 2 * (size_t)c0);
+                }
+            } else
+                for (int i = tid; i < cnt[piece]; i += 256) dst[piece][i] = src[piece][i];
+        }
+    }
+    DEMC_STAMP(15);  // tile copy issued
+    // indexed by the row's position in its group; only pool rows (and, through pt below, own rows) are ever touched
+    const double* rows = TILE ? (const double*)tile - (ptrdiff_t)p.pool_lo * D : grows;
     if (use_base) {
         // stabilised: e_j = exp(w_j - max w); cumulative weights in a fixed two-level order (same as the oracle):
         // sequential inside chunks of 16, sequential over the chunk totals, cdf[i] = offset[chunk] + prefix[i]
-        double m = -INFINITY;
-        for (int i = tid; i < n_cdf; i += 256) m = fmax(m, pw[i]);
         for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
         if ((tid & 63) == 0) s_red[tid >> 6] = m;
-        __syncthreads();
+        lds_barrier();
         m = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
         const int n_chunk = (n_cdf + 15) >> 4;
         double* ctot = cdf + Np;
-        for (int i = tid; i < n_cdf; i += 256) cdf[i] = exp(pw[i] - m);
-        __syncthreads();
+        for (int i = tid; i < n_cdf; i += 256) cdf[i] = exp(cdf[i] - m);  // each thread: the entries it parked above
+        lds_barrier();
         for (int c = tid; c < n_chunk; c += 256) {
+            // 16 reads up front, then the dependent adds in registers (padding with 0.0 leaves a running sum unchanged)
+            double v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = (c * 16 + k < n_cdf) ? cdf[c * 16 + k] : 0.0;
             double pre = 0.0;
-            const int i1 = (c * 16 + 16 < n_cdf) ? c * 16 + 16 : n_cdf;
-            for (int i = c * 16; i < i1; ++i) {
-                pre += cdf[i];
-                cdf[i] = pre;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                pre += v[k];
+                v[k] = pre;
             }
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (c * 16 + k < n_cdf) cdf[c * 16 + k] = v[k];
             ctot[c] = pre;
         }
-        __syncthreads();
-        if (tid == 0) {
+        lds_barrier();
+        // offset of a chunk = the chunk totals before it, summed left to right; every thread folds the totals it needs
+        // itself (LDS broadcast reads) instead of waiting for one lane to scan them
+        for (int i = tid; i < n_cdf; i += 256) {
+            const int ci = i >> 4;
             double off = 0.0;
-            for (int c = 0; c < n_chunk; ++c) {
-                const double t = ctot[c];
-                ctot[c] = off;
-                off = off + t;
-            }
+            for (int c = 0; c < ci; ++c) off = off + ctot[c];
+            cdf[i] = off + cdf[i];
         }
-        __syncthreads();
-        for (int i = tid; i < n_cdf; i += 256) cdf[i] = ctot[i >> 4] + cdf[i];
-        __syncthreads();
+        lds_barrier();
         if (tid == 0) s_total = cdf[n_cdf - 1];
     }
-    DEMC_STAMP(0);  // prologue done except for the tile
+    DEMC_STAMP(0);  // softmax prefix sums done (tile still in flight)
+
+    const int n_pass = (q_hi - q_lo + ppp - 1) / ppp;
+    const int nblk = hist_partners ? 6 : 4;
+    // ---- plan stage.  Everything about a crossover proposal that is one value per PARTICLE -- the snooker coin, the
+    // partner / base indices, the gammas, the accept uniform -- is computed here once, four lanes per particle (lane b of
+    // the quad evaluates Philox block b; quad_perm hands the blocks round), and parked in LDS.  The passes below, where
+    // lpp lanes share a particle, then read it back instead of recomputing it lpp times over.
+    const bool planned = TILE && p.plan && de_any && lpp >= 4;
+    if (planned) {
+        const int n_loc = q_hi - q_lo;
+        for (int base = 0; base < n_loc; base += 64) {
+            const int ql = base + (tid >> 2), blk = tid & 3;
+            const bool ok = ql < n_loc;
+            const int pl = p.a_lo + q_lo + (ok ? ql : 0);
+            const uint32_t eslot = (uint32_t)g_glob * (uint32_t)Np + (uint32_t)pl;
+            const U4 mine = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)blk);
+            const U4 r0 = bcast_u4<0>(mine, 4, 0), ri = bcast_u4<1>(mine, 4, 0), rg = bcast_u4<2>(mine, 4, 0),
+                     ra = bcast_u4<3>(mine, 4, 0);
+            const double u_snk = u53(r0.x, r0.y), u_base = u53(r0.z, r0.w);
+            const double u_g1 = u53(rg.x, rg.y), u_g2 = u53(rg.z, rg.w);
+            const bool snooker = u_snk <= p.theta_snooker;  // crossover.jl:31
+            int i0, i1, i2 = -1;
+            double g1, g2 = 0.0;
+            if (snooker) {
+                uint32_t a, b, c;  // snooker_update! draws 3 from the whole pool (crossover.jl:241)
+                pick_triple(ri.x, ri.y, ri.z, (uint32_t)p.pool_n, a, b, c);
+                i0 = (int)a + p.pool_lo; i1 = (int)b + p.pool_lo; i2 = (int)c + p.pool_lo;
+                g1 = 1.2 + (2.2 - 1.2) * u_g1;  // crossover.jl:249
+            } else {
+                uint32_t a, b;
+                if (p.exclude_self) {  // setdiff(group, [Pt]) crossover.jl:158
+                    pick_pair(ri.x, ri.y, (uint32_t)p.pool_n - 1, a, b);
+                    const uint32_t t = (uint32_t)(pl - p.pool_lo);
+                    a += (a >= t); b += (b >= t);
+                } else
+                    pick_pair(ri.x, ri.y, (uint32_t)p.pool_n, a, b);
+                i0 = (int)a + p.pool_lo; i1 = (int)b + p.pool_lo;
+                if (p.proposal_kind == 0) {
+                    g1 = 0.5 + (1.0 - 0.5) * u_g1;  // crossover.jl:162
+                    if (use_base) {
+                        g2 = 0.5 + (1.0 - 0.5) * u_g2;
+                        const double total = cdf[n_cdf - 1];
+                        int b2;
+                        if (!(total > 0.0) || !(total < INFINITY)) {
+                            b2 = (int)(u_base * n_cdf);
+                            b2 = b2 < n_cdf ? b2 : n_cdf - 1;
+                        } else {  // first i with cdf[i] >= t, else last (cdf is monotone): binary search
+                            const double t = u_base * total;
+                            int lo = 0, hi = n_cdf - 1;
+                            while (lo < hi) {
+                                const int mid = (lo + hi) >> 1;
+                                if (cdf[mid] >= t) hi = mid; else lo = mid + 1;
+                            }
+                            b2 = lo;
+                        }
+                        i2 = b2 + p.pool_lo;
+                    }
+                } else if (p.proposal_kind == 1)
+                    g1 = 2.38;  // crossover.jl:191
+                else
+                    g1 = 2.38 / sqrt(2.0 * (double)D);  // crossover.jl:218
+            }
+            if (ok && blk == 0) {
+                plan_i[4 * ql + 0] = snooker ? 1 : 0;
+                plan_i[4 * ql + 1] = i0;
+                plan_i[4 * ql + 2] = i1;
+                plan_i[4 * ql + 3] = i2;
+                plan_d[3 * ql + 0] = g1;
+                plan_d[3 * ql + 1] = g2;
+                plan_d[3 * ql + 2] = u53(ra.x, ra.y);
+            }
+        }
+    }
+    DEMC_STAMP(11);  // this wave's share of the plan written
     if (TILE && even) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA pieces have landed
     __syncthreads();
-    DEMC_STAMP(1);  // tile visible
+    DEMC_STAMP(1);  // tile and plan visible
 
     const int sub = tid / lpp, sl = tid % lpp;
     const int sub_base = (tid & 63) & ~(lpp - 1);  // lane 0 of this sub-group inside its wave
-    const int per_split = (p.n_act + p.n_split - 1) / p.n_split;
-    const int q_lo = sp * per_split;
-    const int q_hi = (q_lo + per_split < p.n_act) ? q_lo + per_split : p.n_act;
-    const int n_pass = (q_hi - q_lo + ppp - 1) / ppp;
     const double eps = p.eps, eps2 = p.eps - (-p.eps);
-    const int nblk = hist_partners ? 6 : 4;
     // MFMA preparation (prep_mfma): y[4 particles x d] = theta~[4 x d] . A^-1[d x d] as one 16x16x4 tile product per
     // 16 columns; the wave's four sub-groups are rows 0..3 of the A operand (rows 4..15 are zero), and the C layout
     // (row = (lane>>4) + 4r, col = lane&15) hands every lane the y of ITS OWN particle at columns sl and sl+16 in
@@ -502,18 +639,19 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             }
     }
 
+    DEMC_STAMP(13);  // A^-1 fragments in registers
     for (int pass = 0; pass < n_pass; ++pass) {
         const int q = q_lo + pass * ppp + sub;
         const bool valid = q < q_hi;
         const int pl = p.a_lo + (valid ? q : q_lo);
         const size_t slot = (size_t)g * Np + pl;
         const uint32_t eslot = (uint32_t)g_glob * (uint32_t)Np + (uint32_t)pl;
-        const double* pt = rows + (size_t)pl * D;
+        const double* pt = (TILE && !p.own_in_pool) ? own + (size_t)(valid ? q - q_lo : 0) * D : rows + (size_t)pl * D;
 
         // per-particle Philox blocks: lane b of the sub-group evaluates block b (when the sub-group is wide enough)
-        if (pass == 1 || n_pass == 1) DEMC_STAMP(2);  // top of the steady-state pass
+        if (pass == DEMC_STAMP_PASS || n_pass == 1) DEMC_STAMP(2);  // top of the steady-state pass
         U4 r0 = {0, 0, 0, 0}, ri = r0, rg = r0, ra = r0, h4 = r0, h5 = r0;
-        if (p.mode == MODE_STEP) {
+        if (p.mode == MODE_STEP && !planned) {
             if (lpp >= nblk && lpp <= 64) {
                 const U4 mine = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)(sl < nblk ? sl : 0));
                 r0 = bcast_u4<0>(mine, lpp, sub_base);
@@ -536,13 +674,38 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             }
         }
 
-        if (pass == 1 || n_pass == 1) DEMC_STAMP(3);  // particle Philox blocks handed out
+        if (pass == DEMC_STAMP_PASS || n_pass == 1) DEMC_STAMP(3);  // particle Philox blocks handed out
         int kind = 3;  // 0 DE, 1 snooker, 2 mutation, 3 identity
         int i0 = -1, i1 = -1, i2 = -1;
         const double *Pa = pt, *Pb2 = pt, *Pc = pt, *Pbase = pt;
         double g1 = 0.0, g2 = 0.0, cm = 0.0, cn = 0.0;
         bool base_on = false;
-        if (p.mode == MODE_STEP) {
+        double u_acc = u53(ra.x, ra.y);
+        if (planned) {
+            const int ql = valid ? q - q_lo : 0;
+            kind = plan_i[4 * ql + 0];
+            i0 = plan_i[4 * ql + 1]; i1 = plan_i[4 * ql + 2]; i2 = plan_i[4 * ql + 3];
+            g1 = plan_d[3 * ql + 0]; g2 = plan_d[3 * ql + 1]; u_acc = plan_d[3 * ql + 2];
+            Pa = rows + (size_t)i0 * D; Pb2 = rows + (size_t)i1 * D;
+            if (kind == 1) {
+                Pc = rows + (size_t)i2 * D;
+                // project(Pm,Pd), project(Pn,Pd): dots over all scalars (utilities.jl:239-246)
+                double vm = 0.0, vn = 0.0, vd = 0.0;
+                for (int k = sl; 2 * k < D; k += lpp)
+                    for (int e = 0; e < 2; ++e) {
+                        const int j = 2 * k + e;
+                        if (j < D) {
+                            const double dj = pt[j] - Pa[j];
+                            vm += Pb2[j] * dj; vn += Pc[j] * dj; vd += dj * dj;
+                        }
+                    }
+                vm = group_sum(vm, lpp, s_gsum); vn = group_sum(vn, lpp, s_gsum); vd = group_sum(vd, lpp, s_gsum);
+                cm = vm / vd; cn = vn / vd;
+            } else if (i2 >= 0) {
+                Pbase = rows + (size_t)i2 * D;
+                base_on = true;
+            }
+        } else if (p.mode == MODE_STEP) {
             if (is_mut)
                 kind = 2;
             else {
@@ -686,7 +849,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             }
         };
 
-        if (pass == 1 || n_pass == 1) DEMC_STAMP(4);  // indices, gammas, base picked
+        if (pass == DEMC_STAMP_PASS || n_pass == 1) DEMC_STAMP(4);  // indices, gammas, base picked
         int oob = 0;
         double prior = 0.0, s1 = 0.0, s2 = 0.0;
         int ref_cached = -1;
@@ -734,7 +897,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
                 if (has1) scr[sub * scr_stride + j0 + 1] = v1;
             }
         }
-        if (pass == 1 || n_pass == 1) DEMC_STAMP(5);  // per-dimension loop done
+        if (pass == DEMC_STAMP_PASS || n_pass == 1) DEMC_STAMP(5);  // per-dimension loop done
         prior = group_sum(prior, lpp, s_gsum);
         oob = group_sum(oob, lpp, s_gsumi);
         double adj = 0.0;
@@ -744,7 +907,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             adj = (double)(D - 1) * (0.5 * log(s1) - 0.5 * log(s2));
         }
 
-        if (pass == 1 || n_pass == 1) DEMC_STAMP(6);  // reductions done
+        if (pass == DEMC_STAMP_PASS || n_pass == 1) DEMC_STAMP(6);  // reductions done
         double aux = 0.0, S = 0.0;
         if (p.fuse_prep) {
             // y = A^-1 theta' (FULL) or theta' (ISO) for the data dimensions; each lane owns output columns {2k, 2k+1}.
@@ -810,7 +973,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             S = group_sum(S, lpp, s_gsum);
         }
 
-        if (pass == 1 || n_pass == 1) DEMC_STAMP(7);  // MvNormal preparation done
+        if (pass == DEMC_STAMP_PASS || n_pass == 1) DEMC_STAMP(7);  // MvNormal preparation done
         if (p.fuse_obs) {
             // small-N scalar-data families: the sub-group visits every observation itself (lanes stride over them)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -839,7 +1002,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             continue;
         }
 
-        if (pass == 1 || n_pass == 1) DEMC_STAMP(8);  // in-kernel observation loop done
+        if (pass == DEMC_STAMP_PASS || n_pass == 1) DEMC_STAMP(8);  // in-kernel observation loop done
         // ---- fused tail: compute_posterior! + mh_update! + store_samples! for this particle ----
         const double w = gw[pl];
         const double sg = (p.family == FAM_MVN_ISO) ? scr[sub * scr_stride + d]
@@ -849,7 +1012,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             wp = oob ? (p.update_kind == 1 ? -INFINITY : INFINITY) : loglike_from_stats(p, S, aux, sg);
         else
             wp = oob ? -INFINITY : prior + loglike_from_stats(p, S, aux, sg);
-        const int acc = decide(p, ra, wp, w, adj);  // every lane of the sub-group holds the same inputs
+        const int acc = decide(p, u_acc, wp, w, adj);  // every lane of the sub-group holds the same inputs
         if (sl == 0 && valid) {
             if (acc) p.weight[slot] = wp;
             if (p.trace) {
@@ -887,7 +1050,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();  // scratch rows are reused by the same sub-group in the next pass
-        if (pass == 1 || n_pass == 1) DEMC_STAMP(9);  // accept + row moves done
+        if (pass == DEMC_STAMP_PASS || n_pass == 1) DEMC_STAMP(9);  // accept + row moves done
     }
     DEMC_STAMP(10);  // kernel end
 }
@@ -1088,7 +1251,7 @@ __global__ __launch_bounds__(256) void k_accept_store(KParams p) {
             wp = oob ? -INFINITY : p.prop_prior[slot] + finalize_loglike(p, slot, s_sum);
         const uint32_t eslot = (uint32_t)(p.group_offset + g) * (uint32_t)p.Np + (uint32_t)pl;
         const U4 ra = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 3);
-        acc = decide(p, ra, wp, w, p.prop_adj[slot]);  // mh_update! / maximize! / minimize!
+        acc = decide(p, u53(ra.x, ra.y), wp, w, p.prop_adj[slot]);  // mh_update! / maximize! / minimize!
         w_new = acc ? wp : w;
         if (acc) p.weight[slot] = wp;
         if (p.trace) {

@@ -12,7 +12,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, "differentialevolutionmcmc.jl_amd", "csrc")
-subprocess.check_call(["make", "-C", csrc, "-s", "STAMPS=1", "OUT=../libdemc_hip_stamps.so"])
+subprocess.check_call(["make", "-B", "-C", csrc, "-s", "STAMPS=1", "OUT=../libdemc_hip_stamps.so"] +
+                      (["STAMP_PASS=" + os.environ["STAMP_PASS"]] if "STAMP_PASS" in os.environ else []))
 import demc_amd  # noqa: E402
 demc_amd._ffi.LIB_PATH = os.path.join(ROOT, "differentialevolutionmcmc.jl_amd", "libdemc_hip_stamps.so")
 import bench  # noqa: E402
@@ -31,9 +32,10 @@ bench.configure(eng, prob, a.dim)
 eng.set_state(bench.init_theta(a.n_groups * a.Np, a.dim, 0))
 eng.step(1, 30)
 n_wg = min(512, (a.n_groups * a.Np) // 16)
-t = eng.get_trace()["w_prop"][: n_wg * 16].reshape(n_wg, 16)[:, :11]
-t = t[t[:, 10] > 0]
-names = ["prologue (coin, softmax prefix sums; tile in flight)", "tile landed (LDS-DMA wait + barrier)",
+full = eng.get_trace()["w_prop"][: n_wg * 16].reshape(n_wg, 16)
+full = full[full[:, 10] > 0]
+t = full[:, :11]
+names = ["softmax prefix sums done (tile in flight)", "plan written; tile landed (LDS-DMA wait + barrier)",
          "top of steady-state pass (passes before it)", "particle Philox blocks + broadcast", "indices / gammas / base pick",
          "per-dimension loop (noise, proposal, bounds, prior)", "sub-group reductions", "MvNormal preparation",
          "in-kernel observation loop", "accept + row moves", "kernel end (remaining passes)"]
@@ -43,3 +45,7 @@ print(f"{len(t)} workgroups; cycles since kernel start (median), and the step")
 for n, m in zip(names, med):
     print(f"  {n:55s} {m:9.0f}  (+{m - prev:7.0f})")
     prev = m
+ex = np.median(full[:, [11, 13]], 0)
+print(f"  also: plan written (before the tile wait) {ex[0]:.0f}; A^-1 fragments in registers (before pass 0) {ex[1]:.0f}")
+pro = np.median(full[:, [12, 14, 15]], 0)
+print(f"  inside the prologue: group coin {pro[0]:.0f}; weights / A^-1 parked {pro[1]:.0f}; tile copy issued {pro[2]:.0f}")
