@@ -18,8 +18,8 @@ EXPORTS = [
     "demc_version", "demc_create", "demc_destroy", "demc_last_error", "demc_set_stream", "demc_set_model",
     "demc_set_model_source", "demc_set_priors", "demc_set_bounds", "demc_set_blocks", "demc_set_state", "demc_get_state",
     "demc_set_history_rows", "demc_get_history", "demc_export_chains", "demc_step", "demc_update", "demc_migration_due",
-    "demc_migration_pack", "demc_migration_apply", "demc_logpost", "demc_get_trace", "demc_timing_enable",
-    "demc_timing_read",
+    "demc_migration_pack", "demc_migration_apply", "demc_apply_migration", "demc_get_weights", "demc_logpost",
+    "demc_get_trace", "demc_timing_enable", "demc_timing_read",
 ]
 
 
@@ -201,6 +201,20 @@ class HipEngine:
         i = np.empty(self.P, np.int64)
         self._ck(self.L.demc_get_state(self.h, _d(th), _d(w), i.ctypes.data_as(_lp)))
         return th, w, i
+
+    def get_weights(self):
+        w = np.empty(self.P)
+        self._ck(self.L.demc_get_weights(self.h, _d(w)))
+        return w
+
+    def apply_migration(self, src_slot, dst_slot):
+        """shift_particles! with a host-drawn plan (migration.jl:84-91): slot dst[k] receives what slot src[k] held"""
+        src = np.ascontiguousarray(src_slot, dtype=np.int32)
+        dst = np.ascontiguousarray(dst_slot, dtype=np.int32)
+        if src.shape != dst.shape or src.ndim != 1:
+            raise ValueError("src_slot and dst_slot must be 1-D and of equal length")
+        _li = C.POINTER(C.c_int32)
+        self._ck(self.L.demc_apply_migration(self.h, src.ctypes.data_as(_li), dst.ctypes.data_as(_li), len(src)))
 
     def set_history_rows(self, row0, rows):
         rows = np.ascontiguousarray(rows, dtype=np.float64).reshape(-1, self.P, self.D)

@@ -939,6 +939,47 @@ int32_t demc_migration_apply(demc_handle* h, int64_t iter, const double* dev_all
     return DEMC_OK;
 }
 
+int32_t demc_apply_migration(demc_handle* h, const int32_t* src_slot, const int32_t* dst_slot, int32_t n) {
+    if (!h || n < 0 || (n > 0 && (!src_slot || !dst_slot))) return DEMC_EINVAL;
+    USE_DEVICE(h);
+    if (n == 0) return DEMC_OK;
+    std::vector<char> seen((size_t)h->P, 0);
+    for (int k = 0; k < n; ++k) {
+        if (src_slot[k] < 0 || src_slot[k] >= h->P || dst_slot[k] < 0 || dst_slot[k] >= h->P)
+            return fail(h, DEMC_EINVAL, "migration slot out of range");
+        if (seen[(size_t)dst_slot[k]]) return fail(h, DEMC_EINVAL, "migration destination slots must be distinct");
+        seen[(size_t)dst_slot[k]] = 1;
+    }
+    const size_t W = (size_t)h->c.D + 2;
+    int* d_slots = nullptr;
+    double* d_stage = nullptr;
+    HIPCHK(hipMalloc(&d_slots, 2 * (size_t)n * sizeof(int)));
+    if (hipMalloc(&d_stage, (size_t)n * W * sizeof(double)) != hipSuccess) {
+        hipFree(d_slots);
+        return fail(h, DEMC_ENOMEM, "out of device memory for the migration staging rows");
+    }
+    int rc = DEMC_OK;
+    hipError_t e = hipMemcpyAsync(d_slots, src_slot, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_slots + n, dst_slot, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        KParams k = base_params(h);
+        const unsigned wgs = (unsigned)(((size_t)n * W + 255) / 256);
+        hipLaunchKernelGGL(k_slot_moves, dim3(wgs), dim3(256), 0, h->stream, k, d_slots, d_stage, n, 0);
+        hipLaunchKernelGGL(k_slot_moves, dim3(wgs), dim3(256), 0, h->stream, k, d_slots + n, d_stage, n, 1);
+        e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    if (e != hipSuccess) rc = fail(h, DEMC_EHIP, hipGetErrorString(e));
+    hipFree(d_slots);
+    hipFree(d_stage);
+    return rc;
+}
+
+int32_t demc_get_weights(demc_handle* h, double* weight) {
+    if (!h || !weight) return DEMC_EINVAL;
+    return demc_get_state(h, nullptr, weight, nullptr);
+}
+
 int32_t demc_logpost(demc_handle* h, const double* theta, int64_t n, double* out) {
     if (!h || !theta || !out || n < 0) return DEMC_EINVAL;
     USE_DEVICE(h);

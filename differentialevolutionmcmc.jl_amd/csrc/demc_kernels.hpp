@@ -1389,6 +1389,25 @@ __global__ __launch_bounds__(256) void k_mig_pack(KParams p, double* __restrict_
     for (int k = tid; k < D; k += 256) o[1 + k] = p.theta[slot * D + k];
 }
 
+// demc_apply_migration: slot moves planned by the host.  Two launches: gather the source rows into a staging buffer
+// ([n][D+2]: theta, weight, id), then scatter them to the destination slots -- reads complete before any write.
+__global__ __launch_bounds__(256) void k_slot_moves(KParams p, const int* __restrict__ slots, double* __restrict__ stage, int n,
+                                                    int scatter) {
+    const int D = p.D, W = D + 2;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)n * W) return;
+    const int k = (int)(e / W), j = (int)(e % W);
+    const size_t slot = (size_t)slots[k];
+    if (!scatter)
+        stage[e] = j < D ? p.theta[slot * D + j] : j == D ? p.weight[slot] : __longlong_as_double(p.id[slot]);
+    else if (j < D)
+        p.theta[slot * D + j] = stage[e];
+    else if (j == D)
+        p.weight[slot] = stage[e];
+    else
+        p.id[slot] = __double_as_longlong(stage[e]);
+}
+
 __global__ __launch_bounds__(256) void k_mig_apply(KParams p, const double* __restrict__ all_rows, int n_groups_total) {
     extern __shared__ int perm[];  // [n_groups_total]
     __shared__ int s_ns;

@@ -185,6 +185,14 @@ int32_t demc_update(demc_handle* h, int64_t iter0, int32_t n_iters);
 int32_t demc_migration_due(const demc_config* cfg, int64_t iter);
 int32_t demc_migration_pack(demc_handle* h, int64_t iter, double* dev_rows);
 int32_t demc_migration_apply(demc_handle* h, int64_t iter, const double* dev_all_rows);
+/* shift_particles! (migration.jl:84-91) with a HOST-drawn plan: for every k, slot dst_slot[k] receives the row
+ * (theta, weight, id) that slot src_slot[k] held BEFORE the call -- all reads precede all writes, so a cycle is a
+ * rotation.  For a caller that keeps migration!'s own random choices (select_groups / select_particles,
+ * migration.jl:31-35, :48-53) on the host, e.g. the Julia side replaying its task-local RNG, and drives the rest
+ * through demc_update.  Slots are local (0 <= slot < n_groups*Np); dst slots must be distinct.  Arrays are host memory. */
+int32_t demc_apply_migration(demc_handle* h, const int32_t* src_slot, const int32_t* dst_slot, int32_t n);
+/* the weights alone ([P] doubles): what select_particles' inverse-weight draw needs on the host (migration.jl:64-70) */
+int32_t demc_get_weights(demc_handle* h, double* weight);
 
 /* compute_posterior! / evaluate_fun! for n arbitrary host rows [n][D] (utilities.jl:92-120) */
 int32_t demc_logpost(demc_handle* h, const double* theta, int64_t n, double* out);

@@ -398,3 +398,32 @@ def test_device_chain_export_equals_host_rekey():
     eng._ck(eng.L.demc_export_chains(eng.h, 2, n, 0, julia.ctypes.data_as(C.POINTER(C.c_double))))
     assert np.array_equal(np.transpose(julia, (2, 1, 0)), exp)
     eng.close()
+
+
+def test_host_planned_migration_moves_whole_rows():
+    """demc_apply_migration = shift_particles! (migration.jl:84-91) with the plan drawn by the caller: dst[k] receives the
+    row (theta, weight, id) src[k] held before the call; a cycle is a rotation; everything else is untouched (bit-exact)."""
+    rng = np.random.default_rng(5)
+    G, Np, Dm = 6, 8, 5
+    eng = D.HipEngine(n_groups=G, Np=Np, D=Dm, n_rows=0, store_history=0, seed=3)
+    th0 = rng.standard_normal((G * Np, Dm))
+    w0 = rng.standard_normal(G * Np)
+    id0 = rng.permutation(G * Np).astype(np.int64)
+    eng.set_state(th0, w0, id0)
+    # the reference's plan: one particle from each of 4 selected groups, shifted circularly (utility_tests.jl:149-154)
+    groups = rng.choice(G, 4, replace=False)
+    slots = np.array([g * Np + rng.integers(Np) for g in groups], np.int32)
+    eng.apply_migration(np.roll(slots, 1), slots)
+    th, w, ids = eng.get_state()
+    eth, ew, eid = th0.copy(), w0.copy(), id0.copy()
+    eth[slots], ew[slots], eid[slots] = th0[np.roll(slots, 1)], w0[np.roll(slots, 1)], id0[np.roll(slots, 1)]
+    assert np.array_equal(th, eth) and np.array_equal(w, ew) and np.array_equal(ids, eid)
+    assert sorted(ids) == sorted(id0), "a migration permutes particles, it never duplicates one"
+    assert np.array_equal(eng.get_weights(), ew)
+    eng.apply_migration([], [])  # empty plan: nothing to do
+    with pytest.raises(D.DemcError):
+        eng.apply_migration([0, 1], [2, 2])  # two rows into one slot
+    with pytest.raises(D.DemcError):
+        eng.apply_migration([0], [G * Np])  # out of range
+    assert np.array_equal(eng.get_state()[0], eth), "a rejected plan must leave the state untouched"
+    eng.close()
