@@ -294,6 +294,15 @@ int launch_loglike(demc_handle* h, KParams& k) {
 
 bool is_mvn(int fam) { return fam == FAM_MVN_FULL || fam == FAM_MVN_ISO; }
 
+// the K1 instance for (tile in LDS?, fused tail)
+using K1Fn = void (*)(KParams);
+K1Fn k1_instance(bool tile, int tail) {
+    static const K1Fn tab[2][4] = {
+        {k_propose<false, TAIL_NONE>, k_propose<false, TAIL_PREP>, k_propose<false, TAIL_PREP_MFMA>, k_propose<false, TAIL_OBS>},
+        {k_propose<true, TAIL_NONE>, k_propose<true, TAIL_PREP>, k_propose<true, TAIL_PREP_MFMA>, k_propose<true, TAIL_OBS>}};
+    return tab[tile ? 1 : 0][tail];
+}
+
 int launch_phase(demc_handle* h, KParams& k) {
     const long long n_prop = (long long)k.n_groups * k.n_act;
     if (n_prop == 0) return DEMC_OK;
@@ -332,11 +341,9 @@ int launch_phase(demc_handle* h, KParams& k) {
     k.plan = (tile && k.mode == MODE_STEP && k.lpp >= 4 && k.lpp <= 64 && lds_tile + plan_bytes <= kMaxDynLds) ? 1 : 0;
     if (const char* e = std::getenv("DEMC_K1_PLAN")) k.plan = k.plan && e[0] == '1';  // A/B experiments
     tick(h, 0, true);
-    if (tile)
-        hipLaunchKernelGGL(k_propose<true>, dim3(k.n_groups * n_split), dim3(256), lds_tile + (k.plan ? plan_bytes : 0),
-                           h->stream, k);
-    else
-        hipLaunchKernelGGL(k_propose<false>, dim3(k.n_groups * n_split), dim3(256), h->k1_lds - h->k1_tile_bytes, h->stream, k);
+    const int tail = k.prep_mfma ? TAIL_PREP_MFMA : k.fuse_prep ? TAIL_PREP : k.fuse_obs ? TAIL_OBS : TAIL_NONE;
+    const size_t lds = tile ? lds_tile + (k.plan ? plan_bytes : 0) : h->k1_lds - h->k1_tile_bytes;
+    hipLaunchKernelGGL(k1_instance(tile, tail), dim3(k.n_groups * n_split), dim3(256), lds, h->stream, k);
     tick(h, 0, false);
     if (k.fuse_accept) return DEMC_OK;
     int rc = launch_loglike(h, k);
@@ -405,8 +412,10 @@ int size_k1_lds(demc_handle* h) {
     if (h->k1_lds > kMaxDynLds) return fail(h, DEMC_EINVAL, "K1 LDS budget exceeded (Np too large for this D)");
     // the attribute is per function, not per handle: always raise it to the same ceiling so that handles of different
     // sizes in one process do not lower each other's limit
-    HIPCHK(hipFuncSetAttribute((const void*)k_propose<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
-    HIPCHK(hipFuncSetAttribute((const void*)k_propose<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
+    for (int t = 0; t < 2; ++t)
+        for (int tail = 0; tail < 4; ++tail)
+            HIPCHK(hipFuncSetAttribute((const void*)k1_instance(t != 0, tail), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)kMaxDynLds));
     HIPCHK(hipFuncSetAttribute((const void*)k_mig_pack, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
     return DEMC_OK;
 }

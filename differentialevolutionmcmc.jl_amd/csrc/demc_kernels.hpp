@@ -400,8 +400,14 @@ __device__ inline void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <bool TILE>
+// TAIL selects the fused tail compiled into the instance (the host passes the matching flags in KParams): registers
+// are allocated for the worst path of a kernel, so the tails a model cannot take are kept out of its instance.
+enum K1Tail : int { TAIL_NONE = 0, TAIL_PREP = 1, TAIL_PREP_MFMA = 2, TAIL_OBS = 3 };
+template <bool TILE, int TAIL>
 __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
+    constexpr bool FUSE_PREP = TAIL == TAIL_PREP || TAIL == TAIL_PREP_MFMA;
+    constexpr bool PREP_MFMA = TAIL == TAIL_PREP_MFMA;
+    constexpr bool FUSE_OBS = TAIL == TAIL_OBS;
     extern __shared__ double lds[];
     DEMC_STAMP_INIT();
     __shared__ double s_red[4];
@@ -425,9 +431,9 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     double* cdf = tile + (TILE ? (size_t)p.tile_rows * D : 0);
     double* ainv_s = cdf + Np + ((Np + 15) >> 4);
     const int scr_stride = D + 2;
-    double* xb_s = ainv_s + ((p.fuse_prep && p.Ainv) ? (size_t)d * d : 0);
-    double* scr = xb_s + (p.fuse_prep ? d : 0);
-    const bool use_scr = p.fuse_prep || p.fuse_obs;  // theta' of the pass kept in LDS for the fused tails
+    double* xb_s = ainv_s + ((FUSE_PREP && p.Ainv) ? (size_t)d * d : 0);
+    double* scr = xb_s + (FUSE_PREP ? d : 0);
+    const bool use_scr = FUSE_PREP || FUSE_OBS;  // theta' of the pass kept in LDS for the fused tails
     double* plan_d = scr + p.scr_doubles;                              // [per_split][3]: g1, g2, accept uniform
     int* plan_i = reinterpret_cast<int*>(plan_d + 3 * (size_t)per_split);  // [per_split][4]
 
@@ -440,13 +446,13 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     // consumes (pool weights, A^-1, xbar) are issued FIRST, all at once, and the bulk tile copy after them; the copy
     // then stays in flight under the softmax prefix sums and the plan stage, none of which touch global memory.
     const bool maybe_base = p.mode == MODE_STEP && p.proposal_kind == 0 && p.iter <= p.burnin;  // crossover.jl:164
-    const bool ld_ainv = p.fuse_prep && p.Ainv;
+    const bool ld_ainv = FUSE_PREP && p.Ainv;
     const int dd = d * d;
     double w0 = -INFINITY, av[4], xv = 0.0;
     if (maybe_base && tid < n_cdf) w0 = pw[tid];
 #pragma unroll
     for (int k = 0; k < 4; ++k) av[k] = (ld_ainv && tid + 256 * k < dd) ? p.Ainv[tid + 256 * k] : 0.0;
-    if (p.fuse_prep && tid < d) xv = p.xbar[tid];
+    if (FUSE_PREP && tid < d) xv = p.xbar[tid];
 
     bool is_mut = false;  // the group's coin, drawn while those loads are in flight
     if (p.mode == MODE_STEP) {
@@ -467,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             m = fmax(m, w);
         }
     }
-    if (p.fuse_prep) {
+    if (FUSE_PREP) {
         if (ld_ainv) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -628,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     // (row = (lane>>4) + 4r, col = lane&15) hands every lane the y of ITS OWN particle at columns sl and sl+16 in
     // register r = 0.  B fragments (A^-1, lane: k = 4ks + (lane>>4), col = 16nt + (lane&15)) are loaded once per workgroup.
     double bfrag[2][8];
-    if (p.prep_mfma) {
+    if (PREP_MFMA) {
         const int kq = (tid & 63) >> 4, col = tid & 15;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -909,7 +915,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
 
         if (pass == DEMC_STAMP_PASS || n_pass == 1) DEMC_STAMP(6);  // reductions done
         double aux = 0.0, S = 0.0;
-        if (p.fuse_prep) {
+        if (FUSE_PREP) {
             // y = A^-1 theta' (FULL) or theta' (ISO) for the data dimensions; each lane owns output columns {2k, 2k+1}.
             // A scratch row is written and read by ONE sub-group, which lives inside one wave: LDS operations of a
             // wave execute in order, so only the compiler must be kept from reordering them.
@@ -917,7 +923,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             __builtin_amdgcn_wave_barrier();
             const double* th = scr + sub * scr_stride;
             // centred proposal mu~ = theta' - xbar (the data were centred the same way at demc_set_model)
-            if (p.prep_mfma) {
+            if (PREP_MFMA) {
                 const int lane = tid & 63, kq = lane >> 4, row = lane & 15;
                 const double* trow = scr + ((tid >> 6) * 4 + (row & 3)) * scr_stride;  // rows 0..3 = this wave's particles
                 d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
@@ -967,14 +973,14 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
                     if (c1 < p.dpad) p.Ypad[slot * p.dpad + c1] = (c1 < d) ? y1 : 0.0;
                 }
             }
-            if (!p.sx && valid && !p.prep_mfma)  // zero the k-step padding beyond d
+            if (!p.sx && valid && !PREP_MFMA)  // zero the k-step padding beyond d
                 for (int c = 2 * ((d + 1) / 2) + sl; c < p.dpad; c += lpp) p.Ypad[slot * p.dpad + c] = 0.0;
             aux = group_sum(aux, lpp, s_gsum);
             S = group_sum(S, lpp, s_gsum);
         }
 
         if (pass == DEMC_STAMP_PASS || n_pass == 1) DEMC_STAMP(7);  // MvNormal preparation done
-        if (p.fuse_obs) {
+        if (FUSE_OBS) {
             // small-N scalar-data families: the sub-group visits every observation itself (lanes stride over them)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -986,7 +992,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
                 p.prop_prior[slot] = prior;
                 p.prop_oob[slot] = oob ? 1 : 0;
                 p.prop_adj[slot] = adj;
-                if (p.fuse_prep) {
+                if (FUSE_PREP) {
                     p.aux[slot] = aux;
                     if (p.sx) p.partial[slot] = S;
                 }
