@@ -519,9 +519,23 @@ int32_t demc_create(const demc_config* cfg, demc_handle** out) {
                 HIPCHK(hipMemcpy(h->id_hist + (size_t)r * P, row.data(), P * sizeof(int), hipMemcpyHostToDevice));
         }
     }
-    // lanes per particle: every lane owns dim pairs {2k,2k+1}
+    // lanes per particle: every lane owns dim pairs {2k,2k+1}, k = sl, sl+lpp, ...  Upper end: one pair per lane (or a
+    // whole workgroup per particle for very long rows).  Several pairs per lane give each lane independent work to
+    // overlap and fewer cross-lane reduction steps, so take the FEWEST lanes (>= 4) that still (i) fill every lane of
+    // a pass with a particle and (ii) leave at least two workgroups per CU; small populations keep the widest split
+    // (measured at D = 32: 256x256 particles -> 4, 128x256 -> 8, 64x128 and below -> 16).
     h->lpp = pow2_ceil((c.D + 1) / 2);
-    if (h->lpp > 64) h->lpp = (c.D >= 2048) ? 256 : 64;  // very long rows: a whole workgroup per particle
+    if (h->lpp > 64) h->lpp = (c.D >= 2048) ? 256 : 64;
+    if (h->lpp <= 64) {
+        const int n_act = (c.schedule == DEMC_SCHED_TWO_COLOUR) ? c.Np / 2 : c.Np;  // moving particles per group and phase
+        for (int l = 4; l < h->lpp; l *= 2) {
+            const int ppp = 256 / l;
+            if (ppp <= n_act && (long long)c.n_groups * ((n_act + ppp - 1) / ppp) >= 512) {
+                h->lpp = l;
+                break;
+            }
+        }
+    }
     if (const char* e = std::getenv("DEMC_LPP")) {  // A/B experiments: fewer lanes per particle = less replicated scalar work
         const int v = std::atoi(e);
         if (v >= 1 && v <= 256 && v != 128 && (v & (v - 1)) == 0 && (v <= h->lpp || v == 256)) h->lpp = v;
