@@ -311,7 +311,7 @@ int launch_phase(demc_handle* h, KParams& k) {
     // K1 tails: MvNormal preparation always; the whole update when the likelihood is O(D^2) given data-only
     // statistics and a phase writes only rows that no other workgroup reads (two_colour, or the identity pass)
     k.fuse_prep = is_mvn(h->family) ? 1 : 0;
-    k.prep_mfma = (h->family == FAM_MVN_FULL && k.lpp == 16 && h->d <= 32) ? 1 : 0;
+    k.prep_mfma = (h->family == FAM_MVN_FULL && k.lpp >= 4 && k.lpp <= 16 && h->d <= 32) ? 1 : 0;
     if (const char* e = std::getenv("DEMC_PREP_MFMA")) k.prep_mfma = k.prep_mfma && e[0] == '1';  // A/B experiments
     k.sx = (k.fuse_prep && suff) ? h->sx : nullptr;
     k.Ainv = (h->family == FAM_MVN_FULL) ? h->Ainv : nullptr;

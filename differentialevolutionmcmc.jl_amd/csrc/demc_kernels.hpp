@@ -629,10 +629,9 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     const int sub = tid / lpp, sl = tid % lpp;
     const int sub_base = (tid & 63) & ~(lpp - 1);  // lane 0 of this sub-group inside its wave
     const double eps = p.eps, eps2 = p.eps - (-p.eps);
-    // MFMA preparation (prep_mfma): y[4 particles x d] = theta~[4 x d] . A^-1[d x d] as one 16x16x4 tile product per
-    // 16 columns; the wave's four sub-groups are rows 0..3 of the A operand (rows 4..15 are zero), and the C layout
-    // (row = (lane>>4) + 4r, col = lane&15) hands every lane the y of ITS OWN particle at columns sl and sl+16 in
-    // register r = 0.  B fragments (A^-1, lane: k = 4ks + (lane>>4), col = 16nt + (lane&15)) are loaded once per workgroup.
+    // MFMA preparation (TAIL_PREP_MFMA): y[R particles x d] = theta~[R x d] . A^-1[d x d], R = 64/lpp particles per wave,
+    // as one 16x16x4 tile product per 16 columns and k-step.  B fragments (A^-1, lane: k = 4ks + (lane>>4),
+    // col = 16nt + (lane&15)) are loaded once per workgroup.
     double bfrag[2][8];
     if (PREP_MFMA) {
         const int kq = (tid & 63) >> 4, col = tid & 15;
@@ -924,27 +923,56 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             const double* th = scr + sub * scr_stride;
             // centred proposal mu~ = theta' - xbar (the data were centred the same way at demc_set_model)
             if (PREP_MFMA) {
+                // The wave's R = 64/lpp particles are rows 0..R-1 of the A operand (lane: row = lane&15, k = 4ks + lane>>4);
+                // the C layout then hands lane l the y of particles (l>>4) + 4r, r = 0..3, at columns l&15 and 16 + (l&15).
+                // The two dot products a particle needs (mu~.y and y.sx) are sums over columns = over the 16 lanes of a DPP
+                // row; lane 0 of the row parks them in the two spare slots of the particle's scratch row, from where the
+                // particle's own lanes pick them up.
                 const int lane = tid & 63, kq = lane >> 4, row = lane & 15;
-                const double* trow = scr + ((tid >> 6) * 4 + (row & 3)) * scr_stride;  // rows 0..3 = this wave's particles
+                const int R = 64 / lpp, wrow0 = (tid >> 6) * R;
+                const double* trow = scr + (wrow0 + (row < R ? row : 0)) * scr_stride;
                 d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
                     const int k = 4 * ks + kq;
-                    const double a = (row < 4 && k < d) ? trow[k] - xb_s[k] : 0.0;
+                    const double a = (row < R && k < d) ? trow[k] - xb_s[k] : 0.0;
                     acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[0][ks], acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[1][ks], acc1, 0, 0, 0);
                 }
-                const int c0 = sl, c1 = sl + 16;  // this lane's two columns of its own particle's y
-                const double y0 = acc0[0], y1 = acc1[0];
-                if (c0 < d) aux = fma(th[c0] - xb_s[c0], y0, aux);
-                if (c1 < d) aux = fma(th[c1] - xb_s[c1], y1, aux);
-                if (p.sx) {
-                    if (c0 < d) S = fma(y0, p.sx[c0], S);
-                    if (c1 < d) S = fma(y1, p.sx[c1], S);
-                } else if (valid) {
-                    if (c0 < p.dpad) p.Ypad[slot * p.dpad + c0] = (c0 < d) ? y0 : 0.0;
-                    if (c1 < p.dpad) p.Ypad[slot * p.dpad + c1] = (c1 < d) ? y1 : 0.0;
+                const int c0 = row, c1 = row + 16;
+                const double xb0 = c0 < d ? xb_s[c0] : 0.0, xb1 = c1 < d ? xb_s[c1] : 0.0;
+                const double sx0 = (p.sx && c0 < d) ? p.sx[c0] : 0.0, sx1 = (p.sx && c1 < d) ? p.sx[c1] : 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int pr = kq + 4 * r;  // uniform over the 16 lanes of a DPP row
+                    if (pr < R) {
+                        double* tr = scr + (wrow0 + pr) * scr_stride;
+                        const double y0 = c0 < d ? acc0[r] : 0.0, y1 = c1 < d ? acc1[r] : 0.0;
+                        double a_ = 0.0, s_ = 0.0;
+                        if (c0 < d) a_ = fma(tr[c0] - xb0, y0, a_);
+                        if (c1 < d) a_ = fma(tr[c1] - xb1, y1, a_);
+                        if (p.sx)
+                            s_ = fma(y1, sx1, y0 * sx0);
+                        else {
+                            const int qr = q_lo + pass * ppp + wrow0 + pr;
+                            if (qr < q_hi) {
+                                double* yrow = p.Ypad + ((size_t)g * Np + p.a_lo + qr) * p.dpad;
+                                if (c0 < p.dpad) yrow[c0] = y0;
+                                if (c1 < p.dpad) yrow[c1] = y1;
+                            }
+                        }
+                        a_ = subgroup_sum(a_, 16);
+                        s_ = subgroup_sum(s_, 16);
+                        if (row == 0) {
+                            tr[D] = a_;
+                            tr[D + 1] = s_;
+                        }
+                    }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                aux = th[D];
+                S = th[D + 1];
             } else
             for (int k = sl; 2 * k < d; k += lpp) {
                 const int c0 = 2 * k, c1 = 2 * k + 1;
@@ -975,8 +1003,10 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             }
             if (!p.sx && valid && !PREP_MFMA)  // zero the k-step padding beyond d
                 for (int c = 2 * ((d + 1) / 2) + sl; c < p.dpad; c += lpp) p.Ypad[slot * p.dpad + c] = 0.0;
-            aux = group_sum(aux, lpp, s_gsum);
-            S = group_sum(S, lpp, s_gsum);
+            if (!PREP_MFMA) {
+                aux = group_sum(aux, lpp, s_gsum);
+                S = group_sum(S, lpp, s_gsum);
+            }
         }
 
         if (pass == DEMC_STAMP_PASS || n_pass == 1) DEMC_STAMP(7);  // MvNormal preparation done
