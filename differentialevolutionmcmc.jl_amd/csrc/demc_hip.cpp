@@ -331,9 +331,9 @@ int launch_phase(demc_handle* h, KParams& k) {
     if (n_split < 1) n_split = 1;
     k.n_split = n_split;
     const bool tile = k.tile_in_lds && c.partner_kind == DEMC_PARTNER_CURRENT;
-    // plan stage (per-particle scalars once per workgroup): 3 doubles + 4 ints per particle of the workgroup's slice
+    // plan stage (per-particle scalars once per workgroup): 4 doubles + 4 ints per particle of the workgroup's slice
     const size_t per_split = (size_t)(k.n_act + n_split - 1) / n_split;
-    const size_t plan_bytes = per_split * (3 * sizeof(double) + 4 * sizeof(int));
+    const size_t plan_bytes = per_split * (4 * sizeof(double) + 4 * sizeof(int));
     // tile = the partner pool, plus the workgroup's own slice of moving rows when those lie outside the pool
     k.own_in_pool = (k.a_lo >= k.pool_lo && k.a_lo + k.n_act <= k.pool_lo + k.pool_n) ? 1 : 0;
     k.tile_rows = k.pool_n + (k.own_in_pool ? 0 : (int)per_split);

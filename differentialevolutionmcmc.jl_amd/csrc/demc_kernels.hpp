@@ -392,6 +392,28 @@ __device__ inline void lds_dma16(const double* g, double* l) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory", "m0");
 }
 
+// max over the 64 lanes of a wave, returned to all of them: butterfly inside the 16-lane rows on the DPP network, then
+// the four row results through scalar registers
+__device__ inline double wave_max(double v) {
+    v = fmax(v, dpp_mov<kDppXor1>(v));
+    v = fmax(v, dpp_mov<kDppXor2>(v));
+    v = fmax(v, dpp_mov<kDppHalfMirror>(v));
+    v = fmax(v, dpp_mov<kDppMirror>(v));
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        r[k] = __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * k), __builtin_amdgcn_readlane(lo, 16 * k));
+    return fmax(fmax(r[0], r[1]), fmax(r[2], r[3]));
+}
+
+// Orders the LDS operations of ONE wave (which the hardware executes in issue order) against compiler reordering: enough
+// for data handed between lanes of the same wave.
+__device__ inline void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global-memory counter, which
 // would make every barrier of the prologue wait for the tile copy (LDS-DMA) the prologue is supposed to overlap with.
 __device__ inline void lds_barrier() {
@@ -410,12 +432,22 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     constexpr bool FUSE_OBS = TAIL == TAIL_OBS;
     extern __shared__ double lds[];
     DEMC_STAMP_INIT();
-    __shared__ double s_red[4];
     __shared__ double s_total;
     __shared__ double s_gsum[4];
     __shared__ int s_gsumi[4];
     const int tid = threadIdx.x;
-    const int g = blockIdx.x / p.n_split, sp = blockIdx.x % p.n_split;
+    // Workgroups are dealt to the 8 XCDs round-robin by blockIdx, and each XCD has its own L2.  The n_split workgroups of
+    // a group copy the same partner pool, so they are given blockIdx values 8 apart: same XCD, dispatched back to back,
+    // and the second copy is served by that XCD's L2 instead of HBM.  (Plain order when the groups do not divide by 8.)
+    int g, sp;
+    if ((p.n_groups & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        sp = j % p.n_split;
+        g = (j / p.n_split) * 8 + xcd;
+    } else {
+        g = blockIdx.x / p.n_split;
+        sp = blockIdx.x % p.n_split;
+    }
     const int g_glob = p.group_offset + g;
     const int D = p.D, Np = p.Np, d = p.d;
     const bool even = (D & 1) == 0;
@@ -434,8 +466,8 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     double* xb_s = ainv_s + ((FUSE_PREP && p.Ainv) ? (size_t)d * d : 0);
     double* scr = xb_s + (FUSE_PREP ? d : 0);
     const bool use_scr = FUSE_PREP || FUSE_OBS;  // theta' of the pass kept in LDS for the fused tails
-    double* plan_d = scr + p.scr_doubles;                              // [per_split][3]: g1, g2, accept uniform
-    int* plan_i = reinterpret_cast<int*>(plan_d + 3 * (size_t)per_split);  // [per_split][4]
+    double* plan_d = scr + p.scr_doubles;  // [per_split][4]: g1, g2, accept uniform, select_base uniform
+    int* plan_i = reinterpret_cast<int*>(plan_d + 4 * (size_t)per_split);  // [per_split][4]: snooker?, three row indices
 
     // select_base (crossover.jl:282-289) over the partner POOL: the whole group in the synchronous schedule, the fixed
     // half in two_colour -- so nothing a moving particle reads (partners, base row, base weights) can change during
@@ -448,8 +480,13 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     const bool maybe_base = p.mode == MODE_STEP && p.proposal_kind == 0 && p.iter <= p.burnin;  // crossover.jl:164
     const bool ld_ainv = FUSE_PREP && p.Ainv;
     const int dd = d * d;
-    double w0 = -INFINITY, av[4], xv = 0.0;
-    if (maybe_base && tid < n_cdf) w0 = pw[tid];
+    const int wave = tid >> 6, lane = tid & 63;
+    double wv[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, av[4], xv = 0.0;
+    if (maybe_base && wave == 0) {  // the softmax below is wave 0's job alone
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (lane + 64 * k < n_cdf) wv[k] = pw[lane + 64 * k];
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) av[k] = (ld_ainv && tid + 256 * k < dd) ? p.Ainv[tid + 256 * k] : 0.0;
     if (FUSE_PREP && tid < d) xv = p.xbar[tid];
@@ -464,15 +501,6 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     const bool hist_partners = !TILE && p.partner_kind == 1;
     DEMC_STAMP(12);  // group coin drawn
 
-    double m = w0;
-    if (maybe_base) {
-        if (tid < n_cdf) cdf[tid] = w0;
-        for (int i = tid + 256; i < n_cdf; i += 256) {
-            const double w = pw[i];
-            cdf[i] = w;
-            m = fmax(m, w);
-        }
-    }
     if (FUSE_PREP) {
         if (ld_ainv) {
 #pragma unroll
@@ -483,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
         if (tid < d) xb_s[tid] = xv;
         for (int i = tid + 256; i < d; i += 256) xb_s[i] = p.xbar[i];
     }
-    DEMC_STAMP(14);  // pool weights, A^-1, xbar parked in LDS
+    DEMC_STAMP(14);  // A^-1, xbar parked in LDS; pool weights in wave 0's registers
     // The tile holds what this workgroup can read: the partner pool (all partner / base rows come from it) and, when
     // the moving particles are not pool rows (two_colour), its own slice of them -- two linear pieces of theta.
     double* own = tile + (size_t)p.pool_n * D;
@@ -497,7 +525,6 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
                 // LDS-DMA (global_load_lds_dwordx4): 16 B per lane straight into LDS, no VGPR round trip; the destination
                 // of one wave-instruction is a wave-uniform LDS base + lane*16, i.e. exactly a linear copy.
                 const int n16 = cnt[piece] >> 1;  // 16-byte pieces
-                const int wave = tid >> 6, lane = tid & 63;
                 for (int c0 = wave * 64; c0 < n16; c0 += 256) {
                     if (c0 + lane < n16) lds_dma16(src[piece] + 2 * (size_t)(c0 + lane), dst[piece] + 2 * (size_t)c0);
                 }
@@ -508,18 +535,22 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     DEMC_STAMP(15);  // tile copy issued
     // indexed by the row's position in its group; only pool rows (and, through pt below, own rows) are ever touched
     const double* rows = TILE ? (const double*)tile - (ptrdiff_t)p.pool_lo * D : grows;
-    if (use_base) {
+    if (use_base && wave == 0) {
         // stabilised: e_j = exp(w_j - max w); cumulative weights in a fixed two-level order (same as the oracle):
-        // sequential inside chunks of 16, sequential over the chunk totals, cdf[i] = offset[chunk] + prefix[i]
-        for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
-        if ((tid & 63) == 0) s_red[tid >> 6] = m;
-        lds_barrier();
-        m = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+        // sequential inside chunks of 16, sequential over the chunk totals, cdf[i] = offset[chunk] + prefix[i].
+        // One wave does all of it: its LDS operations execute in order, so the steps need no workgroup barrier (the
+        // other three waves are computing their share of the plan meanwhile).
+        double m = fmax(fmax(wv[0], wv[1]), fmax(wv[2], wv[3]));
+        for (int i = lane + 256; i < n_cdf; i += 64) m = fmax(m, pw[i]);  // pools beyond 256 (these reads queue behind the tile)
+        m = wave_max(m);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (lane + 64 * k < n_cdf) cdf[lane + 64 * k] = exp(wv[k] - m);
+        for (int i = lane + 256; i < n_cdf; i += 64) cdf[i] = exp(pw[i] - m);
+        wave_lds_sync();
         const int n_chunk = (n_cdf + 15) >> 4;
         double* ctot = cdf + Np;
-        for (int i = tid; i < n_cdf; i += 256) cdf[i] = exp(cdf[i] - m);  // each thread: the entries it parked above
-        lds_barrier();
-        for (int c = tid; c < n_chunk; c += 256) {
+        for (int c = lane; c < n_chunk; c += 64) {
             // 16 reads up front, then the dependent adds in registers (padding with 0.0 leaves a running sum unchanged)
             double v[16];
 #pragma unroll
@@ -535,31 +566,42 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
                 if (c * 16 + k < n_cdf) cdf[c * 16 + k] = v[k];
             ctot[c] = pre;
         }
-        lds_barrier();
-        // offset of a chunk = the chunk totals before it, summed left to right; every thread folds the totals it needs
-        // itself (LDS broadcast reads) instead of waiting for one lane to scan them
-        for (int i = tid; i < n_cdf; i += 256) {
-            const int ci = i >> 4;
+        wave_lds_sync();
+        if (lane == 0) {  // chunk offsets, left to right, eight totals per round trip
             double off = 0.0;
-            for (int c = 0; c < ci; ++c) off = off + ctot[c];
-            cdf[i] = off + cdf[i];
+            for (int c0 = 0; c0 < n_chunk; c0 += 8) {
+                double t[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t[k] = (c0 + k < n_chunk) ? ctot[c0 + k] : 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (c0 + k < n_chunk) {
+                        ctot[c0 + k] = off;
+                        off = off + t[k];
+                    }
+            }
         }
-        lds_barrier();
-        if (tid == 0) s_total = cdf[n_cdf - 1];
+        wave_lds_sync();
+        for (int i = lane; i < n_cdf; i += 64) cdf[i] = ctot[i >> 4] + cdf[i];
+        wave_lds_sync();
+        if (lane == 0) s_total = cdf[n_cdf - 1];
     }
-    DEMC_STAMP(0);  // softmax prefix sums done (tile still in flight)
+    DEMC_STAMP(0);  // wave 0: softmax prefix sums done (tile still in flight)
 
     const int n_pass = (q_hi - q_lo + ppp - 1) / ppp;
     const int nblk = hist_partners ? 6 : 4;
     // ---- plan stage.  Everything about a crossover proposal that is one value per PARTICLE -- the snooker coin, the
     // partner / base indices, the gammas, the accept uniform -- is computed here once, four lanes per particle (lane b of
     // the quad evaluates Philox block b; quad_perm hands the blocks round), and parked in LDS.  The passes below, where
-    // lpp lanes share a particle, then read it back instead of recomputing it lpp times over.
+    // lpp lanes share a particle, then read it back instead of recomputing it lpp times over.  The base pick needs the
+    // prefix sums and follows after a barrier.
     const bool planned = TILE && p.plan && de_any && lpp >= 4;
-    if (planned) {
-        const int n_loc = q_hi - q_lo;
-        for (int base = 0; base < n_loc; base += 64) {
-            const int ql = base + (tid >> 2), blk = tid & 3;
+    const int n_loc = q_hi - q_lo;
+    // While wave 0 is busy with the prefix sums the other three waves draw the plan for all of the workgroup's particles.
+    const int plan_t0 = use_base ? 64 : 0, plan_q = (256 - plan_t0) >> 2;
+    if (planned && tid >= plan_t0) {
+        for (int base = 0; base < n_loc; base += plan_q) {
+            const int ql = base + ((tid - plan_t0) >> 2), blk = tid & 3;
             const bool ok = ql < n_loc;
             const int pl = p.a_lo + q_lo + (ok ? ql : 0);
             const uint32_t eslot = (uint32_t)g_glob * (uint32_t)Np + (uint32_t)pl;
@@ -587,24 +629,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
                 i0 = (int)a + p.pool_lo; i1 = (int)b + p.pool_lo;
                 if (p.proposal_kind == 0) {
                     g1 = 0.5 + (1.0 - 0.5) * u_g1;  // crossover.jl:162
-                    if (use_base) {
-                        g2 = 0.5 + (1.0 - 0.5) * u_g2;
-                        const double total = cdf[n_cdf - 1];
-                        int b2;
-                        if (!(total > 0.0) || !(total < INFINITY)) {
-                            b2 = (int)(u_base * n_cdf);
-                            b2 = b2 < n_cdf ? b2 : n_cdf - 1;
-                        } else {  // first i with cdf[i] >= t, else last (cdf is monotone): binary search
-                            const double t = u_base * total;
-                            int lo = 0, hi = n_cdf - 1;
-                            while (lo < hi) {
-                                const int mid = (lo + hi) >> 1;
-                                if (cdf[mid] >= t) hi = mid; else lo = mid + 1;
-                            }
-                            b2 = lo;
-                        }
-                        i2 = b2 + p.pool_lo;
-                    }
+                    if (use_base) g2 = 0.5 + (1.0 - 0.5) * u_g2;
                 } else if (p.proposal_kind == 1)
                     g1 = 2.38;  // crossover.jl:191
                 else
@@ -615,13 +640,38 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
                 plan_i[4 * ql + 1] = i0;
                 plan_i[4 * ql + 2] = i1;
                 plan_i[4 * ql + 3] = i2;
-                plan_d[3 * ql + 0] = g1;
-                plan_d[3 * ql + 1] = g2;
-                plan_d[3 * ql + 2] = u53(ra.x, ra.y);
+                plan_d[4 * ql + 0] = g1;
+                plan_d[4 * ql + 1] = g2;
+                plan_d[4 * ql + 2] = u53(ra.x, ra.y);
+                plan_d[4 * ql + 3] = u_base;
             }
         }
     }
-    DEMC_STAMP(11);  // this wave's share of the plan written
+    if (planned) {
+        if (use_base) {
+            lds_barrier();  // prefix sums (wave 0) and plan records visible to everyone
+            DEMC_STAMP(11);
+            const double total = cdf[n_cdf - 1];
+            for (int ql = tid; ql < n_loc; ql += 256)
+                if (plan_i[4 * ql + 0] == 0) {  // select_base for the crossover proposals (crossover.jl:282-289)
+                    const double u_base = plan_d[4 * ql + 3];
+                    int b2;
+                    if (!(total > 0.0) || !(total < INFINITY)) {
+                        b2 = (int)(u_base * n_cdf);
+                        b2 = b2 < n_cdf ? b2 : n_cdf - 1;
+                    } else {  // first i with cdf[i] >= t, else last (cdf is monotone): binary search
+                        const double t = u_base * total;
+                        int lo = 0, hi = n_cdf - 1;
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if (cdf[mid] >= t) hi = mid; else lo = mid + 1;
+                        }
+                        b2 = lo;
+                    }
+                    plan_i[4 * ql + 3] = b2 + p.pool_lo;
+                }
+        }
+    }
     if (TILE && even) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA pieces have landed
     __syncthreads();
     DEMC_STAMP(1);  // tile and plan visible
@@ -690,7 +740,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             const int ql = valid ? q - q_lo : 0;
             kind = plan_i[4 * ql + 0];
             i0 = plan_i[4 * ql + 1]; i1 = plan_i[4 * ql + 2]; i2 = plan_i[4 * ql + 3];
-            g1 = plan_d[3 * ql + 0]; g2 = plan_d[3 * ql + 1]; u_acc = plan_d[3 * ql + 2];
+            g1 = plan_d[4 * ql + 0]; g2 = plan_d[4 * ql + 1]; u_acc = plan_d[4 * ql + 2];
             Pa = rows + (size_t)i0 * D; Pb2 = rows + (size_t)i1 * D;
             if (kind == 1) {
                 Pc = rows + (size_t)i2 * D;
