@@ -67,6 +67,9 @@ struct demc_handle {
     int lpp = 1;
     int tile_in_lds = 0;
     size_t k1_lds = 0, k1_tile_bytes = 0, k1_scr_bytes = 0;
+    bool res_ok = false;  // resident K1 (plan_resident)
+    int res_lpp = 0, res_wg = 0, res_scr_doubles = 0;
+    size_t res_lds = 0;
     std::string err;
     // timing
     bool timing = false;
@@ -298,14 +301,15 @@ bool is_mvn(int fam) { return fam == FAM_MVN_FULL || fam == FAM_MVN_ISO; }
 using K1Fn = void (*)(KParams);
 K1Fn k1_instance(bool tile, int tail) {
     static const K1Fn tab[2][4] = {
-        {k_propose<false, TAIL_NONE>, k_propose<false, TAIL_PREP>, k_propose<false, TAIL_PREP_MFMA>, k_propose<false, TAIL_OBS>},
-        {k_propose<true, TAIL_NONE>, k_propose<true, TAIL_PREP>, k_propose<true, TAIL_PREP_MFMA>, k_propose<true, TAIL_OBS>}};
+        {k_propose<256, false, TAIL_NONE, false>, k_propose<256, false, TAIL_PREP, false>,
+         k_propose<256, false, TAIL_PREP_MFMA, false>, k_propose<256, false, TAIL_OBS, false>},
+        {k_propose<256, true, TAIL_NONE, false>, k_propose<256, true, TAIL_PREP, false>,
+         k_propose<256, true, TAIL_PREP_MFMA, false>, k_propose<256, true, TAIL_OBS, false>}};
     return tab[tile ? 1 : 0][tail];
 }
 
-int launch_phase(demc_handle* h, KParams& k) {
-    const long long n_prop = (long long)k.n_groups * k.n_act;
-    if (n_prop == 0) return DEMC_OK;
+// which tail K1 carries for this model, mode and schedule
+void set_tail_flags(demc_handle* h, KParams& k) {
     const demc_config& c = h->c;
     const bool suff = c.loglike_mode == DEMC_LOGLIKE_SUFFSTAT;
     // K1 tails: MvNormal preparation always; the whole update when the likelihood is O(D^2) given data-only
@@ -322,6 +326,14 @@ int launch_phase(demc_handle* h, KParams& k) {
     k.fuse_obs = (cheap_obs && phase_private && c.fuse != 1) ? 1 : 0;
     k.fuse_accept = (((k.fuse_prep && suff) || k.fuse_obs) && c.fuse != 1 && phase_private) ? 1 : 0;
     k.write_prop = (!k.fuse_accept || k.trace) ? 1 : 0;
+}
+int tail_of(const KParams& k) { return k.prep_mfma ? TAIL_PREP_MFMA : k.fuse_prep ? TAIL_PREP : k.fuse_obs ? TAIL_OBS : TAIL_NONE; }
+
+int launch_phase(demc_handle* h, KParams& k) {
+    const long long n_prop = (long long)k.n_groups * k.n_act;
+    if (n_prop == 0) return DEMC_OK;
+    const demc_config& c = h->c;
+    set_tail_flags(h, k);
     const int ppp = 256 / k.lpp, ppp3 = 256 / k.lpp3;
     const int max_split = (k.n_act + ppp - 1) / ppp;
     int target_wgs = 512;
@@ -341,7 +353,7 @@ int launch_phase(demc_handle* h, KParams& k) {
     k.plan = (tile && k.mode == MODE_STEP && k.lpp >= 4 && k.lpp <= 64 && lds_tile + plan_bytes <= kMaxDynLds) ? 1 : 0;
     if (const char* e = std::getenv("DEMC_K1_PLAN")) k.plan = k.plan && e[0] == '1';  // A/B experiments
     tick(h, 0, true);
-    const int tail = k.prep_mfma ? TAIL_PREP_MFMA : k.fuse_prep ? TAIL_PREP : k.fuse_obs ? TAIL_OBS : TAIL_NONE;
+    const int tail = tail_of(k);
     const size_t lds = tile ? lds_tile + (k.plan ? plan_bytes : 0) : h->k1_lds - h->k1_tile_bytes;
     hipLaunchKernelGGL(k1_instance(tile, tail), dim3(k.n_groups * n_split), dim3(256), lds, h->stream, k);
     tick(h, 0, false);
@@ -351,6 +363,64 @@ int launch_phase(demc_handle* h, KParams& k) {
     tick(h, 3, true);
     hipLaunchKernelGGL(k_accept_store, dim3((unsigned)((n_prop + ppp3 - 1) / ppp3)), dim3(256), 0, h->stream, k);
     tick(h, 3, false);
+    return DEMC_OK;
+}
+
+// ---- resident form of K1: one workgroup per group, both colour phases of several iterations in one launch ----
+K1Fn k1_resident_instance(int wg, int tail) {
+    static const K1Fn tab[2][4] = {
+        {k_propose<256, true, TAIL_NONE, true>, k_propose<256, true, TAIL_PREP, true>, k_propose<256, true, TAIL_PREP_MFMA, true>,
+         k_propose<256, true, TAIL_OBS, true>},
+        {k_propose<512, true, TAIL_NONE, true>, k_propose<512, true, TAIL_PREP, true>, k_propose<512, true, TAIL_PREP_MFMA, true>,
+         k_propose<512, true, TAIL_OBS, true>}};
+    return tab[wg == 512 ? 1 : 0][tail];
+}
+
+// Decides once per model whether the resident form applies and with which geometry (lanes per particle, workgroup size,
+// LDS bytes).  It needs the fused accept tail (the whole update inside K1), the two_colour schedule (a phase writes only
+// rows nobody reads), partners from the current population, and the whole group + its scratch in LDS.
+void plan_resident(demc_handle* h) {
+    const demc_config& c = h->c;
+    h->res_ok = false;
+    if (c.fuse != 0 || c.schedule != DEMC_SCHED_TWO_COLOUR || c.partner_kind != DEMC_PARTNER_CURRENT || c.Np < 4) return;
+    if (const char* e = std::getenv("DEMC_RESIDENT"))  // A/B experiments
+        if (e[0] == '0') return;
+    int lpp_max = pow2_ceil((c.D + 1) / 2);
+    if (lpp_max > 64) return;
+    const int n_act = c.Np - c.Np / 2;
+    int lpp = 4;  // one pass of a 512-thread workgroup over the moving half when possible; never below 4 lanes
+    while (lpp * 2 <= lpp_max && n_act * lpp * 2 <= 512) lpp *= 2;
+    if (lpp > lpp_max) lpp = lpp_max;
+    const int wg = (n_act * lpp > 256) ? 512 : 256;
+    KParams k = base_params(h);
+    k.lpp = lpp;
+    k.mode = MODE_STEP;
+    set_tail_flags(h, k);
+    if (!k.fuse_accept) return;
+    const size_t D = (size_t)c.D, Np = (size_t)c.Np, d = (size_t)h->d;
+    const bool mvn = is_mvn(h->family);
+    const size_t scr_doubles = (k.fuse_prep || k.fuse_obs) ? (size_t)(wg / lpp) * (D + 2) : 0;
+    const size_t doubles = Np * D + Np + (Np + (Np + 15) / 16) + (h->family == FAM_MVN_FULL ? d * d : 0) + (mvn ? d : 0) + scr_doubles;
+    const size_t bytes = doubles * sizeof(double) + (size_t)n_act * (4 * sizeof(double) + 4 * sizeof(int));
+    if (bytes > kMaxDynLds) return;
+    h->res_ok = true; h->res_lpp = lpp; h->res_wg = wg; h->res_lds = bytes; h->res_scr_doubles = (int)scr_doubles;
+}
+
+int launch_resident(demc_handle* h, long long iter0, int n_iters) {
+    const demc_config& c = h->c;
+    KParams k = base_params(h);
+    k.lpp = h->res_lpp;
+    set_tail_flags(h, k);
+    k.iter = iter0; k.n_iters = n_iters; k.n_sweeps = c.n_blocks > 0 ? c.n_blocks : 1;
+    k.mask = c.n_blocks > 0 ? h->masks : nullptr;
+    k.n_rows = h->hist ? c.n_rows : 0;
+    k.n_split = 1; k.exclude_self = 0; k.own_in_pool = 1; k.tile_rows = c.Np; k.tile_in_lds = 1;
+    k.scr_doubles = h->res_scr_doubles;
+    k.plan = (k.lpp >= 4) ? 1 : 0;
+    if (const char* e = std::getenv("DEMC_K1_PLAN")) k.plan = k.plan && e[0] == '1';  // A/B experiments
+    tick(h, 0, true);
+    hipLaunchKernelGGL(k1_resident_instance(h->res_wg, tail_of(k)), dim3(k.n_groups), dim3(h->res_wg), h->res_lds, h->stream, k);
+    tick(h, 0, false);
     return DEMC_OK;
 }
 
@@ -413,9 +483,13 @@ int size_k1_lds(demc_handle* h) {
     // the attribute is per function, not per handle: always raise it to the same ceiling so that handles of different
     // sizes in one process do not lower each other's limit
     for (int t = 0; t < 2; ++t)
-        for (int tail = 0; tail < 4; ++tail)
+        for (int tail = 0; tail < 4; ++tail) {
             HIPCHK(hipFuncSetAttribute((const void*)k1_instance(t != 0, tail), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)kMaxDynLds));
+            HIPCHK(hipFuncSetAttribute((const void*)k1_resident_instance(t ? 512 : 256, tail),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
+        }
+    plan_resident(h);
     HIPCHK(hipFuncSetAttribute((const void*)k_mig_pack, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
     return DEMC_OK;
 }
@@ -917,6 +991,14 @@ static int32_t step_impl(demc_handle* h, int64_t iter0, int32_t n_iters, bool wi
             if (c.n_groups_total != c.n_groups)
                 return fail(h, DEMC_EINVAL, "sharded handle: drive the exchange with demc_migration_pack/apply + demc_update");
             migration_enqueue(h, iter, h->mig_rows, h->mig_rows, true, true);
+        }
+        if (h->res_ok) {  // every iteration up to the next migration in one launch
+            int run = 1;
+            while (iter + run < iter0 + n_iters && !(with_migration && demc_migration_due(&c, iter + run))) ++run;
+            int rc = launch_resident(h, iter, run);
+            if (rc != DEMC_OK) return rc;
+            iter += run - 1;
+            continue;
         }
         for (int b = 0; b < n_sweeps; ++b) {
             const unsigned char* mask = c.n_blocks > 0 ? h->masks + (size_t)b * c.D : nullptr;

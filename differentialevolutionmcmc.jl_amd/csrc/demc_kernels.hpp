@@ -73,6 +73,9 @@ struct KParams {
     long long store_row;      // >= 0: K3 stores this history row
     int tile_in_lds;          // K1: stage the group tile in LDS
     int n_split;              // K1: workgroups per group
+    // K1 resident form (one workgroup keeps its group in LDS over both colour phases of several iterations)
+    int n_iters, n_sweeps;    // iterations to run from `iter`, and block sweeps per iteration; mask = all block masks [n_sweeps][D]
+    long long n_rows;         // history rows allocated (store while iter-1 < n_rows)
     int fuse_prep;            // K1 computes y = A^-1 theta', a = theta'.y (MvNormal families)
     int prep_mfma;            // ... on the matrix cores (full Sigma, d <= 32, 16 lanes per particle)
     int tile_rows;            // K1: rows of the LDS tile = the partner pool (+ the workgroup's own rows if outside it)
@@ -371,13 +374,17 @@ __device__ inline double prior_term(const DimTab& t, double x, double inv_sref, 
     do {                                                                                                           \
         if (threadIdx.x == 0) p.tr_w[blockIdx.x * 16 + (i)] = (double)(__builtin_amdgcn_s_memtime() - t_start__); \
     } while (0)
-#define DEMC_STAMP_INIT() const unsigned long long t_start__ = __builtin_amdgcn_s_memtime()
+#define DEMC_STAMP_INIT() unsigned long long t_start__ = __builtin_amdgcn_s_memtime()
+#define DEMC_STAMP_RESET() t_start__ = __builtin_amdgcn_s_memtime()  // resident form: stamps are relative to the step's start
 #else
 #define DEMC_STAMP(i) \
     do {              \
     } while (0)
 #define DEMC_STAMP_INIT() \
     do {                  \
+    } while (0)
+#define DEMC_STAMP_RESET() \
+    do {                   \
     } while (0)
 #endif
 
@@ -425,22 +432,29 @@ __device__ inline void lds_barrier() {
 // TAIL selects the fused tail compiled into the instance (the host passes the matching flags in KParams): registers
 // are allocated for the worst path of a kernel, so the tails a model cannot take are kept out of its instance.
 enum K1Tail : int { TAIL_NONE = 0, TAIL_PREP = 1, TAIL_PREP_MFMA = 2, TAIL_OBS = 3 };
-template <bool TILE, int TAIL>
-__global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
+// RES = resident form: ONE workgroup of WG threads owns a group, copies all of its rows and weights into LDS once, and then
+// runs both colour phases of p.n_iters iterations (x p.n_sweeps block sweeps) without leaving the kernel: accepted rows are
+// written to the LDS copy and through to HBM, a workgroup barrier separates the phases.  Groups never interact inside
+// update! (main.jl:135-167), so nothing else is needed between two migrations.  Requires the fused accept tail,
+// two_colour, current-population partners.  RES = false is the one-phase-per-launch form with n_split workgroups per group.
+template <int WG, bool TILE, int TAIL, bool RES>
+__global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
     constexpr bool FUSE_PREP = TAIL == TAIL_PREP || TAIL == TAIL_PREP_MFMA;
     constexpr bool PREP_MFMA = TAIL == TAIL_PREP_MFMA;
     constexpr bool FUSE_OBS = TAIL == TAIL_OBS;
+    static_assert(!RES || TILE, "the resident form keeps the group in LDS");
     extern __shared__ double lds[];
     DEMC_STAMP_INIT();
     __shared__ double s_total;
     __shared__ double s_gsum[4];
     __shared__ int s_gsumi[4];
+    KParams p = p0;  // RES: the per-phase fields (iter, sweep, mask, store_row, active range, pool) are rewritten every step
     const int tid = threadIdx.x;
     // Workgroups are dealt to the 8 XCDs round-robin by blockIdx, and each XCD has its own L2.  The n_split workgroups of
     // a group copy the same partner pool, so they are given blockIdx values 8 apart: same XCD, dispatched back to back,
     // and the second copy is served by that XCD's L2 instead of HBM.  (Plain order when the groups do not divide by 8.)
     int g, sp;
-    if ((p.n_groups & 7) == 0) {
+    if (!RES && (p.n_groups & 7) == 0) {
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
         sp = j % p.n_split;
         g = (j / p.n_split) * 8 + xcd;
@@ -451,36 +465,73 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     const int g_glob = p.group_offset + g;
     const int D = p.D, Np = p.Np, d = p.d;
     const bool even = (D & 1) == 0;
-    const double* grows = p.theta + (size_t)g * Np * D;
-    const double* gw = p.weight + (size_t)g * Np;
+    double* grows = p.theta + (size_t)g * Np * D;
+    double* gw = p.weight + (size_t)g * Np;
     const int lpp = p.lpp;
-    const int ppp = 256 / lpp;  // particles per pass
+    const int ppp = WG / lpp;  // particles per pass
+    const int wave = tid >> 6, lane = tid & 63;
+    const int dd = d * d;
+    const bool ld_ainv = FUSE_PREP && p.Ainv;
+    // LDS carve-up (host computes the same sizes): tile | weights (RES) | cdf + chunk totals | A^-1 | theta' scratch | plan
+    const int plan_cap = RES ? Np - Np / 2 : (p.n_act + p.n_split - 1) / p.n_split;  // particles a workgroup moves per phase
+    double* tile = lds;
+    double* w_s = tile + (TILE ? (size_t)p.tile_rows * D : 0);
+    double* cdf = w_s + (RES ? Np : 0);
+    double* ainv_s = cdf + Np + ((Np + 15) >> 4);
+    const int scr_stride = D + 2;
+    double* xb_s = ainv_s + (ld_ainv ? (size_t)dd : 0);
+    double* scr = xb_s + (FUSE_PREP ? d : 0);
+    const bool use_scr = FUSE_PREP || FUSE_OBS;  // theta' of the pass kept in LDS for the fused tails
+    double* plan_d = scr + p.scr_doubles;  // [plan_cap][4]: g1, g2, accept uniform, select_base uniform
+    int* plan_i = reinterpret_cast<int*>(plan_d + 4 * (size_t)plan_cap);  // [plan_cap][4]: snooker?, three row indices
+
+    if (RES) {  // once: every row and weight of the group, A^-1 and xbar
+        if (even) {
+            const int n16 = (Np * D) >> 1;
+            for (int c0 = wave * 64; c0 < n16; c0 += WG)
+                if (c0 + lane < n16) lds_dma16(grows + 2 * (size_t)(c0 + lane), tile + 2 * (size_t)c0);
+        } else
+            for (int i = tid; i < Np * D; i += WG) tile[i] = grows[i];
+        for (int i = tid; i < Np; i += WG) w_s[i] = gw[i];
+        if (ld_ainv)
+            for (int i = tid; i < dd; i += WG) ainv_s[i] = p.Ainv[i];
+        if (FUSE_PREP)
+            for (int i = tid; i < d; i += WG) xb_s[i] = p.xbar[i];
+        if (even) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    double bfrag[2][8];  // A^-1 fragments of the MFMA preparation, loaded once (below)
+
+    const long long n_steps = RES ? (long long)p0.n_iters * p0.n_sweeps * 2 : 1;
+    for (long long step = 0; step < n_steps; ++step) {
+    if (RES) {  // step -> (iteration, block sweep, colour phase)
+        DEMC_STAMP_RESET();
+        const int ph = (int)(step & 1);
+        const long long s2 = step >> 1;
+        const int bsw = (int)(s2 % p0.n_sweeps);
+        p.iter = p0.iter + s2 / p0.n_sweeps;
+        p.sweep = (unsigned)bsw;
+        p.mask = p0.mask ? p0.mask + (size_t)bsw * D : nullptr;  // block_update! main.jl:174-179
+        p.store_row = (bsw == p0.n_sweeps - 1 && p0.hist && p.iter - 1 < p0.n_rows) ? p.iter - 1 : -1;
+        const int half = Np / 2;  // two_colour: the halves take turns, partners and base come from the resting half
+        p.a_lo = ph ? half : 0;
+        p.n_act = ph ? Np - half : half;
+        p.pool_lo = ph ? 0 : half;
+        p.pool_n = ph ? half : Np - half;
+    }
     const int per_split = (p.n_act + p.n_split - 1) / p.n_split;
     const int q_lo = sp * per_split;
     const int q_hi = (q_lo + per_split < p.n_act) ? q_lo + per_split : p.n_act;
-    // LDS carve-up (host computes the same sizes): tile | cdf + chunk totals | A^-1 | theta' scratch | plan
-    double* tile = lds;
-    double* cdf = tile + (TILE ? (size_t)p.tile_rows * D : 0);
-    double* ainv_s = cdf + Np + ((Np + 15) >> 4);
-    const int scr_stride = D + 2;
-    double* xb_s = ainv_s + ((FUSE_PREP && p.Ainv) ? (size_t)d * d : 0);
-    double* scr = xb_s + (FUSE_PREP ? d : 0);
-    const bool use_scr = FUSE_PREP || FUSE_OBS;  // theta' of the pass kept in LDS for the fused tails
-    double* plan_d = scr + p.scr_doubles;  // [per_split][4]: g1, g2, accept uniform, select_base uniform
-    int* plan_i = reinterpret_cast<int*>(plan_d + 4 * (size_t)per_split);  // [per_split][4]: snooker?, three row indices
 
     // select_base (crossover.jl:282-289) over the partner POOL: the whole group in the synchronous schedule, the fixed
     // half in two_colour -- so nothing a moving particle reads (partners, base row, base weights) can change during
     // the phase, which is what makes the fused accept tail race-free across workgroups.
     const int n_cdf = p.pool_n;
-    const double* pw = gw + p.pool_lo;
+    const double* pw = (RES ? w_s : gw) + p.pool_lo;
     // Order of the prologue: a wave's memory results return in issue order, so the few global reads the prologue itself
     // consumes (pool weights, A^-1, xbar) are issued FIRST, all at once, and the bulk tile copy after them; the copy
     // then stays in flight under the softmax prefix sums and the plan stage, none of which touch global memory.
     const bool maybe_base = p.mode == MODE_STEP && p.proposal_kind == 0 && p.iter <= p.burnin;  // crossover.jl:164
-    const bool ld_ainv = FUSE_PREP && p.Ainv;
-    const int dd = d * d;
-    const int wave = tid >> 6, lane = tid & 63;
     double wv[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, av[4], xv = 0.0;
     if (maybe_base && wave == 0) {  // the softmax below is wave 0's job alone
 #pragma unroll
@@ -488,8 +539,8 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             if (lane + 64 * k < n_cdf) wv[k] = pw[lane + 64 * k];
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) av[k] = (ld_ainv && tid + 256 * k < dd) ? p.Ainv[tid + 256 * k] : 0.0;
-    if (FUSE_PREP && tid < d) xv = p.xbar[tid];
+    for (int k = 0; k < 4; ++k) av[k] = (!RES && ld_ainv && tid + WG * k < dd) ? p.Ainv[tid + WG * k] : 0.0;
+    if (!RES && FUSE_PREP && tid < d) xv = p.xbar[tid];
 
     bool is_mut = false;  // the group's coin, drawn while those loads are in flight
     if (p.mode == MODE_STEP) {
@@ -501,21 +552,21 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     const bool hist_partners = !TILE && p.partner_kind == 1;
     DEMC_STAMP(12);  // group coin drawn
 
-    if (FUSE_PREP) {
+    if (!RES && FUSE_PREP) {
         if (ld_ainv) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (tid + 256 * k < dd) ainv_s[tid + 256 * k] = av[k];
-            for (int i = tid + 1024; i < dd; i += 256) ainv_s[i] = p.Ainv[i];
+                if (tid + WG * k < dd) ainv_s[tid + WG * k] = av[k];
+            for (int i = tid + 4 * WG; i < dd; i += WG) ainv_s[i] = p.Ainv[i];
         }
         if (tid < d) xb_s[tid] = xv;
-        for (int i = tid + 256; i < d; i += 256) xb_s[i] = p.xbar[i];
+        for (int i = tid + WG; i < d; i += WG) xb_s[i] = p.xbar[i];
     }
     DEMC_STAMP(14);  // A^-1, xbar parked in LDS; pool weights in wave 0's registers
     // The tile holds what this workgroup can read: the partner pool (all partner / base rows come from it) and, when
     // the moving particles are not pool rows (two_colour), its own slice of them -- two linear pieces of theta.
     double* own = tile + (size_t)p.pool_n * D;
-    if (TILE) {
+    if (TILE && !RES) {
         const double* src[2] = {grows + (size_t)p.pool_lo * D, grows + (size_t)(p.a_lo + q_lo) * D};
         double* dst[2] = {tile, own};
         const int cnt[2] = {p.pool_n * D, p.own_in_pool ? 0 : (q_hi - q_lo) * D};
@@ -525,16 +576,16 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
                 // LDS-DMA (global_load_lds_dwordx4): 16 B per lane straight into LDS, no VGPR round trip; the destination
                 // of one wave-instruction is a wave-uniform LDS base + lane*16, i.e. exactly a linear copy.
                 const int n16 = cnt[piece] >> 1;  // 16-byte pieces
-                for (int c0 = wave * 64; c0 < n16; c0 += 256) {
+                for (int c0 = wave * 64; c0 < n16; c0 += WG) {
                     if (c0 + lane < n16) lds_dma16(src[piece] + 2 * (size_t)(c0 + lane), dst[piece] + 2 * (size_t)c0);
                 }
             } else
-                for (int i = tid; i < cnt[piece]; i += 256) dst[piece][i] = src[piece][i];
+                for (int i = tid; i < cnt[piece]; i += WG) dst[piece][i] = src[piece][i];
         }
     }
     DEMC_STAMP(15);  // tile copy issued
     // indexed by the row's position in its group; only pool rows (and, through pt below, own rows) are ever touched
-    const double* rows = TILE ? (const double*)tile - (ptrdiff_t)p.pool_lo * D : grows;
+    const double* rows = RES ? (const double*)tile : TILE ? (const double*)tile - (ptrdiff_t)p.pool_lo * D : grows;
     if (use_base && wave == 0) {
         // stabilised: e_j = exp(w_j - max w); cumulative weights in a fixed two-level order (same as the oracle):
         // sequential inside chunks of 16, sequential over the chunk totals, cdf[i] = offset[chunk] + prefix[i].
@@ -548,6 +599,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             if (lane + 64 * k < n_cdf) cdf[lane + 64 * k] = exp(wv[k] - m);
         for (int i = lane + 256; i < n_cdf; i += 64) cdf[i] = exp(pw[i] - m);
         wave_lds_sync();
+        if (RES) DEMC_STAMP(14);  // (diagnostic, resident form) exponentials written
         const int n_chunk = (n_cdf + 15) >> 4;
         double* ctot = cdf + Np;
         for (int c = lane; c < n_chunk; c += 64) {
@@ -567,6 +619,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             ctot[c] = pre;
         }
         wave_lds_sync();
+        if (RES) DEMC_STAMP(15);  // (diagnostic, resident form) chunk scans done
         if (lane == 0) {  // chunk offsets, left to right, eight totals per round trip
             double off = 0.0;
             for (int c0 = 0; c0 < n_chunk; c0 += 8) {
@@ -598,7 +651,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     const bool planned = TILE && p.plan && de_any && lpp >= 4;
     const int n_loc = q_hi - q_lo;
     // While wave 0 is busy with the prefix sums the other three waves draw the plan for all of the workgroup's particles.
-    const int plan_t0 = use_base ? 64 : 0, plan_q = (256 - plan_t0) >> 2;
+    const int plan_t0 = use_base ? 64 : 0, plan_q = (WG - plan_t0) >> 2;
     if (planned && tid >= plan_t0) {
         for (int base = 0; base < n_loc; base += plan_q) {
             const int ql = base + ((tid - plan_t0) >> 2), blk = tid & 3;
@@ -652,7 +705,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             lds_barrier();  // prefix sums (wave 0) and plan records visible to everyone
             DEMC_STAMP(11);
             const double total = cdf[n_cdf - 1];
-            for (int ql = tid; ql < n_loc; ql += 256)
+            for (int ql = tid; ql < n_loc; ql += WG)
                 if (plan_i[4 * ql + 0] == 0) {  // select_base for the crossover proposals (crossover.jl:282-289)
                     const double u_base = plan_d[4 * ql + 3];
                     int b2;
@@ -672,7 +725,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
                 }
         }
     }
-    if (TILE && even) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA pieces have landed
+    if (TILE && even && !RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA pieces have landed
     __syncthreads();
     DEMC_STAMP(1);  // tile and plan visible
 
@@ -682,8 +735,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
     // MFMA preparation (TAIL_PREP_MFMA): y[R particles x d] = theta~[R x d] . A^-1[d x d], R = 64/lpp particles per wave,
     // as one 16x16x4 tile product per 16 columns and k-step.  B fragments (A^-1, lane: k = 4ks + (lane>>4),
     // col = 16nt + (lane&15)) are loaded once per workgroup.
-    double bfrag[2][8];
-    if (PREP_MFMA) {
+    if (PREP_MFMA && step == 0) {
         const int kq = (tid & 63) >> 4, col = tid & 15;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -1090,7 +1142,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
 
         if (pass == DEMC_STAMP_PASS || n_pass == 1) DEMC_STAMP(8);  // in-kernel observation loop done
         // ---- fused tail: compute_posterior! + mh_update! + store_samples! for this particle ----
-        const double w = gw[pl];
+        const double w = RES ? w_s[pl] : gw[pl];
         const double sg = (p.family == FAM_MVN_ISO) ? scr[sub * scr_stride + d]
                           : (p.family == FAM_GAUSSIAN) ? scr[sub * scr_stride + 1] : 0.0;
         double wp;
@@ -1100,7 +1152,10 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
             wp = oob ? -INFINITY : prior + loglike_from_stats(p, S, aux, sg);
         const int acc = decide(p, u_acc, wp, w, adj);  // every lane of the sub-group holds the same inputs
         if (sl == 0 && valid) {
-            if (acc) p.weight[slot] = wp;
+            if (acc) {
+                p.weight[slot] = wp;
+                if (RES) w_s[pl] = wp;
+            }
             if (p.trace) {
                 p.tr_idx[slot * 4 + 0] = kind; p.tr_idx[slot * 4 + 1] = i0;
                 p.tr_idx[slot * 4 + 2] = i1; p.tr_idx[slot * 4 + 3] = i2;
@@ -1117,6 +1172,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
         }
         if (valid) {
             double* trow = p.theta + slot * D;
+            double* lrow = tile + (size_t)pl * D;  // RES: the group's copy in LDS moves with it
             double* hrow = (p.store_row >= 0) ? p.hist + ((size_t)p.store_row * p.P + slot) * D : nullptr;
             const double* th = scr + sub * scr_stride;
             if (acc || hrow)
@@ -1127,9 +1183,11 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
                     const double v1 = has1 ? (acc ? th[j0 + 1] : pt[j0 + 1]) : 0.0;
                     if (even) {
                         if (acc) *reinterpret_cast<double2*>(trow + j0) = make_double2(v0, v1);  // utilities.jl:204
+                        if (RES && acc) *reinterpret_cast<double2*>(lrow + j0) = make_double2(v0, v1);
                         if (hrow) *reinterpret_cast<double2*>(hrow + j0) = make_double2(v0, v1);  // utilities.jl:170-180
                     } else {
                         if (acc) { trow[j0] = v0; if (has1) trow[j0 + 1] = v1; }
+                        if (RES && acc) { lrow[j0] = v0; if (has1) lrow[j0 + 1] = v1; }
                         if (hrow) { hrow[j0] = v0; if (has1) hrow[j0 + 1] = v1; }
                     }
                 }
@@ -1138,7 +1196,9 @@ __global__ __launch_bounds__(256, 2) void k_propose(KParams p) {
         __builtin_amdgcn_wave_barrier();  // scratch rows are reused by the same sub-group in the next pass
         if (pass == DEMC_STAMP_PASS || n_pass == 1) DEMC_STAMP(9);  // accept + row moves done
     }
-    DEMC_STAMP(10);  // kernel end
+    if (RES) __syncthreads();  // the other colour reads what this phase wrote (rows, weights); scratch and plan are reused
+    DEMC_STAMP(10);  // end of the step (of the kernel in the one-phase form)
+    }  // step
 }
 
 // ------------------------------------------------------------------------------------------------

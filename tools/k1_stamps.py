@@ -31,7 +31,7 @@ eng = demc_amd.HipEngine(n_groups=a.n_groups, Np=a.Np, D=a.dim, n_rows=40, sched
 bench.configure(eng, prob, a.dim)
 eng.set_state(bench.init_theta(a.n_groups * a.Np, a.dim, 0))
 eng.step(1, 30)
-n_wg = min(512, (a.n_groups * a.Np) // 16)
+n_wg = min(512, (a.n_groups * a.Np) // 16) if os.environ.get('DEMC_RESIDENT') == '0' else a.n_groups  # resident: one per group
 full = eng.get_trace()["w_prop"][: n_wg * 16].reshape(n_wg, 16)
 full = full[full[:, 10] > 0]
 t = full[:, :11]
