@@ -35,6 +35,8 @@ def measured_traffic(kernel, a):
     path = os.path.join(ROOT, "profiles", "r01", f"bench_cfg3_{a.mode}_pmc.json")
     try:
         rec = json.load(open(path))[kernel]
+        if "bytes" in rec:  # already reduced by tools/collect_profiles.py (e.g. per iteration for the resident K1)
+            return float(rec["bytes"])
         return (2.0 * rec["FETCH_SIZE_KB_mean"] + rec["WRITE_SIZE_KB_mean"]) * 1024.0
     except (OSError, KeyError):
         return None
@@ -208,13 +210,21 @@ def main():
                             traffic=measured_traffic("demc::k_cross_mfma<8, 4>", a),
                             launch_ms=t_launch * 1e3, executed_tflops=2.0 * N * d * units / t_launch / 1e12)
         else:
-            t_launch = (tm["propose"]["ms"] + tm["loglike_prep"]["ms"] + tm["accept_store"]["ms"]) / max(
-                1, tm["propose"]["launches"]) * 1e-3
-            byts = (24.0 * d + 17.0) * units  # algorithmic bytes per particle-update
-            ach = byts / t_launch / 1e9
-            roofline = dict(bound="hbm", kernel="k_propose with fused prep/accept/store tail (one launch per colour phase)", achieved=ach,
-                            peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
-                            traffic=measured_traffic("demc::k_propose<true>", a), launch_ms=t_launch * 1e3)
+            # fused K1 does the whole update.  Resident form: ONE launch runs all k iterations (both colour phases each), so
+            # the rate is taken over the iterations, not per launch; launch_ms and updates_per_launch say what one launch was.
+            t_total = (tm["propose"]["ms"] + tm["loglike_prep"]["ms"] + tm["accept_store"]["ms"]) * 1e-3
+            launches = max(1, tm["propose"]["launches"])
+            byts = (24.0 * d + 17.0) * P * k  # algorithmic bytes per particle-update x updates in the k iterations
+            ach = byts / t_total / 1e9
+            resident = launches < phases * k
+            tr = measured_traffic("k_propose_fused_per_iteration", a)
+            roofline = dict(bound="hbm",
+                            kernel="k_propose, fused prep/accept/store tail, " +
+                                   ("resident form (one launch per run of iterations between migrations)" if resident
+                                    else "one launch per colour phase"),
+                            achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
+                            traffic=None if tr is None else tr * k / launches, launch_ms=t_total / launches * 1e3,
+                            updates_per_launch=P * k / launches)
         roofline["per_kernel_ms_per_iter"] = {n: v["ms"] / k for n, v in tm.items()}
 
     cpu = None

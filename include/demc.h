@@ -120,8 +120,13 @@ typedef struct demc_config {
     int32_t device_id;
     int32_t loglike_mode;
     int32_t trace;           /* 1: keep the per-slot diagnostic trace readable by demc_get_trace (tests) */
-    int32_t fuse;            /* 0: auto (one fused kernel per colour phase when the likelihood allows: MvNormal in
-                                SUFFSTAT mode, Gaussian / Binomial with few observations); 1: never */
+    int32_t fuse;            /* 0: auto -- when the likelihood allows (MvNormal in SUFFSTAT mode, Gaussian / Binomial with
+                                few observations) the whole update runs inside the proposal kernel, and with two_colour
+                                and the group in LDS that kernel stays resident: one launch runs every iteration up to
+                                the next migration; 1: never fuse (proposal, likelihood, accept as separate kernels);
+                                2: fuse, but one launch per colour phase (no resident form).  Same samples in all three; a
+                                log-density can differ in its last bits between them (a particle may be split over a
+                                different number of lanes, which changes the order of the sums). */
 } demc_config;
 
 typedef struct demc_handle demc_handle;

@@ -215,21 +215,65 @@ def test_fused_tail_with_several_workgroups_per_group(demc, orc):
                    check_hist=False)
 
 
+def _run_fuse_mode(demc, prob, th0, fuse, G, Np, D, n_iter, blocks=None, **kw):
+    e = demc.HipEngine(n_groups=G, Np=Np, D=D, n_rows=n_iter, schedule=2, seed=3, fuse=fuse, n_blocks=0 if blocks is None else len(blocks),
+                       **kw)
+    setup_engine(e, prob)
+    if blocks is not None:
+        e.set_blocks(blocks)
+    e.set_state(th0)
+    e.step(1, n_iter)
+    out = e.get_history(0, n_iter) + e.get_state()
+    e.close()
+    return out
+
+
 def test_fused_equals_unfused(demc):
-    """the fused tail is an implementation detail: same bits as K1 -> K3"""
+    """the fused tail and the resident form are implementation details: fuse = 0 (resident K1: one launch per run of
+    iterations between migrations), 2 (one fused launch per colour phase) and 1 (K1 -> K3) give the same bits"""
     prob = make_problem("mvn_full", np.random.default_rng(22), N=400, d=10)
     th0 = prob["init"](6 * 20)
-    hs = []
-    for fuse in (0, 1):
-        e = demc.HipEngine(n_groups=6, Np=20, D=10, n_rows=25, schedule=2, seed=3, loglike_mode=1, fuse=fuse,
-                           theta_snooker=0.1, alpha=0.3, burnin=10)
-        setup_engine(e, prob)
-        e.set_state(th0)
-        e.step(1, 25)
-        hs.append(e.get_history(0, 25) + e.get_state())
-        e.close()
-    for a, b in zip(*hs):
-        assert np.array_equal(a, b)
+    hs = [_run_fuse_mode(demc, prob, th0, fuse, 6, 20, 10, 25, loglike_mode=1, theta_snooker=0.1, alpha=0.3, burnin=10)
+          for fuse in (0, 2, 1)]
+    for other in hs[1:]:
+        for a, b in zip(hs[0], other):
+            assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("family,Np,d,kw", [
+    ("mvn_full", 256, 32, dict(loglike_mode=1)),                    # 512-thread workgroups, one pass per phase, MFMA prep
+    ("mvn_full", 301, 16, dict(loglike_mode=1, theta_snooker=0.3)),  # odd Np: halves of 150 / 151, two passes
+    ("mvn_iso", 64, 9, dict(loglike_mode=1, kappa=0.7)),            # odd D (no LDS-DMA), recombination
+    ("gaussian", 10, 2, dict()),                                    # in-kernel observation loop, one lane per particle
+    ("binomial", 33, 1, dict(beta=0.5)),                            # mutation in half of the groups
+])
+def test_resident_form_equals_one_launch_per_phase(demc, family, Np, d, kw):
+    """fuse = 0 runs every iteration between two migrations inside ONE launch with the group resident in LDS; fuse = 2
+    launches once per colour phase.  Same samples, acceptances and ids, across migrations (alpha = 0.3) and burn-in."""
+    prob = make_problem(family, np.random.default_rng(61), N=200, d=d)
+    D = prob["D"]
+    th0 = prob["init"](5 * Np)
+    a, b = (_run_fuse_mode(demc, prob, th0, fuse, 5, Np, D, 30, alpha=0.3, burnin=12, **kw) for fuse in (0, 2))
+    # (theta_hist, accept_hist, lp_hist, id_hist, theta, weight, id).  The two forms may split a particle over a different
+    # number of lanes, i.e. form its sums in a different order: log-densities agree to rounding, and so do snooker
+    # proposals (their projection is such a sum, utilities.jl:239-246); acceptances, ids and crossover samples exactly.
+    for i, (x, y) in enumerate(zip(a, b)):
+        if i in (2, 5):
+            np.testing.assert_allclose(x, y, rtol=1e-11)
+        elif i in (0, 4) and kw.get("theta_snooker", 0.0) > 0.0:
+            np.testing.assert_allclose(x, y, rtol=0, atol=1e-11)
+        else:
+            assert np.array_equal(x, y)
+
+
+def test_resident_form_with_block_updates(demc):
+    """block_update! (main.jl:174-179): several masked sweeps per iteration, all inside the resident launch"""
+    prob = make_problem("mvn_full", np.random.default_rng(62), N=150, d=6)
+    blocks = np.array([[1, 1, 0, 0, 0, 0], [0, 0, 1, 1, 1, 1]], np.uint8)
+    th0 = prob["init"](4 * 24)
+    a, b = (_run_fuse_mode(demc, prob, th0, fuse, 4, 24, 6, 20, blocks=blocks, alpha=0.2, burnin=8, loglike_mode=1) for fuse in (0, 2))
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
 
 
 def test_rejects_unsupported(demc):
