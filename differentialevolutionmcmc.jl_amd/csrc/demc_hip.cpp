@@ -67,6 +67,7 @@ struct demc_handle {
     int lpp = 1;
     int tile_in_lds = 0;
     size_t k1_lds = 0, k1_tile_bytes = 0, k1_scr_bytes = 0;
+    bool hier_scr = false;  // hierarchical family whose theta' scratch fits in LDS
     bool res_ok = false;  // resident K1 (plan_resident)
     int res_lpp = 0, res_wg = 0, res_scr_doubles = 0;
     size_t res_lds = 0;
@@ -320,8 +321,12 @@ void set_tail_flags(demc_handle* h, KParams& k) {
     k.sx = (k.fuse_prep && suff) ? h->sx : nullptr;
     k.Ainv = (h->family == FAM_MVN_FULL) ? h->Ainv : nullptr;
     // small-N scalar-data families: the sub-group of a particle sums the per-observation terms itself
-    const bool cheap_obs = (h->family == FAM_GAUSSIAN || h->family == FAM_BINOMIAL || h->family == FAM_RASTRIGIN) &&
-                           h->N / k.lpp <= 512;
+    // (hierarchical families: one term per subject, i.e. O(D) like the proposal itself; their Gaussian form has p.d
+    // observations behind every subject)
+    const long long obs_work = (h->family == FAM_HIER_GAUSSIAN) ? h->N * (h->d > 0 ? h->d : 1) : h->N;
+    const bool cheap_obs = ((h->family == FAM_GAUSSIAN || h->family == FAM_BINOMIAL || h->family == FAM_RASTRIGIN) &&
+                            h->N / k.lpp <= 512) ||
+                           (h->hier_scr && obs_work / k.lpp <= 4096);
     const bool phase_private = c.schedule == DEMC_SCHED_TWO_COLOUR || k.mode == MODE_IDENT;  // nothing read can move
     k.fuse_obs = (cheap_obs && phase_private && c.fuse != 1) ? 1 : 0;
     k.fuse_accept = (((k.fuse_prep && suff) || k.fuse_obs) && c.fuse != 1 && phase_private) ? 1 : 0;
@@ -471,8 +476,12 @@ int size_k1_lds(demc_handle* h) {
     const size_t cdf = ((size_t)c.Np + ((size_t)c.Np + 15) / 16) * sizeof(double);
     const size_t ainv = (h->family == FAM_MVN_FULL) ? (size_t)h->d * h->d * sizeof(double) : 0;
     const size_t xb = is_mvn(h->family) ? (size_t)h->d * sizeof(double) : 0;
-    const bool scr_fam = is_mvn(h->family) || h->family == FAM_GAUSSIAN || h->family == FAM_BINOMIAL || h->family == FAM_RASTRIGIN;
-    const size_t scr = scr_fam ? (size_t)(256 / (h->lpp > 256 ? 256 : h->lpp)) * (D + 2) * sizeof(double) : 0;
+    const size_t scr_rows = (size_t)(256 / (h->lpp > 256 ? 256 : h->lpp)) * (D + 2) * sizeof(double);
+    const bool hier = h->family == FAM_HIER_BINOMIAL || h->family == FAM_HIER_GAUSSIAN;
+    h->hier_scr = hier && scr_rows <= 96 * 1024;  // theta' of the pass fits in LDS: the subjects can be summed in K1
+    const bool scr_fam = is_mvn(h->family) || h->family == FAM_GAUSSIAN || h->family == FAM_BINOMIAL ||
+                         h->family == FAM_RASTRIGIN || h->hier_scr;
+    const size_t scr = scr_fam ? scr_rows : 0;
     const size_t tile = (size_t)c.Np * D * sizeof(double);
     h->tile_in_lds = (tile + cdf + ainv + xb + scr <= 96 * 1024) ? 1 : 0;
     if (const char* e = std::getenv("DEMC_K1_TILE")) h->tile_in_lds = (e[0] == '1') && h->tile_in_lds;  // A/B experiments

@@ -268,6 +268,28 @@ __device__ inline double obs_range_sum(const KParams& p, const double* th, long 
                 acc += ll;
             }
         } break;
+        case FAM_HIER_BINOMIAL: {  // k_s ~ Binomial(n, logistic(mu_b0 + b0_s)) (BASELINE cfg4); "observation" = subject
+            const double mu0 = th[0], n = p.c0;
+            const double* lgc = p.data + p.N;
+            for (long long s = i0; s < i1; s += stride) {
+                const double eta = mu0 + th[2 + s], k = p.data[s];
+                acc += lgc[s] - k * softplus(-eta) - (n - k) * softplus(eta);
+            }
+        } break;
+        case FAM_HIER_GAUSSIAN: {  // Hierarchical_Example.jl:36-44
+            const double mu0 = th[0], sg = th[2 + p.N];
+            const int n = p.d;
+            const double lsg = log(sg), isg = 1.0 / sg;
+            for (long long s = i0; s < i1; s += stride) {
+                const double mu = mu0 + th[2 + s];
+                double l = 0.0;
+                for (int i = 0; i < n; ++i) {
+                    const double z = (p.data[s * n + i] - mu) * isg;
+                    l += -(z * z + kLog2Pi) / 2.0 - lsg;
+                }
+                acc += l;
+            }
+        } break;
         case FAM_RASTRIGIN: {  // optimization_tests.jl:15-23
             if (i0 == 0) {
                 acc = 10.0 * p.D;
@@ -1113,9 +1135,11 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
 
         if (pass == DEMC_STAMP_PASS || n_pass == 1) DEMC_STAMP(7);  // MvNormal preparation done
         if (FUSE_OBS) {
-            // small-N scalar-data families: the sub-group visits every observation itself (lanes stride over them)
+            // small-N scalar-data families (and the hierarchical ones, whose "observations" are the subjects): the
+            // sub-group visits every observation itself (lanes stride over them), reading theta' from its scratch row
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if (lpp > 64) __syncthreads();  // the row was written by all four waves
             S = group_sum(obs_range_sum(p, scr + sub * scr_stride, sl, p.N, lpp, nullptr), lpp, s_gsum);
         }
 
@@ -1194,6 +1218,7 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();  // scratch rows are reused by the same sub-group in the next pass
+        if (lpp > 64 && use_scr) __syncthreads();
         if (pass == DEMC_STAMP_PASS || n_pass == 1) DEMC_STAMP(9);  // accept + row moves done
     }
     if (RES) __syncthreads();  // the other colour reads what this phase wrote (rows, weights); scratch and plan are reused
