@@ -852,6 +852,12 @@ int32_t demc_set_model_source(demc_handle* h, const char* hip_source, const doub
     return size_k1_lds(h);
 }
 
+int upload_dimtab(demc_handle* h) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->dimtab, h->h_tab.data(), (size_t)h->c.D * sizeof(DimTab), hipMemcpyHostToDevice));
+    return DEMC_OK;
+}
+
 int32_t demc_set_priors(demc_handle* h, const int32_t* kind, const double* a, const double* b, const int32_t* ref) {
     if (!h || !kind) return DEMC_EINVAL;
     USE_DEVICE(h);
@@ -873,9 +879,7 @@ int32_t demc_set_priors(demc_handle* h, const int32_t* kind, const double* a, co
         t.b = recip ? 1.0 / bj : bj;
         t.c = prior_const(kind[j], aj, bj);
     }
-    HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(h->dimtab, h->h_tab.data(), D * sizeof(DimTab), hipMemcpyHostToDevice));
-    return DEMC_OK;
+    return upload_dimtab(h);
 }
 
 int32_t demc_set_bounds(demc_handle* h, const double* lo, const double* hi) {
@@ -886,9 +890,7 @@ int32_t demc_set_bounds(demc_handle* h, const double* lo, const double* hi) {
         h->h_tab[j].lo = lo[j];
         h->h_tab[j].hi = hi[j];
     }
-    HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(h->dimtab, h->h_tab.data(), D * sizeof(DimTab), hipMemcpyHostToDevice));
-    return DEMC_OK;
+    return upload_dimtab(h);
 }
 
 int32_t demc_set_blocks(demc_handle* h, const uint8_t* masks, int32_t n_blocks) {

@@ -273,7 +273,8 @@ __device__ inline double obs_range_sum(const KParams& p, const double* th, long 
             const double* lgc = p.data + p.N;
             for (long long s = i0; s < i1; s += stride) {
                 const double eta = mu0 + th[2 + s], k = p.data[s];
-                acc += lgc[s] - k * softplus(-eta) - (n - k) * softplus(eta);
+                // k log p + (n-k) log(1-p), p = logistic(eta): softplus(eta) = eta + softplus(-eta), so ONE softplus per subject
+                acc += lgc[s] - n * softplus(-eta) - (n - k) * eta;
             }
         } break;
         case FAM_HIER_GAUSSIAN: {  // Hierarchical_Example.jl:36-44
@@ -1353,7 +1354,7 @@ __global__ __launch_bounds__(256) void k_hier_loglike(KParams p) {
         const double* lgc = p.data + S;
         for (long long s = tid; s < S; s += 256) {
             const double eta = mu0 + th[2 + s], k = p.data[s];
-            acc += lgc[s] - k * softplus(-eta) - (n - k) * softplus(eta);
+            acc += lgc[s] - n * softplus(-eta) - (n - k) * eta;  // softplus(eta) = eta + softplus(-eta)
         }
     } else {  // FAM_HIER_GAUSSIAN  Hierarchical_Example.jl:36-44
         const double mu0 = th[0], sg = th[2 + S];
