@@ -137,4 +137,28 @@ function sample(model::DEModel, de::DE, b::HIPBackend, n_iter::Int; model_spec::
     return bundle_samples(model, de, [particles], n_iter)                   # src/main.jl:222-250, unchanged
 end
 
+"""
+    host_migration!(h, de, P)
+
+`migration!` (src/migration.jl:11-19) with the reference's OWN random choices kept on the host: the weights come back
+through `demc_get_weights`, `select_groups` / `select_particles` run unchanged on them (they only look at
+`Particle.weight`), and only `shift_particles!` (:84-91) happens on the device through `demc_apply_migration`.
+For callers that want the package's task-local RNG stream to decide who migrates (e.g. to compare runs with the CPU
+path); the default `sample` method above leaves the whole exchange on the device (`demc_step`).
+"""
+function host_migration!(h, de::DE, P::Int)  # P = de.n_groups * de.Np
+    w = Vector{Float64}(undef, P)
+    check(h, @ccall LIB.demc_get_weights(h::Ptr{Cvoid}, w::Ptr{Float64})::Int32)
+    # stand-in particles carrying only what selection reads; groups are contiguous blocks of Np slots
+    groups = [[DifferentialEvolutionMCMC.Particle(Θ = [0.0], weight = w[(g - 1) * de.Np + p]) for p = 1:de.Np] for g = 1:de.n_groups]
+    sub_group = DifferentialEvolutionMCMC.select_groups(de, groups)                       # migration.jl:31-35
+    p_idx, _ = DifferentialEvolutionMCMC.select_particles(sub_group)                       # migration.jl:46-54
+    g_idx = [findfirst(x -> x === sg, groups) for sg in sub_group]
+    slots = Int32[(g_idx[i] - 1) * de.Np + (p_idx[i] - 1) for i in eachindex(g_idx)]      # 0-based local slots
+    src = circshift(slots, 1)                                                              # shift_particles! :84-91
+    check(h, @ccall LIB.demc_apply_migration(h::Ptr{Cvoid}, src::Ptr{Int32}, slots::Ptr{Int32}, Int32(length(slots))::Int32)::Int32)
+    return nothing
+end
+# driver loop for that mode: `rand() <= de.α && host_migration!(h, de, P); demc_update(h, iter, 1)` per iteration
+
 end # module
