@@ -1,18 +1,20 @@
 // demc_kernels.hpp -- hand-written gfx950 kernels of the DE-MCMC hot path.
 //
-//   K1  k_propose<TILE>  crossover!/snooker_update!/mutation!/recombination!/reset!/in_bounds + prior
+//   K1  k_propose<WG,TILE,TAIL,RES>  crossover!/snooker_update!/mutation!/recombination!/reset!/in_bounds + prior
 //                        (crossover.jl:30-99,154-257,301-352; mutation.jl:13-25; utilities.jl:70-78)
 //       (fused tails)    MvNormal preparation y = A^-1 (theta' - xbar), a = (theta' - xbar).y; optionally the whole
-//                        accept/store when the likelihood needs no pass over the data (SUFFSTAT, two_colour)
+//                        accept/store when the likelihood needs no separate pass over the data (SUFFSTAT, small N,
+//                        hierarchical families; two_colour) -- then also as a RESIDENT kernel that runs every
+//                        iteration up to the next migration with the group held in LDS
 //   K2  k_cross_mfma     S_p = sum_i y_p . x~_i over all observations on v_mfma_f64_16x16x4_f64
 //       k_obs_loglike    thread-per-proposal streaming likelihoods (Gaussian, Binomial, LBA, LNR, rastrigin)
-//       k_hier_loglike   workgroup-per-proposal likelihoods whose cost is O(D) (hierarchical families)
+//       k_hier_loglike   workgroup-per-proposal likelihoods whose cost is O(D) (hierarchical families, unfused form)
 //   K3  k_accept_store   compute_posterior! finalisation + mh_update!/maximize!/minimize! + store_samples!
 //                        (utilities.jl:92-99,161-180,201-226)
 //   M   k_mig_pack / k_mig_apply   select_particle / select_groups + shift_particles! (migration.jl:31-91)
 //
 // Wave = 64 lanes everywhere.  A particle is handled by a power-of-two sub-group of LPP lanes
-// (LPP = lanes per particle, chosen on the host from D) so that rows of theta are read and written
+// (LPP = lanes per particle, chosen on the host from D and the population size) so that rows of theta are read and written
 // as contiguous segments; every lane owns dims {2k, 2k+1} for k = sl, sl+LPP, ... which is also
 // the granularity of one Philox block (two 53-bit uniforms).
 #pragma once
@@ -315,24 +317,25 @@ __device__ inline int decide(const KParams& p, double u, double wp, double w, do
 
 // ------------------------------------------------------------------------------------------------
 // K1: proposals.  grid = n_groups x n_split workgroups; workgroup (g, sp) proposes for a slice of the
-// active particles of group g.  TILE = true: the group tile [Np][D] is staged in LDS and every partner /
-// base / current row is read from there (partner rows never re-read HBM); TILE = false (tile too large, or
-// history partners): rows come from theta / hist in HBM-L2.  Either way a phase-start snapshot: in the
+// active particles of group g.  TILE = true: the partner pool of the phase (plus the workgroup's own moving rows) is
+// staged in LDS and every partner / base / current row is read from there (partner rows never re-read HBM); TILE = false
+// (tile too large, or history partners): rows come from theta / hist in HBM-L2.  Either way a phase-start snapshot: in the
 // unfused path theta is only written by K3, and in the fused path (two_colour) a phase writes active rows only
 // while partners come from the other colour.
 //
-// Instruction economy (the kernel is issue-bound, not bandwidth-bound, at D = 32):
-//   - the per-particle Philox blocks (snooker/base, indices, gammas, accept, history cells) are evaluated ONCE per
-//     sub-group: lane b of the sub-group computes block b, the words are handed out with shuffles;
-//   - one noise block per lane covers its two dims; per-dimension constants come packed in one 48-byte DimTab;
+// Instruction economy (at D = 32 the pass is bound by VALU issue and latency, not by bandwidth):
+//   - everything that is one value per PARTICLE (Philox blocks for snooker/base, indices, gammas, accept) is drawn
+//     ONCE, four lanes per particle, in the plan stage and read back from LDS by the particle's lanes; without a plan
+//     lane b of the sub-group computes block b and the words are handed out on the DPP network;
+//   - one noise block per lane and dim pair; per-dimension constants come packed in one 48-byte DimTab;
 //   - no FP64 division in the per-dimension path (reciprocal scales are precomputed on the host).
 //
-// Optional fused tails (uniform flags, no divergence):
-//   fuse_prep   (MvNormal families): y = A^-1 theta' and a = theta'.y from an LDS copy of theta' and A^-1;
-//               SUFFSTAT mode also forms S = y . sum_i x_i here.
-//   fuse_accept (likelihoods that are O(D^2) given data-only statistics, two_colour schedule): finishes the
-//               whole update -- prior + loglike, Metropolis accept, theta/weight write-back and the history
-//               row -- so that one launch per colour phase is the entire DE-MCMC sweep.
+// Fused tails (one kernel instance each, template TAIL):
+//   TAIL_PREP / TAIL_PREP_MFMA (MvNormal families): y = A^-1 theta~ and a = theta~.y from an LDS copy of theta' and A^-1
+//               (on the matrix cores for d <= 32); SUFFSTAT mode also forms S = y . sum_i x~_i here.
+//   TAIL_OBS    (few observations, or one term per scalar): the particle's lanes sum the per-observation terms.
+//   fuse_accept (a tail that leaves nothing for K2, two_colour schedule): finishes the whole update -- prior +
+//               loglike, Metropolis accept, theta/weight write-back and the history row -- in the same launch.
 // ------------------------------------------------------------------------------------------------
 template <int B>
 __device__ inline U4 bcast_u4(const U4& v, int lpp, int sub_base) {
@@ -622,7 +625,6 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
             if (lane + 64 * k < n_cdf) cdf[lane + 64 * k] = exp(wv[k] - m);
         for (int i = lane + 256; i < n_cdf; i += 64) cdf[i] = exp(pw[i] - m);
         wave_lds_sync();
-        if (RES) DEMC_STAMP(14);  // (diagnostic, resident form) exponentials written
         const int n_chunk = (n_cdf + 15) >> 4;
         double* ctot = cdf + Np;
         for (int c = lane; c < n_chunk; c += 64) {
@@ -642,7 +644,6 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
             ctot[c] = pre;
         }
         wave_lds_sync();
-        if (RES) DEMC_STAMP(15);  // (diagnostic, resident form) chunk scans done
         if (lane == 0) {  // chunk offsets, left to right, eight totals per round trip
             double off = 0.0;
             for (int c0 = 0; c0 < n_chunk; c0 += 8) {
