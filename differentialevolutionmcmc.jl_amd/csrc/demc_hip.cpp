@@ -1004,8 +1004,8 @@ static int32_t step_impl(demc_handle* h, int64_t iter0, int32_t n_iters, bool wi
             migration_enqueue(h, iter, h->mig_rows, h->mig_rows, true, true);
         }
         if (h->res_ok) {  // every iteration up to the next migration in one launch
-            int run = 1;
-            while (iter + run < iter0 + n_iters && !(with_migration && demc_migration_due(&c, iter + run))) ++run;
+            int run = 1;  // capped so that a single launch stays in the millisecond range whatever the caller asks for
+            while (run < 1024 && iter + run < iter0 + n_iters && !(with_migration && demc_migration_due(&c, iter + run))) ++run;
             int rc = launch_resident(h, iter, run);
             if (rc != DEMC_OK) return rc;
             iter += run - 1;
