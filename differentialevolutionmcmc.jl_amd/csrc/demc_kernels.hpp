@@ -1163,6 +1163,7 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if (lpp > 64 && use_scr) __syncthreads();  // (workgroup-wide particle) same hand-over as at the end of the pass
             continue;
         }
 
