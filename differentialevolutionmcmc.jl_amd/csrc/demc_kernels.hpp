@@ -422,7 +422,11 @@ __device__ inline double prior_term(const DimTab& t, double x, double inv_sref, 
 // because a wave's memory operations retire in issue order.
 __device__ inline void lds_dma16(const double* g, double* l) {
     const uint32_t lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) void*)l);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory", "m0");
+    uint32_t saved_m0;  // M0 carries the LDS address of the copy; put back what the compiler may have had in it
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(saved_m0)
+                 : "v"(g), "s"(lds_addr)
+                 : "memory");
 }
 
 // max over the 64 lanes of a wave, returned to all of them: butterfly inside the 16-lane rows on the DPP network, then
