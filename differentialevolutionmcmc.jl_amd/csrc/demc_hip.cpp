@@ -300,13 +300,13 @@ bool is_mvn(int fam) { return fam == FAM_MVN_FULL || fam == FAM_MVN_ISO; }
 
 // the K1 instance for (tile in LDS?, fused tail)
 using K1Fn = void (*)(KParams);
-K1Fn k1_instance(bool tile, int tail) {
-    static const K1Fn tab[2][4] = {
-        {k_propose<256, false, TAIL_NONE, false>, k_propose<256, false, TAIL_PREP, false>,
-         k_propose<256, false, TAIL_PREP_MFMA, false>, k_propose<256, false, TAIL_OBS, false>},
-        {k_propose<256, true, TAIL_NONE, false>, k_propose<256, true, TAIL_PREP, false>,
-         k_propose<256, true, TAIL_PREP_MFMA, false>, k_propose<256, true, TAIL_OBS, false>}};
-    return tab[tile ? 1 : 0][tail];
+K1Fn k1_instance(bool tile, int tail, bool plain) {
+#define K1_ROW(TILE, RES_, PLAIN_)                                                                                   \
+    {k_propose<256, TILE, TAIL_NONE, RES_, PLAIN_>, k_propose<256, TILE, TAIL_PREP, RES_, PLAIN_>,                   \
+     k_propose<256, TILE, TAIL_PREP_MFMA, RES_, PLAIN_>, k_propose<256, TILE, TAIL_OBS, RES_, PLAIN_>}
+    static const K1Fn tab[3][4] = {K1_ROW(false, false, false), K1_ROW(true, false, false), K1_ROW(true, false, true)};
+#undef K1_ROW
+    return tab[tile ? (plain ? 2 : 1) : 0][tail];  // the plain instance exists for the LDS-tile forms only
 }
 
 // which tail K1 carries for this model, mode and schedule
@@ -331,6 +331,12 @@ void set_tail_flags(demc_handle* h, KParams& k) {
     k.fuse_obs = (cheap_obs && phase_private && c.fuse != 1) ? 1 : 0;
     k.fuse_accept = (((k.fuse_prep && suff) || k.fuse_obs) && c.fuse != 1 && phase_private) ? 1 : 0;
     k.write_prop = (!k.fuse_accept || k.trace) ? 1 : 0;
+}
+// the default sampler and nothing else: K1 has an instance with every other branch compiled out
+bool is_plain(const demc_handle* h, const KParams& k) {
+    const demc_config& c = h->c;
+    return k.mode == MODE_STEP && c.proposal_kind == 0 && c.partner_kind == DEMC_PARTNER_CURRENT && c.update_kind == 0 &&
+           c.fitness_kind == 0 && c.theta_snooker == 0.0 && c.kappa == 1.0 && c.n_blocks == 0 && !k.trace;
 }
 int tail_of(const KParams& k) { return k.prep_mfma ? TAIL_PREP_MFMA : k.fuse_prep ? TAIL_PREP : k.fuse_obs ? TAIL_OBS : TAIL_NONE; }
 
@@ -360,7 +366,7 @@ int launch_phase(demc_handle* h, KParams& k) {
     tick(h, 0, true);
     const int tail = tail_of(k);
     const size_t lds = tile ? lds_tile + (k.plan ? plan_bytes : 0) : h->k1_lds - h->k1_tile_bytes;
-    hipLaunchKernelGGL(k1_instance(tile, tail), dim3(k.n_groups * n_split), dim3(256), lds, h->stream, k);
+    hipLaunchKernelGGL(k1_instance(tile, tail, is_plain(h, k)), dim3(k.n_groups * n_split), dim3(256), lds, h->stream, k);
     tick(h, 0, false);
     if (k.fuse_accept) return DEMC_OK;
     int rc = launch_loglike(h, k);
@@ -372,13 +378,13 @@ int launch_phase(demc_handle* h, KParams& k) {
 }
 
 // ---- resident form of K1: one workgroup per group, both colour phases of several iterations in one launch ----
-K1Fn k1_resident_instance(int wg, int tail) {
-    static const K1Fn tab[2][4] = {
-        {k_propose<256, true, TAIL_NONE, true>, k_propose<256, true, TAIL_PREP, true>, k_propose<256, true, TAIL_PREP_MFMA, true>,
-         k_propose<256, true, TAIL_OBS, true>},
-        {k_propose<512, true, TAIL_NONE, true>, k_propose<512, true, TAIL_PREP, true>, k_propose<512, true, TAIL_PREP_MFMA, true>,
-         k_propose<512, true, TAIL_OBS, true>}};
-    return tab[wg == 512 ? 1 : 0][tail];
+K1Fn k1_resident_instance(int wg, int tail, bool plain) {
+#define K1_ROW(WG_, PLAIN_)                                                                                      \
+    {k_propose<WG_, true, TAIL_NONE, true, PLAIN_>, k_propose<WG_, true, TAIL_PREP, true, PLAIN_>,               \
+     k_propose<WG_, true, TAIL_PREP_MFMA, true, PLAIN_>, k_propose<WG_, true, TAIL_OBS, true, PLAIN_>}
+    static const K1Fn tab[4][4] = {K1_ROW(256, false), K1_ROW(512, false), K1_ROW(256, true), K1_ROW(512, true)};
+#undef K1_ROW
+    return tab[(wg == 512 ? 1 : 0) + (plain ? 2 : 0)][tail];
 }
 
 // Decides once per model whether the resident form applies and with which geometry (lanes per particle, workgroup size,
@@ -424,7 +430,8 @@ int launch_resident(demc_handle* h, long long iter0, int n_iters) {
     k.plan = (k.lpp >= 4) ? 1 : 0;
     if (const char* e = std::getenv("DEMC_K1_PLAN")) k.plan = k.plan && e[0] == '1';  // A/B experiments
     tick(h, 0, true);
-    hipLaunchKernelGGL(k1_resident_instance(h->res_wg, tail_of(k)), dim3(k.n_groups), dim3(h->res_wg), h->res_lds, h->stream, k);
+    hipLaunchKernelGGL(k1_resident_instance(h->res_wg, tail_of(k), is_plain(h, k)), dim3(k.n_groups), dim3(h->res_wg), h->res_lds,
+                       h->stream, k);
     tick(h, 0, false);
     return DEMC_OK;
 }
@@ -492,12 +499,13 @@ int size_k1_lds(demc_handle* h) {
     // the attribute is per function, not per handle: always raise it to the same ceiling so that handles of different
     // sizes in one process do not lower each other's limit
     for (int t = 0; t < 2; ++t)
-        for (int tail = 0; tail < 4; ++tail) {
-            HIPCHK(hipFuncSetAttribute((const void*)k1_instance(t != 0, tail), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)kMaxDynLds));
-            HIPCHK(hipFuncSetAttribute((const void*)k1_resident_instance(t ? 512 : 256, tail),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
-        }
+        for (int tail = 0; tail < 4; ++tail)
+            for (int plain = 0; plain < 2; ++plain) {
+                HIPCHK(hipFuncSetAttribute((const void*)k1_instance(t != 0, tail, plain != 0),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
+                HIPCHK(hipFuncSetAttribute((const void*)k1_resident_instance(t ? 512 : 256, tail, plain != 0),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
+            }
     plan_resident(h);
     HIPCHK(hipFuncSetAttribute((const void*)k_mig_pack, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
     return DEMC_OK;

@@ -307,10 +307,13 @@ __device__ inline double obs_range_sum(const KParams& p, const double* th, long 
 
 // mh_update! / maximize! / minimize! decision for one particle (utilities.jl:55-58, 201-226)
 // u = the particle's accept uniform (Philox block 3 of its PART stream)
+template <bool PLAIN = false>
 __device__ inline int decide(const KParams& p, double u, double wp, double w, double adj) {
     if (p.mode == MODE_IDENT) return 1;
-    if (p.update_kind == 1) return wp > w;
-    if (p.update_kind == 2) return wp < w;
+    if (!PLAIN) {
+        if (p.update_kind == 1) return wp > w;
+        if (p.update_kind == 2) return wp < w;
+    }
     const double e = exp(wp - w + adj);  // min(1, NaN) = NaN in Julia -> `rand() <= NaN` is false -> reject
     return (e >= 1.0) || (u <= e);
 }
@@ -467,7 +470,9 @@ enum K1Tail : int { TAIL_NONE = 0, TAIL_PREP = 1, TAIL_PREP_MFMA = 2, TAIL_OBS =
 // written to the LDS copy and through to HBM, a workgroup barrier separates the phases.  Groups never interact inside
 // update! (main.jl:135-167), so nothing else is needed between two migrations.  Requires the fused accept tail,
 // two_colour, current-population partners.  RES = false is the one-phase-per-launch form with n_split workgroups per group.
-template <int WG, bool TILE, int TAIL, bool RES>
+// PLAIN = the default sampler and nothing else (random_gamma, no snooker, kappa = 1, no block masks, posterior + Metropolis,
+// no trace): the branches of everything else are compiled out of the instance (6 % at cfg3 SUFFSTAT).
+template <int WG, bool TILE, int TAIL, bool RES, bool PLAIN>
 __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
     constexpr bool FUSE_PREP = TAIL == TAIL_PREP || TAIL == TAIL_PREP_MFMA;
     constexpr bool PREP_MFMA = TAIL == TAIL_PREP_MFMA;
@@ -691,7 +696,7 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
                      ra = bcast_u4<3>(mine, 4, 0);
             const double u_snk = u53(r0.x, r0.y), u_base = u53(r0.z, r0.w);
             const double u_g1 = u53(rg.x, rg.y), u_g2 = u53(rg.z, rg.w);
-            const bool snooker = u_snk <= p.theta_snooker;  // crossover.jl:31
+            const bool snooker = !PLAIN && u_snk <= p.theta_snooker;  // crossover.jl:31
             int i0, i1, i2 = -1;
             double g1, g2 = 0.0;
             if (snooker) {
@@ -708,7 +713,7 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
                 } else
                     pick_pair(ri.x, ri.y, (uint32_t)p.pool_n, a, b);
                 i0 = (int)a + p.pool_lo; i1 = (int)b + p.pool_lo;
-                if (p.proposal_kind == 0) {
+                if (PLAIN || p.proposal_kind == 0) {
                     g1 = 0.5 + (1.0 - 0.5) * u_g1;  // crossover.jl:162
                     if (use_base) g2 = 0.5 + (1.0 - 0.5) * u_g2;
                 } else if (p.proposal_kind == 1)
@@ -822,7 +827,7 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
             i0 = plan_i[4 * ql + 1]; i1 = plan_i[4 * ql + 2]; i2 = plan_i[4 * ql + 3];
             g1 = plan_d[4 * ql + 0]; g2 = plan_d[4 * ql + 1]; u_acc = plan_d[4 * ql + 2];
             Pa = rows + (size_t)i0 * D; Pb2 = rows + (size_t)i1 * D;
-            if (kind == 1) {
+            if (!PLAIN && kind == 1) {
                 Pc = rows + (size_t)i2 * D;
                 // project(Pm,Pd), project(Pn,Pd): dots over all scalars (utilities.jl:239-246)
                 double vm = 0.0, vn = 0.0, vd = 0.0;
@@ -846,7 +851,7 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
             else {
                 const double u_snk = u53(r0.x, r0.y), u_base = u53(r0.z, r0.w);
                 const double u_g1 = u53(rg.x, rg.y), u_g2 = u53(rg.z, rg.w);
-                const bool snooker = u_snk <= p.theta_snooker;  // crossover.jl:31
+                const bool snooker = !PLAIN && u_snk <= p.theta_snooker;  // crossover.jl:31
                 kind = snooker ? 1 : 0;
                 if (hist_partners) {
                     // resample (crossover.jl:113-124): distinct cells of rows 1:(iter-1) x local particles
@@ -900,7 +905,7 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
                     vm = group_sum(vm, lpp, s_gsum); vn = group_sum(vn, lpp, s_gsum); vd = group_sum(vd, lpp, s_gsum);
                     cm = vm / vd; cn = vn / vd;
                 } else {
-                    if (p.proposal_kind == 0) {
+                    if (PLAIN || p.proposal_kind == 0) {
                         g1 = 0.5 + (1.0 - 0.5) * u_g1;  // crossover.jl:162
                         if (use_base) {
                             g2 = 0.5 + (1.0 - 0.5) * u_g2;
@@ -933,7 +938,7 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
         // crossover / snooker value of scalar j given its uniform (before recombination! / reset!)
         auto cross = [&](int j, double tj, double uu) -> double {
             const double bj = -eps + eps2 * uu;  // b = Uniform(-eps, eps) crossover.jl:166
-            if (kind == 1) {  // (Pt + gamma*(Pr1 - Pr2)) + b  crossover.jl:253
+            if (!PLAIN && kind == 1) {  // (Pt + gamma*(Pr1 - Pr2)) + b  crossover.jl:253
                 const double dj = tj - Pa[j];
                 const double t1 = dj * cm - dj * cn;
                 return (tj + t1 * g1) + bj;
@@ -973,12 +978,12 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
             }
             v0 = cross(j0, t0, u0);
             if (has1) v1 = cross(j1, t1, u1);
-            if (p.kappa != 1.0) {  // recombination! crossover.jl:301-312
+            if (!PLAIN && p.kappa != 1.0) {  // recombination! crossover.jl:301-312
                 const U4 rc = draw_block(p.seed, S_RECOMB, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)k);
                 if (u53(rc.x, rc.y) <= 1.0 - p.kappa) v0 = t0;
                 if (u53(rc.z, rc.w) <= 1.0 - p.kappa) v1 = t1;
             }
-            if (p.mask) {  // reset! crossover.jl:336-352
+            if (!PLAIN && p.mask) {  // reset! crossover.jl:336-352
                 if (!p.mask[j0]) v0 = t0;
                 if (has1 && !p.mask[j1]) v1 = t1;
             }
@@ -994,7 +999,7 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
             const bool has1 = j0 + 1 < D;
             double v0, v1;
             value_pair(k, v0, v1);
-            if (kind == 1) {  // adjust_loglike norms (crossover.jl:268-273)
+            if (!PLAIN && kind == 1) {  // adjust_loglike norms (crossover.jl:268-273)
                 const double a0 = v0 - Pa[j0], b0 = pt[j0] - Pa[j0];
                 s1 += a0 * a0; s2 += b0 * b0;
                 if (has1) {
@@ -1007,7 +1012,7 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
                 const double v = e ? v1 : v0;
                 const DimTab t = p.dimtab[j0 + e];
                 oob |= !(v >= t.lo && v <= t.hi);  // in_bounds utilities.jl:70-78 (NaN fails)
-                if (p.fitness_kind == 0 && t.kind != PR_FLAT) {
+                if ((PLAIN || p.fitness_kind == 0) && t.kind != PR_FLAT) {
                     if (t.kind == PR_NORMAL_REF && t.ref != ref_cached) {
                         ref_cached = t.ref;
                         double r0v, r1v;
@@ -1036,7 +1041,7 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
         prior = group_sum(prior, lpp, s_gsum);
         oob = group_sum(oob, lpp, s_gsumi);
         double adj = 0.0;
-        if (kind == 1) {  // (d-1)(log|a| - log|b|): stable form of log(|a|^(d-1)/|b|^(d-1))  crossover.jl:268-273
+        if (!PLAIN && kind == 1) {  // (d-1)(log|a| - log|b|): stable form of log(|a|^(d-1)/|b|^(d-1))  crossover.jl:268-273
             s1 = group_sum(s1, lpp, s_gsum);
             s2 = group_sum(s2, lpp, s_gsum);
             adj = (double)(D - 1) * (0.5 * log(s1) - 0.5 * log(s2));
@@ -1158,7 +1163,7 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
                     p.aux[slot] = aux;
                     if (p.sx) p.partial[slot] = S;
                 }
-                if (p.trace) {
+                if (!PLAIN && p.trace) {
                     p.tr_idx[slot * 4 + 0] = kind;
                     p.tr_idx[slot * 4 + 1] = i0;
                     p.tr_idx[slot * 4 + 2] = i1;
@@ -1177,24 +1182,24 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
         const double sg = (p.family == FAM_MVN_ISO) ? scr[sub * scr_stride + d]
                           : (p.family == FAM_GAUSSIAN) ? scr[sub * scr_stride + 1] : 0.0;
         double wp;
-        if (p.fitness_kind == 1)
+        if (!PLAIN && p.fitness_kind == 1)
             wp = oob ? (p.update_kind == 1 ? -INFINITY : INFINITY) : loglike_from_stats(p, S, aux, sg);
         else
             wp = oob ? -INFINITY : prior + loglike_from_stats(p, S, aux, sg);
-        const int acc = decide(p, u_acc, wp, w, adj);  // every lane of the sub-group holds the same inputs
+        const int acc = decide<PLAIN>(p, u_acc, wp, w, adj);  // every lane of the sub-group holds the same inputs
         if (sl == 0 && valid) {
             if (acc) {
                 p.weight[slot] = wp;
                 if (RES) w_s[pl] = wp;
             }
-            if (p.trace) {
+            if (!PLAIN && p.trace) {
                 p.tr_idx[slot * 4 + 0] = kind; p.tr_idx[slot * 4 + 1] = i0;
                 p.tr_idx[slot * 4 + 2] = i1; p.tr_idx[slot * 4 + 3] = i2;
                 p.tr_w[slot] = wp; p.tr_acc[slot] = (unsigned char)acc; p.prop_adj[slot] = adj;
             }
             if (p.store_row >= 0) {
                 const size_t hrow = (size_t)p.store_row * p.P + slot;
-                if (p.update_kind == 0 && p.mode == MODE_STEP) {  // utilities.jl:207-208
+                if ((PLAIN || p.update_kind == 0) && p.mode == MODE_STEP) {  // utilities.jl:207-208
                     p.acc_hist[hrow] = (unsigned char)acc;
                     p.lp_hist[hrow] = acc ? wp : w;
                 }

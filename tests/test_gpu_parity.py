@@ -266,6 +266,17 @@ def test_resident_form_equals_one_launch_per_phase(demc, family, Np, d, kw):
             assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("fuse", [0, 2, 1])
+def test_plain_instance_equals_general_instance(demc, fuse):
+    """The default sampler (random_gamma, no snooker, kappa = 1, no blocks, Metropolis, no trace) runs in a K1 instance
+    with every other branch compiled out; trace = 1 selects the general instance.  Same bits."""
+    prob = make_problem("mvn_full", np.random.default_rng(63), N=300, d=12)
+    th0 = prob["init"](8 * 40)
+    a, b = (_run_fuse_mode(demc, prob, th0, fuse, 8, 40, 12, 25, alpha=0.3, burnin=10, loglike_mode=1, trace=tr) for tr in (0, 1))
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
 def test_resident_form_with_block_updates(demc):
     """block_update! (main.jl:174-179): several masked sweeps per iteration, all inside the resident launch"""
     prob = make_problem("mvn_full", np.random.default_rng(62), N=150, d=6)
