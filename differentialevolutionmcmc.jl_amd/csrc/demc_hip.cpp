@@ -149,7 +149,7 @@ KParams base_params(demc_handle* h) {
     const demc_config& c = h->c;
     k.n_groups = c.n_groups; k.Np = c.Np; k.D = c.D; k.group_offset = c.group_offset;
     k.a_lo = 0; k.n_act = c.Np; k.pool_lo = 0; k.pool_n = c.Np; k.exclude_self = 1;
-    k.lpp = h->lpp; k.lpp3 = h->lpp; k.mode = MODE_STEP;
+    k.lpp = h->lpp; k.lpp3 = h->lpp > 256 ? 256 : h->lpp; k.mode = MODE_STEP;
     k.iter = 0; k.burnin = c.burnin; k.sweep = 0; k.seed = c.seed;
     k.beta = c.beta; k.eps = c.eps; k.sigma = c.sigma; k.kappa = c.kappa; k.theta_snooker = c.theta_snooker;
     k.proposal_kind = c.proposal_kind; k.partner_kind = c.partner_kind; k.update_kind = c.update_kind;
@@ -300,12 +300,14 @@ bool is_mvn(int fam) { return fam == FAM_MVN_FULL || fam == FAM_MVN_ISO; }
 
 // the K1 instance for (tile in LDS?, fused tail)
 using K1Fn = void (*)(KParams);
-K1Fn k1_instance(bool tile, int tail, bool plain) {
-#define K1_ROW(TILE, RES_, PLAIN_)                                                                                   \
-    {k_propose<256, TILE, TAIL_NONE, RES_, PLAIN_>, k_propose<256, TILE, TAIL_PREP, RES_, PLAIN_>,                   \
-     k_propose<256, TILE, TAIL_PREP_MFMA, RES_, PLAIN_>, k_propose<256, TILE, TAIL_OBS, RES_, PLAIN_>}
-    static const K1Fn tab[3][4] = {K1_ROW(false, false, false), K1_ROW(true, false, false), K1_ROW(true, false, true)};
+K1Fn k1_instance(bool tile, int tail, bool plain, int wg = 256) {
+#define K1_ROW(WG_, TILE, RES_, PLAIN_)                                                                              \
+    {k_propose<WG_, TILE, TAIL_NONE, RES_, PLAIN_>, k_propose<WG_, TILE, TAIL_PREP, RES_, PLAIN_>,                   \
+     k_propose<WG_, TILE, TAIL_PREP_MFMA, RES_, PLAIN_>, k_propose<WG_, TILE, TAIL_OBS, RES_, PLAIN_>}
+    static const K1Fn tab[4][4] = {K1_ROW(256, false, false, false), K1_ROW(256, true, false, false), K1_ROW(256, true, false, true),
+                                   K1_ROW(512, false, false, false)};
 #undef K1_ROW
+    if (wg == 512) return tab[3][tail];  // a 512-thread workgroup per particle (very long rows, no tile)
     return tab[tile ? (plain ? 2 : 1) : 0][tail];  // the plain instance exists for the LDS-tile forms only
 }
 
@@ -345,7 +347,8 @@ int launch_phase(demc_handle* h, KParams& k) {
     if (n_prop == 0) return DEMC_OK;
     const demc_config& c = h->c;
     set_tail_flags(h, k);
-    const int ppp = 256 / k.lpp, ppp3 = 256 / k.lpp3;
+    const int wg = k.lpp > 256 ? 512 : 256;  // K1 workgroup: 512 threads when one particle takes 512 lanes
+    const int ppp = wg / k.lpp, ppp3 = 256 / k.lpp3;
     const int max_split = (k.n_act + ppp - 1) / ppp;
     int target_wgs = 512;
     if (const char* e = std::getenv("DEMC_K1_WGS")) target_wgs = std::atoi(e);  // A/B experiments
@@ -353,7 +356,7 @@ int launch_phase(demc_handle* h, KParams& k) {
     if (n_split > max_split) n_split = max_split;
     if (n_split < 1) n_split = 1;
     k.n_split = n_split;
-    const bool tile = k.tile_in_lds && c.partner_kind == DEMC_PARTNER_CURRENT;
+    const bool tile = k.tile_in_lds && c.partner_kind == DEMC_PARTNER_CURRENT && wg == 256;
     // plan stage (per-particle scalars once per workgroup): 4 doubles + 4 ints per particle of the workgroup's slice
     const size_t per_split = (size_t)(k.n_act + n_split - 1) / n_split;
     const size_t plan_bytes = per_split * (4 * sizeof(double) + 4 * sizeof(int));
@@ -366,7 +369,7 @@ int launch_phase(demc_handle* h, KParams& k) {
     tick(h, 0, true);
     const int tail = tail_of(k);
     const size_t lds = tile ? lds_tile + (k.plan ? plan_bytes : 0) : h->k1_lds - h->k1_tile_bytes;
-    hipLaunchKernelGGL(k1_instance(tile, tail, is_plain(h, k)), dim3(k.n_groups * n_split), dim3(256), lds, h->stream, k);
+    hipLaunchKernelGGL(k1_instance(tile, tail, is_plain(h, k), wg), dim3(k.n_groups * n_split), dim3(wg), lds, h->stream, k);
     tick(h, 0, false);
     if (k.fuse_accept) return DEMC_OK;
     int rc = launch_loglike(h, k);
@@ -483,7 +486,7 @@ int size_k1_lds(demc_handle* h) {
     const size_t cdf = ((size_t)c.Np + ((size_t)c.Np + 15) / 16) * sizeof(double);
     const size_t ainv = (h->family == FAM_MVN_FULL) ? (size_t)h->d * h->d * sizeof(double) : 0;
     const size_t xb = is_mvn(h->family) ? (size_t)h->d * sizeof(double) : 0;
-    const size_t scr_rows = (size_t)(256 / (h->lpp > 256 ? 256 : h->lpp)) * (D + 2) * sizeof(double);
+    const size_t scr_rows = (size_t)(h->lpp >= 256 ? 1 : 256 / h->lpp) * (D + 2) * sizeof(double);
     const bool hier = h->family == FAM_HIER_BINOMIAL || h->family == FAM_HIER_GAUSSIAN;
     h->hier_scr = hier && scr_rows <= 96 * 1024;  // theta' of the pass fits in LDS: the subjects can be summed in K1
     const bool scr_fam = is_mvn(h->family) || h->family == FAM_GAUSSIAN || h->family == FAM_BINOMIAL ||
@@ -504,6 +507,8 @@ int size_k1_lds(demc_handle* h) {
                 HIPCHK(hipFuncSetAttribute((const void*)k1_instance(t != 0, tail, plain != 0),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
                 HIPCHK(hipFuncSetAttribute((const void*)k1_resident_instance(t ? 512 : 256, tail, plain != 0),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
+                HIPCHK(hipFuncSetAttribute((const void*)k1_instance(false, tail, false, 512),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
             }
     plan_resident(h);
@@ -616,7 +621,7 @@ int32_t demc_create(const demc_config* cfg, demc_handle** out) {
     // a pass with a particle and (ii) leave at least two workgroups per CU; small populations keep the widest split
     // (measured at D = 32: 256x256 particles -> 4, 128x256 -> 8, 64x128 and below -> 16).
     h->lpp = pow2_ceil((c.D + 1) / 2);
-    if (h->lpp > 64) h->lpp = (c.D >= 2048) ? 256 : 64;
+    if (h->lpp > 64) h->lpp = (c.D >= 4096) ? 512 : (c.D >= 2048) ? 256 : 64;  // a whole workgroup per particle for long rows
     if (h->lpp <= 64) {
         const int n_act = (c.schedule == DEMC_SCHED_TWO_COLOUR) ? c.Np / 2 : c.Np;  // moving particles per group and phase
         for (int l = 4; l < h->lpp; l *= 2) {
@@ -629,7 +634,7 @@ int32_t demc_create(const demc_config* cfg, demc_handle** out) {
     }
     if (const char* e = std::getenv("DEMC_LPP")) {  // A/B experiments: fewer lanes per particle = less replicated scalar work
         const int v = std::atoi(e);
-        if (v >= 1 && v <= 256 && v != 128 && (v & (v - 1)) == 0 && (v <= h->lpp || v == 256)) h->lpp = v;
+        if (v >= 1 && v <= 512 && v != 128 && (v & (v - 1)) == 0 && (v <= h->lpp || v == 256 || v == 512)) h->lpp = v;
     }
     int rc_lds = size_k1_lds(h);
     if (rc_lds != DEMC_OK) return rc_lds;

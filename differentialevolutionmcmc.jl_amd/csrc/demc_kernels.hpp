@@ -150,16 +150,18 @@ __device__ inline T subgroup_sum(T v, int lpp) {
     if (lpp >= 64) v += __shfl_xor(v, 32);
     return v;
 }
-// lpp == 256: one particle spans the whole workgroup (very large D); the sum crosses the four waves through LDS.
-// Must be called by every thread of the workgroup (the particle -- hence the control flow -- is workgroup-uniform then).
+// lpp == blockDim (256 or 512): one particle spans the whole workgroup (very large D); the sum crosses the waves through
+// LDS and is formed as a fixed tree over pairs of waves.  Must be called by every thread of the workgroup (the particle --
+// hence the control flow -- is workgroup-uniform then).
 template <typename T>
-__device__ inline T group_sum(T v, int lpp, T* s4) {
+__device__ inline T group_sum(T v, int lpp, T* s8) {
     if (lpp <= 64) return subgroup_sum(v, lpp);
     v = subgroup_sum(v, 64);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 0) s8[threadIdx.x >> 6] = v;
     __syncthreads();
-    return (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    const T lo = (s8[0] + s8[1]) + (s8[2] + s8[3]);
+    return blockDim.x > 256 ? lo + ((s8[4] + s8[5]) + (s8[6] + s8[7])) : lo;
 }
 // value held by lane B of the sub-group (B < lpp): row_newbcast inside a 16-lane row, quad_perm inside a quad
 template <int B>
@@ -393,7 +395,7 @@ __device__ inline double prior_term(const DimTab& t, double x, double inv_sref, 
 }
 
 // In-kernel stamps (diagnostic build only: make STAMPS=1; tools/k1_stamps.py reads them back through the trace).
-// Thread 0 of every workgroup stores the s_memtime delta since kernel start into tr_w[16*blockIdx.x + i]; the
+// Thread 0 of every workgroup (as many as fit in the P-long trace array) stores the s_memtime delta since kernel start into tr_w[16*blockIdx.x + i]; the
 // product build compiles them away.
 #ifndef DEMC_STAMP_PASS
 #define DEMC_STAMP_PASS 1  // which pass of the workgroup the per-pass stamps sample (0 = the cold first pass)
@@ -401,7 +403,8 @@ __device__ inline double prior_term(const DimTab& t, double x, double inv_sref, 
 #ifdef DEMC_STAMPS
 #define DEMC_STAMP(i)                                                                                              \
     do {                                                                                                           \
-        if (threadIdx.x == 0) p.tr_w[blockIdx.x * 16 + (i)] = (double)(__builtin_amdgcn_s_memtime() - t_start__); \
+        if (threadIdx.x == 0 && ((long long)blockIdx.x + 1) * 16 <= p.P)                                          \
+            p.tr_w[blockIdx.x * 16 + (i)] = (double)(__builtin_amdgcn_s_memtime() - t_start__);                   \
     } while (0)
 #define DEMC_STAMP_INIT() unsigned long long t_start__ = __builtin_amdgcn_s_memtime()
 #define DEMC_STAMP_RESET() t_start__ = __builtin_amdgcn_s_memtime()  // resident form: stamps are relative to the step's start
@@ -481,8 +484,8 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
     extern __shared__ double lds[];
     DEMC_STAMP_INIT();
     __shared__ double s_total;
-    __shared__ double s_gsum[4];
-    __shared__ int s_gsumi[4];
+    __shared__ double s_gsum[8];
+    __shared__ int s_gsumi[8];
     KParams p = p0;  // RES: the per-phase fields (iter, sweep, mask, store_row, active range, pool) are rewritten every step
     const int tid = threadIdx.x;
     // Workgroups are dealt to the 8 XCDs round-robin by blockIdx, and each XCD has its own L2.  The n_split workgroups of
@@ -966,6 +969,11 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
             }
             v0 = t0; v1 = t1;
             if (kind == 3) return;
+            bool keep0 = false, keep1 = false;  // reset! (crossover.jl:336-352): asked for now, with the row loads
+            if (!PLAIN && p.mask) {
+                keep0 = !p.mask[j0];
+                keep1 = has1 && !p.mask[j1];
+            }
             const U4 nz = draw_block(p.seed, S_NOISE, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)k);
             const double u0 = u53(nz.x, nz.y), u1 = u53(nz.z, nz.w);
             if (kind == 2) {  // pt + Normal(0, sigma): mutation.jl:15-18 (block mask ignored, main.jl:205)
@@ -983,10 +991,8 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
                 if (u53(rc.x, rc.y) <= 1.0 - p.kappa) v0 = t0;
                 if (u53(rc.z, rc.w) <= 1.0 - p.kappa) v1 = t1;
             }
-            if (!PLAIN && p.mask) {  // reset! crossover.jl:336-352
-                if (!p.mask[j0]) v0 = t0;
-                if (has1 && !p.mask[j1]) v1 = t1;
-            }
+            if (keep0) v0 = t0;
+            if (keep1) v1 = t1;
         };
 
         if (pass == DEMC_STAMP_PASS || n_pass == 1) DEMC_STAMP(4);  // indices, gammas, base picked
@@ -997,6 +1003,9 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
         for (int k = sl; 2 * k < D; k += lpp) {
             const int j0 = 2 * k;
             const bool has1 = j0 + 1 < D;
+            // the per-scalar constants go out with the row loads of value_pair (one wait for all of them) instead of
+            // starting a second round trip once the proposal values exist
+            const DimTab tab0 = p.dimtab[j0], tab1 = p.dimtab[has1 ? j0 + 1 : j0];
             double v0, v1;
             value_pair(k, v0, v1);
             if (!PLAIN && kind == 1) {  // adjust_loglike norms (crossover.jl:268-273)
@@ -1010,7 +1019,7 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
             for (int e = 0; e < 2; ++e) {
                 if (e == 1 && !has1) break;
                 const double v = e ? v1 : v0;
-                const DimTab t = p.dimtab[j0 + e];
+                const DimTab t = e ? tab1 : tab0;
                 oob |= !(v >= t.lo && v <= t.hi);  // in_bounds utilities.jl:70-78 (NaN fails)
                 if ((PLAIN || p.fitness_kind == 0) && t.kind != PR_FLAT) {
                     if (t.kind == PR_NORMAL_REF && t.ref != ref_cached) {
@@ -1150,7 +1159,7 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
             // sub-group visits every observation itself (lanes stride over them), reading theta' from its scratch row
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (lpp > 64) __syncthreads();  // the row was written by all four waves
+            if (lpp > 64) __syncthreads();  // the row was written by all waves of the workgroup
             S = group_sum(obs_range_sum(p, scr + sub * scr_stride, sl, p.N, lpp, nullptr), lpp, s_gsum);
         }
 

@@ -24,15 +24,34 @@ ap.add_argument("--np", type=int, default=256, dest="Np")
 ap.add_argument("--dim", type=int, default=32)
 ap.add_argument("--nobs", type=int, default=100000)
 ap.add_argument("--mode", default="suffstat")
+ap.add_argument("--config", default="")
 a = ap.parse_args()
-prob = bench.make_cfg3(a.n_groups, a.Np, a.nobs, a.dim)
-eng = demc_amd.HipEngine(n_groups=a.n_groups, Np=a.Np, D=a.dim, n_rows=40, schedule=2, seed=1,
-                         loglike_mode=1 if a.mode == "suffstat" else 0, trace=0)
-bench.configure(eng, prob, a.dim)
-eng.set_state(bench.init_theta(a.n_groups * a.Np, a.dim, 0))
-eng.step(1, 30)
-n_wg = min(512, (a.n_groups * a.Np) // 16) if os.environ.get('DEMC_RESIDENT') == '0' else a.n_groups  # resident: one per group
-full = eng.get_trace()["w_prop"][: n_wg * 16].reshape(n_wg, 16)
+if a.config:  # one of tools/run_configs.py's BASELINE shapes (e.g. cfg4: a whole workgroup per particle)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import run_configs  # noqa: E402
+    c = run_configs.build(a.config, np.random.default_rng(20260000 + int(a.config[-1])))
+    ex = dict(c["extra"])
+    masks = ex.pop("masks", None)
+    eng = demc_amd.HipEngine(n_groups=c["G"], Np=c["Np"], D=c["D"], n_rows=40, schedule=2, seed=1, trace=0, **ex)
+    eng.set_model(c["fam"], c["data"], c["dims"], c["hyper"])
+    eng.set_priors(c["pk"], c["pa"], c["pb"], c["pref"])
+    eng.set_bounds(c["lo"], c["hi"])
+    if masks is not None:
+        eng.set_blocks(masks)
+    eng.set_state(c["init"](c["G"] * c["Np"]))
+    eng.step(1, 30)
+    n_wg = c["G"] * c["Np"] // 2  # upper bound on the workgroups of a launch; unused stamp slots are filtered out below
+else:
+    prob = bench.make_cfg3(a.n_groups, a.Np, a.nobs, a.dim)
+    eng = demc_amd.HipEngine(n_groups=a.n_groups, Np=a.Np, D=a.dim, n_rows=40, schedule=2, seed=1,
+                             loglike_mode=1 if a.mode == "suffstat" else 0, trace=0)
+    bench.configure(eng, prob, a.dim)
+    eng.set_state(bench.init_theta(a.n_groups * a.Np, a.dim, 0))
+    eng.step(1, 30)
+    n_wg = min(512, (a.n_groups * a.Np) // 16) if os.environ.get('DEMC_RESIDENT') == '0' else a.n_groups  # resident: one per group
+w_prop = eng.get_trace()["w_prop"]
+n_wg = min(n_wg, len(w_prop) // 16)  # the stamps live in the P-long trace array, 16 per workgroup
+full = w_prop[: n_wg * 16].reshape(n_wg, 16)
 full = full[full[:, 10] > 0]
 t = full[:, :11]
 names = ["softmax prefix sums done (tile in flight)", "plan written; tile landed (LDS-DMA wait + barrier)",
