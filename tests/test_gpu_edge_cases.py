@@ -159,6 +159,14 @@ def test_cfg4_shape_parity(demc, orc):
                    masks=np.stack([m0, 1 - m0]), exact_de=False)
 
 
+@pytest.mark.parametrize("S", [2500, 5000])
+def test_whole_workgroup_per_particle_both_widths(demc, orc, S):
+    """very long rows: one particle per workgroup, 256 threads for 2048 <= D < 4096 and 512 from D = 4096 (the cfg4 test above
+    runs the 512 form with blocks); hierarchical Binomial so that the subject terms are summed inside the proposal kernel"""
+    prob = make_problem("hier_binomial", np.random.default_rng(46), S=S)
+    teacher_forced(demc, orc, prob, n_iter=3, n_groups=2, Np=8, schedule=2, burnin=2, alpha=1.0, exact_de=False)
+
+
 def test_cfg5_shape_parity(demc, orc):
     """BASELINE cfg5's shape with fewer trials/groups: LBA, 3 accumulators (6 parameters), snooker on"""
     prob = make_problem("lba", np.random.default_rng(45), N=2000, na=3)
