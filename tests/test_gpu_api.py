@@ -427,3 +427,31 @@ def test_host_planned_migration_moves_whole_rows():
         eng.apply_migration([0], [G * Np])  # out of range
     assert np.array_equal(eng.get_state()[0], eth), "a rejected plan must leave the state untouched"
     eng.close()
+
+
+@pytest.mark.parametrize("mode", ["streaming", "suffstat"])
+def test_bench_contract_on_a_small_workload(mode):
+    """bench.py prints ONE JSON line with the driver's keys, a `roofline` object for the dominant kernel and a
+    `cpu_baseline` object; checked on a reduced workload so that the line's shape cannot rot unnoticed"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--mode", mode,
+                          "--n-groups", "16", "--np", "32", "--nobs", "4000", "--dim", "8"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in r, key
+    assert r["n_gpus"] == 1 and r["steps"] == 6 and r["warmup"] == 2 and r["dtype"] == "f64" and r["scaling"] == "weak"
+    assert r["vs_baseline"] is None and r["higher_is_better"] is True and "workload" in r["config"]
+    assert abs(r["value"] - 16 * 32 * 6 / (r["ms_per_step"] * 6e-3)) <= 1e-6 * r["value"]
+    rf = r["roofline"]
+    assert rf["bound"] == ("mfma" if mode == "streaming" else "hbm") and rf["unit"] == ("TFLOP/s" if mode == "streaming" else "GB/s")
+    assert rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and "traffic" in rf
+    cb = r["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
