@@ -1,6 +1,6 @@
 // demc_kernels.hpp -- hand-written gfx950 kernels of the DE-MCMC hot path.
 //
-//   K1  k_propose<WG,TILE,TAIL,RES>  crossover!/snooker_update!/mutation!/recombination!/reset!/in_bounds + prior
+//   K1  k_propose<WG,TILE,TAIL,RES,PLAIN>  crossover!/snooker_update!/mutation!/recombination!/reset!/in_bounds + prior
 //                        (crossover.jl:30-99,154-257,301-352; mutation.jl:13-25; utilities.jl:70-78)
 //       (fused tails)    MvNormal preparation y = A^-1 (theta' - xbar), a = (theta' - xbar).y; optionally the whole
 //                        accept/store when the likelihood needs no separate pass over the data (SUFFSTAT, small N,
