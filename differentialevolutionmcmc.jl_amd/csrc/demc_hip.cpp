@@ -465,7 +465,7 @@ int migration_enqueue(demc_handle* h, long long iter, double* dev_rows, const do
     if (apply) {
         const int ngt = h->c.n_groups_total;
         const int grid = ngt < 64 ? ngt : 64;
-        hipLaunchKernelGGL(k_mig_apply, dim3(grid), dim3(256), sizeof(int) * (size_t)ngt, h->stream, k, dev_all_rows, ngt);
+        hipLaunchKernelGGL(k_mig_apply, dim3(grid), dim3(256), 2 * sizeof(int) * (size_t)ngt, h->stream, k, dev_all_rows, ngt);
     }
     tick(h, 4, false);
     return DEMC_OK;
@@ -638,7 +638,7 @@ int32_t demc_create(const demc_config* cfg, demc_handle** out) {
     }
     int rc_lds = size_k1_lds(h);
     if (rc_lds != DEMC_OK) return rc_lds;
-    if ((size_t)c.n_groups_total * sizeof(int) > 48 * 1024) return fail(h, DEMC_EINVAL, "n_groups_total too large");
+    if (2 * (size_t)c.n_groups_total * sizeof(int) > 48 * 1024) return fail(h, DEMC_EINVAL, "n_groups_total too large");
     return DEMC_OK;
 }
 

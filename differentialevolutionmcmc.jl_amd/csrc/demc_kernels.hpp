@@ -1601,18 +1601,28 @@ __global__ __launch_bounds__(256) void k_slot_moves(KParams p, const int* __rest
 }
 
 __global__ __launch_bounds__(256) void k_mig_apply(KParams p, const double* __restrict__ all_rows, int n_groups_total) {
-    extern __shared__ int perm[];  // [n_groups_total]
+    extern __shared__ int perm[];  // [n_groups_total] the shuffle, then [n_groups_total] its random words
     __shared__ int s_ns;
     const int tid = threadIdx.x, D = p.D;
-    if (tid == 0) {  // select_groups migration.jl:31-35
-        const int ng = n_groups_total;
-        U4 r = draw_block(p.seed, S_STEP, 0, (uint64_t)p.iter, 0, 0);
+    const int ng = n_groups_total;
+    uint32_t* words = reinterpret_cast<uint32_t*>(perm + ng);
+    // select_groups migration.jl:31-35.  The swaps of the partial shuffle depend on each other, their random words do
+    // not: all lanes draw the Philox blocks (word i = word i&3 of block 1 + i/4 of the STEP stream) and fill the identity
+    // first, one lane then walks the swaps.
+    for (int b = tid; 4 * b < ng; b += 256) {
+        const U4 r = draw_block(p.seed, S_STEP, 0, (uint64_t)p.iter, 0, 1 + (uint32_t)b);
+        words[4 * b] = r.x;
+        if (4 * b + 1 < ng) words[4 * b + 1] = r.y;
+        if (4 * b + 2 < ng) words[4 * b + 2] = r.z;
+        if (4 * b + 3 < ng) words[4 * b + 3] = r.w;
+    }
+    for (int i = tid; i < ng; i += 256) perm[i] = i;
+    __syncthreads();
+    if (tid == 0) {
+        const U4 r = draw_block(p.seed, S_STEP, 0, (uint64_t)p.iter, 0, 0);
         const int ns = 2 + (int)mulhi32(r.z, (uint32_t)(ng - 1));
-        for (int i = 0; i < ng; ++i) perm[i] = i;
         for (int i = 0; i < ns; ++i) {
-            if ((i & 3) == 0) r = draw_block(p.seed, S_STEP, 0, (uint64_t)p.iter, 0, 1 + (uint32_t)(i >> 2));
-            const uint32_t w = (i & 3) == 0 ? r.x : (i & 3) == 1 ? r.y : (i & 3) == 2 ? r.z : r.w;
-            const int j = i + (int)mulhi32(w, (uint32_t)(ng - i));
+            const int j = i + (int)mulhi32(words[i], (uint32_t)(ng - i));
             const int t = perm[i]; perm[i] = perm[j]; perm[j] = t;
         }
         s_ns = ns;
