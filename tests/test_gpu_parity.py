@@ -277,6 +277,25 @@ def test_plain_instance_equals_general_instance(demc, fuse):
         assert np.array_equal(x, y)
 
 
+def test_resident_form_over_a_grid_of_shapes(demc):
+    """boundary shapes of the resident kernel: smallest and odd group sizes, the 256 / 512-thread switch (moving half x lanes
+    per particle around 256), odd and tiny D, one and several passes per phase -- each against the per-phase form"""
+    rng = np.random.default_rng(64)
+    checked = 0
+    for Np in (4, 5, 7, 8, 9, 16, 17, 31, 33, 63, 64, 65, 127, 129):
+        for d in (1, 2, 3, 5, 8, 9, 16, 17, 32, 33):
+            prob = make_problem("mvn_full", rng, N=40, d=d)
+            th0 = prob["init"](3 * Np)
+            a, b = (_run_fuse_mode(demc, prob, th0, fuse, 3, Np, d, 6, alpha=0.4, burnin=3, loglike_mode=1) for fuse in (0, 2))
+            for i, (x, y) in enumerate(zip(a, b)):
+                if i in (2, 5):
+                    np.testing.assert_allclose(x, y, rtol=1e-11, err_msg=f"Np={Np} d={d} array {i}")
+                else:
+                    assert np.array_equal(x, y), f"Np={Np} d={d} array {i}"
+            checked += 1
+    assert checked == 140
+
+
 def test_resident_form_with_block_updates(demc):
     """block_update! (main.jl:174-179): several masked sweeps per iteration, all inside the resident launch"""
     prob = make_problem("mvn_full", np.random.default_rng(62), N=150, d=6)
