@@ -101,7 +101,11 @@ int dev_alloc(demc_handle* h, T** p, size_t n) {
     if (n == 0) n = 1;
     hipError_t e = hipMalloc((void**)p, n * sizeof(T));
     if (e != hipSuccess) return fail(h, DEMC_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    // hipMemset runs on the null stream and may return before the fill has happened; the handle's own stream is
+    // non-blocking, i.e. NOT ordered behind the null stream -- without the wait a kernel launched right after an
+    // allocation (demc_export_chains) could have its output zeroed underneath it.
     e = hipMemset(*p, 0, n * sizeof(T));
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) return fail(h, DEMC_EHIP, std::string("hipMemset: ") + hipGetErrorString(e));
     return DEMC_OK;
 }
@@ -402,21 +406,32 @@ void plan_resident(demc_handle* h) {
     int lpp_max = pow2_ceil((c.D + 1) / 2);
     if (lpp_max > 64) return;
     const int n_act = c.Np - c.Np / 2;
-    int lpp = 4;  // one pass of a 512-thread workgroup over the moving half when possible; never below 4 lanes
-    while (lpp * 2 <= lpp_max && n_act * lpp * 2 <= 512) lpp *= 2;
-    if (lpp > lpp_max) lpp = lpp_max;
-    const int wg = (n_act * lpp > 256) ? 512 : 256;
-    KParams k = base_params(h);
-    k.lpp = lpp;
-    k.mode = MODE_STEP;
-    set_tail_flags(h, k);
-    if (!k.fuse_accept) return;
     const size_t D = (size_t)c.D, Np = (size_t)c.Np, d = (size_t)h->d;
     const bool mvn = is_mvn(h->family);
-    const size_t scr_doubles = (k.fuse_prep || k.fuse_obs) ? (size_t)(wg / lpp) * (D + 2) : 0;
-    const size_t doubles = Np * D + Np + (Np + (Np + 15) / 16) + (h->family == FAM_MVN_FULL ? d * d : 0) + (mvn ? d : 0) + scr_doubles;
-    const size_t bytes = doubles * sizeof(double) + (size_t)n_act * (4 * sizeof(double) + 4 * sizeof(int));
-    if (bytes > kMaxDynLds) return;
+    // geometry for a thread budget: lanes per particle so that the moving half fills one pass when possible (never below
+    // 4 lanes), workgroup size, LDS bytes; false when the update cannot be fused or the group does not fit
+    int lpp = 0, wg = 0;
+    size_t bytes = 0, scr_doubles = 0;
+    auto geometry = [&](int budget) -> bool {
+        lpp = 4;
+        while (lpp * 2 <= lpp_max && n_act * lpp * 2 <= budget) lpp *= 2;
+        if (lpp > lpp_max) lpp = lpp_max;
+        wg = (n_act * lpp > 256 && budget > 256) ? 512 : 256;
+        KParams k = base_params(h);
+        k.lpp = lpp;
+        k.mode = MODE_STEP;
+        set_tail_flags(h, k);
+        if (!k.fuse_accept) return false;
+        scr_doubles = (k.fuse_prep || k.fuse_obs) ? (size_t)(wg / lpp) * (D + 2) : 0;
+        const size_t doubles =
+            Np * D + Np + (Np + (Np + 15) / 16) + (h->family == FAM_MVN_FULL ? d * d : 0) + (mvn ? d : 0) + scr_doubles;
+        bytes = doubles * sizeof(double) + (size_t)n_act * (4 * sizeof(double) + 4 * sizeof(int));
+        return bytes <= kMaxDynLds;
+    };
+    // More groups than CUs: two 256-thread workgroups per CU keep twice as many groups in flight as one of 512 -- when
+    // two of them fit in a CU's LDS (measured at 1024 groups x 64: 0.082 -> see DESIGN.md section 6).
+    const bool two_per_cu = c.n_groups > 256 && geometry(256) && bytes <= 75 * 1024;
+    if (!two_per_cu && !geometry(512)) return;
     h->res_ok = true; h->res_lpp = lpp; h->res_wg = wg; h->res_lds = bytes; h->res_scr_doubles = (int)scr_doubles;
 }
 

@@ -400,6 +400,23 @@ def test_device_chain_export_equals_host_rekey():
     eng.close()
 
 
+def test_chain_export_is_repeatable():
+    """regression: the staging buffer of demc_export_chains used to be zero-filled on the null stream while the export
+    kernel ran on the handle's own (non-blocking) stream, so now and then part of an export came back as zeros.  A
+    2000-row export (the size at which it showed about one time in five) repeated 40 times must not change."""
+    prob = make_problem("gaussian", np.random.default_rng(62), N=400)
+    G, Np, n = 4, 6, 2000
+    eng = D.HipEngine(n_groups=G, Np=Np, D=2, n_rows=n, schedule=2, seed=2, trace=0)
+    setup_engine(eng, prob)
+    eng.set_state(prob["init"](G * Np))
+    eng.step(1, n)
+    first = eng.export_chains(0, n)
+    assert np.isfinite(first).all() and (first[:, 1, :] > 0).all()  # sigma column: a zeroed patch would show here
+    for _ in range(40):
+        assert np.array_equal(eng.export_chains(0, n), first)
+    eng.close()
+
+
 def test_host_planned_migration_moves_whole_rows():
     """demc_apply_migration = shift_particles! (migration.jl:84-91) with the plan drawn by the caller: dst[k] receives the
     row (theta, weight, id) src[k] held before the call; a cycle is a rotation; everything else is untouched (bit-exact)."""
