@@ -204,3 +204,25 @@ def test_randomised_configurations(demc, orc, fam, kw, cfg):
     """seeded sweep over families x shapes x sampler settings x schedules x likelihood modes"""
     prob = make_problem(fam, np.random.default_rng(cfg["seed"]), **kw)
     teacher_forced(demc, orc, prob, n_iter=4, exact_de=False, **cfg)
+
+
+def test_repeat_runs_agree_bit_for_bit(demc):
+    """no atomics, fixed reduction trees, every host<->device hand-over ordered: a configuration run twice on fresh handles
+    gives the same bits in state, history and chain export, in all three fuse modes (tools/determinism_sweep.py is the
+    long form of this test)"""
+    import hashlib
+    for case in _fuzz_cases(16, seed=11):
+        fam, kw, cfg = case.values
+        prob = make_problem(fam, np.random.default_rng(cfg["seed"]), **kw)
+        th0 = prob["init"](cfg["n_groups"] * cfg["Np"])
+        for fuse in (0, 2, 1):
+            sigs = set()
+            for _ in range(2):
+                e = demc.HipEngine(D=prob["D"], n_rows=12, trace=0, fuse=fuse, **cfg)
+                setup_engine(e, prob)
+                e.set_state(th0)
+                e.step(1, 12)
+                parts = list(e.get_state()) + list(e.get_history(0, 12)) + [e.export_chains(0, 12)]
+                e.close()
+                sigs.add(hashlib.md5(b"".join(np.ascontiguousarray(p).tobytes() for p in parts)).hexdigest())
+            assert len(sigs) == 1, (case.id, fuse)
