@@ -19,7 +19,7 @@ EXPORTS = [
     "demc_set_model_source", "demc_set_priors", "demc_set_bounds", "demc_set_blocks", "demc_set_state", "demc_get_state",
     "demc_set_history_rows", "demc_get_history", "demc_export_chains", "demc_step", "demc_update", "demc_migration_due",
     "demc_migration_pack", "demc_migration_apply", "demc_apply_migration", "demc_get_weights", "demc_logpost",
-    "demc_get_trace", "demc_timing_enable", "demc_timing_read",
+    "demc_get_trace", "demc_set_replay", "demc_timing_enable", "demc_timing_read",
 ]
 
 
@@ -40,8 +40,52 @@ class DemcConfig(C.Structure):
         ("fitness_kind", C.c_int32), ("schedule", C.c_int32), ("store_history", C.c_int32),
         ("group_offset", C.c_int32), ("n_groups_total", C.c_int32),
         ("seed", C.c_uint64), ("device_id", C.c_int32), ("loglike_mode", C.c_int32),
-        ("trace", C.c_int32), ("fuse", C.c_int32),
+        ("trace", C.c_int32), ("fuse", C.c_int32), ("geometry_groups", C.c_int32), ("reserved0", C.c_int32),
     ]
+
+
+class DemcReplay(C.Structure):
+    """demc_replay (include/demc.h): caller-supplied draws for the test mode of demc_set_replay"""
+    _fields_ = [
+        ("u_step", C.POINTER(C.c_double)), ("u_group", C.POINTER(C.c_double)), ("u_part", C.POINTER(C.c_double)),
+        ("partner", C.POINTER(C.c_int64)), ("u_noise", C.POINTER(C.c_double)), ("z_noise", C.POINTER(C.c_double)),
+        ("u_recomb", C.POINTER(C.c_double)), ("mig_groups", C.POINTER(C.c_int32)), ("n_mig_groups", C.c_int32),
+        ("reserved", C.c_int32), ("mig_particle", C.POINTER(C.c_int64)),
+    ]
+
+
+def fill_replay(struct, P, D, G, u_step=None, u_group=None, u_part=None, partner=None, u_noise=None, z_noise=None,
+                u_recomb=None, mig_groups=None, mig_particle=None):
+    """Fill a replay struct (this module's DemcReplay, or a struct of the same field names) from arrays; returns the list
+    of arrays that must stay alive for the call.  Shapes: u_part [P][5], partner [P][3], u_noise/z_noise/u_recomb [P][D],
+    u_group / mig_particle [G], mig_groups [n]."""
+    keep = []
+
+    def arr(x, dtype, shape):
+        if x is None:
+            return None
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=dtype), shape))
+        keep.append(a)
+        return a
+
+    def ptr(a, ct):
+        return None if a is None else a.ctypes.data_as(C.POINTER(ct))
+
+    struct.u_step = ptr(arr(u_step, np.float64, (1,)), C.c_double)
+    struct.u_group = ptr(arr(u_group, np.float64, (G,)), C.c_double)
+    struct.u_part = ptr(arr(u_part, np.float64, (P, 5)), C.c_double)
+    struct.partner = ptr(arr(partner, np.int64, (P, 3)), C.c_int64)
+    struct.u_noise = ptr(arr(u_noise, np.float64, (P, D)), C.c_double)
+    struct.z_noise = ptr(arr(z_noise, np.float64, (P, D)), C.c_double)
+    struct.u_recomb = ptr(arr(u_recomb, np.float64, (P, D)), C.c_double)
+    mg = None if mig_groups is None else np.ascontiguousarray(mig_groups, dtype=np.int32)
+    if mg is not None:
+        keep.append(mg)
+    struct.mig_groups = ptr(mg, C.c_int32)
+    struct.n_mig_groups = 0 if mg is None else int(mg.size)
+    struct.reserved = 0
+    struct.mig_particle = ptr(arr(mig_particle, np.int64, (G,)), C.c_int64)
+    return keep
 
 
 CFG_KEYS = [f[0] for f in DemcConfig._fields_]
@@ -94,6 +138,7 @@ def load():
     L.demc_migration_apply.argtypes = [H, C.c_int64, C.c_void_p]
     L.demc_logpost.argtypes = [H, _dp, C.c_int64, _dp]
     L.demc_get_trace.argtypes = [H, _dp, _dp, _dp, _ip, _bp]
+    L.demc_set_replay.argtypes = [H, C.POINTER(DemcReplay)]
     L.demc_timing_enable.argtypes = [H, C.c_int32]
     L.demc_timing_read.argtypes = [H, _dp, C.c_int32]
     for name in EXPORTS:  # every entry point returns an int32 status, except the error string
@@ -106,7 +151,7 @@ def make_config(**kw):
     d = dict(n_groups=4, Np=4, D=1, n_blocks=0, burnin=1000, n_initial=0, n_rows=0, alpha=0.1, beta=0.1, eps=0.001,
              sigma=0.05, kappa=1.0, theta_snooker=0.0, proposal_kind=0, partner_kind=0, update_kind=0,
              fitness_kind=0, schedule=2, store_history=1, group_offset=0, n_groups_total=0, seed=1, device_id=0,
-             loglike_mode=0, trace=1, fuse=0)
+             loglike_mode=0, trace=1, fuse=0, geometry_groups=0, reserved0=0)
     for k, v in kw.items():
         if k in d:
             d[k] = v
@@ -258,6 +303,16 @@ class HipEngine:
         self._ck(self.L.demc_get_trace(self.h, _d(prop), _d(w), _d(adj), idx.ctypes.data_as(_ip),
                                        acc.ctypes.data_as(_bp)))
         return dict(proposal=prop, w_prop=w, log_adj=adj, idx=idx, accepted=acc)
+
+    def set_replay(self, **draws):
+        """test mode: caller-supplied draws (see fill_replay / demc_replay); no arguments -> back to Philox"""
+        if not draws:
+            self._ck(self.L.demc_set_replay(self.h, None))
+            return
+        r = DemcReplay()
+        keep = fill_replay(r, self.P, self.D, self.cfg.n_groups, **draws)
+        self._ck(self.L.demc_set_replay(self.h, C.byref(r)))
+        del keep
 
     def migration_due(self, it):
         return bool(self.L.demc_migration_due(C.byref(self.cfg), it))

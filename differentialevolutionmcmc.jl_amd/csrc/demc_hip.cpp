@@ -17,6 +17,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -24,6 +26,9 @@
 
 using namespace demc;
 
+#ifndef DEMC_ARCH_STR
+#define DEMC_ARCH_STR "gfx950"  // the Makefile passes its ARCH, so that the JIT-compiled plug-in matches the library
+#endif
 constexpr size_t kMaxDynLds = 150 * 1024;  // of the 160 KB per CU; the rest covers the kernels' static __shared__
 
 namespace {
@@ -72,6 +77,14 @@ struct demc_handle {
     int res_lpp = 0, res_wg = 0, res_scr_doubles = 0;
     size_t res_lds = 0;
     std::string err;
+    // replay (demc_set_replay): device copies of the caller's draws
+    double *rp_group = nullptr, *rp_part = nullptr, *rp_noise = nullptr, *rp_znoise = nullptr, *rp_recomb = nullptr;
+    long long *rp_partner = nullptr, *rp_mig_particle = nullptr;
+    int* rp_mig_groups = nullptr;
+    int rp_n_mig = 0;
+    bool rp_active = false, rp_has_step = false;
+    double rp_u_step = 0.0;
+    int geo_groups = 0;  // groups the lane geometry is sized for (demc_config.geometry_groups, else n_groups)
     // timing
     bool timing = false;
     std::vector<Timed> events;
@@ -81,9 +94,39 @@ struct demc_handle {
 
 namespace {
 
-int fail(demc_handle* h, int code, const std::string& msg) {
-    if (h) h->err = msg;
+int fail(demc_handle* h, int code, const std::string& msg) noexcept {
+    if (h) {
+        try {
+            h->err = msg;
+        } catch (...) {  // not even the message could be stored: the code alone goes back
+        }
+    }
     return code;
+}
+
+// No C++ exception crosses the C-ABI (include/demc.h): every extern "C" body runs inside this guard.
+template <typename F>
+int32_t guarded(demc_handle* h, F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(h, DEMC_ENOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(h, DEMC_EHIP, std::string("internal error: ") + e.what());
+    } catch (...) {
+        return fail(h, DEMC_EHIP, "internal error (unknown exception)");
+    }
+}
+
+// A/B switches for kernel experiments (tools/, profiles/README.md).  They exist only in a build made with
+// -DDEMC_EXPERIMENTS (make EXPERIMENTS=1); the product library never reads the environment.
+inline const char* experiment(const char* name) {
+#ifdef DEMC_EXPERIMENTS
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
 }
 
 #define HIPCHK(expr)                                                                                         \
@@ -169,6 +212,9 @@ KParams base_params(demc_handle* h) {
     k.n_split = 1; k.fuse_prep = 0; k.prep_mfma = 0; k.fuse_obs = 0; k.fuse_accept = 0; k.plan = 0;
     k.scr_doubles = (int)(h->k1_scr_bytes / sizeof(double)); k.write_prop = 1; k.trace = c.trace;
     k.Ainv = h->Ainv; k.sx = nullptr; k.xbar = h->xbar; k.Ypad = h->Ypad; k.dpad = h->dpad;
+    k.rp_group = h->rp_group; k.rp_part = h->rp_part; k.rp_partner = h->rp_partner; k.rp_noise = h->rp_noise;
+    k.rp_znoise = h->rp_znoise; k.rp_recomb = h->rp_recomb; k.rp_mig_groups = h->rp_mig_groups;
+    k.rp_mig_particle = h->rp_mig_particle; k.rp_n_mig = h->rp_n_mig;
     return k;
 }
 
@@ -323,7 +369,7 @@ void set_tail_flags(demc_handle* h, KParams& k) {
     // statistics and a phase writes only rows that no other workgroup reads (two_colour, or the identity pass)
     k.fuse_prep = is_mvn(h->family) ? 1 : 0;
     k.prep_mfma = (h->family == FAM_MVN_FULL && k.lpp >= 4 && k.lpp <= 16 && h->d <= 32) ? 1 : 0;
-    if (const char* e = std::getenv("DEMC_PREP_MFMA")) k.prep_mfma = k.prep_mfma && e[0] == '1';  // A/B experiments
+    if (const char* e = experiment("DEMC_PREP_MFMA")) k.prep_mfma = k.prep_mfma && e[0] == '1';  // A/B experiments
     k.sx = (k.fuse_prep && suff) ? h->sx : nullptr;
     k.Ainv = (h->family == FAM_MVN_FULL) ? h->Ainv : nullptr;
     // small-N scalar-data families: the sub-group of a particle sums the per-observation terms itself
@@ -333,7 +379,9 @@ void set_tail_flags(demc_handle* h, KParams& k) {
     const bool cheap_obs = ((h->family == FAM_GAUSSIAN || h->family == FAM_BINOMIAL || h->family == FAM_RASTRIGIN) &&
                             h->N / k.lpp <= 512) ||
                            (h->hier_scr && obs_work / k.lpp <= 4096);
-    const bool phase_private = c.schedule == DEMC_SCHED_TWO_COLOUR || k.mode == MODE_IDENT;  // nothing read can move
+    // nothing a moving particle reads can move in the same launch: two_colour (partners rest), the identity pass, and the
+    // sequential schedule (one particle per group and launch, handled by that group's only workgroup)
+    const bool phase_private = c.schedule == DEMC_SCHED_TWO_COLOUR || c.schedule == DEMC_SCHED_SEQUENTIAL || k.mode == MODE_IDENT;
     k.fuse_obs = (cheap_obs && phase_private && c.fuse != 1) ? 1 : 0;
     k.fuse_accept = (((k.fuse_prep && suff) || k.fuse_obs) && c.fuse != 1 && phase_private) ? 1 : 0;
     k.write_prop = (!k.fuse_accept || k.trace) ? 1 : 0;
@@ -342,7 +390,7 @@ void set_tail_flags(demc_handle* h, KParams& k) {
 bool is_plain(const demc_handle* h, const KParams& k) {
     const demc_config& c = h->c;
     return k.mode == MODE_STEP && c.proposal_kind == 0 && c.partner_kind == DEMC_PARTNER_CURRENT && c.update_kind == 0 &&
-           c.fitness_kind == 0 && c.theta_snooker == 0.0 && c.kappa == 1.0 && c.n_blocks == 0 && !k.trace;
+           c.fitness_kind == 0 && c.theta_snooker == 0.0 && c.kappa == 1.0 && c.n_blocks == 0 && !k.trace && !h->rp_active;
 }
 int tail_of(const KParams& k) { return k.prep_mfma ? TAIL_PREP_MFMA : k.fuse_prep ? TAIL_PREP : k.fuse_obs ? TAIL_OBS : TAIL_NONE; }
 
@@ -355,7 +403,7 @@ int launch_phase(demc_handle* h, KParams& k) {
     const int ppp = wg / k.lpp, ppp3 = 256 / k.lpp3;
     const int max_split = (k.n_act + ppp - 1) / ppp;
     int target_wgs = 512;
-    if (const char* e = std::getenv("DEMC_K1_WGS")) target_wgs = std::atoi(e);  // A/B experiments
+    if (const char* e = experiment("DEMC_K1_WGS")) target_wgs = std::atoi(e);  // A/B experiments
     int n_split = (target_wgs + k.n_groups - 1) / k.n_groups;
     if (n_split > max_split) n_split = max_split;
     if (n_split < 1) n_split = 1;
@@ -368,8 +416,8 @@ int launch_phase(demc_handle* h, KParams& k) {
     k.own_in_pool = (k.a_lo >= k.pool_lo && k.a_lo + k.n_act <= k.pool_lo + k.pool_n) ? 1 : 0;
     k.tile_rows = k.pool_n + (k.own_in_pool ? 0 : (int)per_split);
     const size_t lds_tile = h->k1_lds - h->k1_tile_bytes + (size_t)k.tile_rows * c.D * sizeof(double);  // <= k1_lds
-    k.plan = (tile && k.mode == MODE_STEP && k.lpp >= 4 && k.lpp <= 64 && lds_tile + plan_bytes <= kMaxDynLds) ? 1 : 0;
-    if (const char* e = std::getenv("DEMC_K1_PLAN")) k.plan = k.plan && e[0] == '1';  // A/B experiments
+    k.plan = (tile && k.mode == MODE_STEP && k.lpp >= 4 && k.lpp <= 64 && lds_tile + plan_bytes <= kMaxDynLds && !h->rp_active) ? 1 : 0;
+    if (const char* e = experiment("DEMC_K1_PLAN")) k.plan = k.plan && e[0] == '1';  // A/B experiments
     tick(h, 0, true);
     const int tail = tail_of(k);
     const size_t lds = tile ? lds_tile + (k.plan ? plan_bytes : 0) : h->k1_lds - h->k1_tile_bytes;
@@ -401,7 +449,7 @@ void plan_resident(demc_handle* h) {
     const demc_config& c = h->c;
     h->res_ok = false;
     if (c.fuse != 0 || c.schedule != DEMC_SCHED_TWO_COLOUR || c.partner_kind != DEMC_PARTNER_CURRENT || c.Np < 4) return;
-    if (const char* e = std::getenv("DEMC_RESIDENT"))  // A/B experiments
+    if (const char* e = experiment("DEMC_RESIDENT"))  // A/B experiments
         if (e[0] == '0') return;
     int lpp_max = pow2_ceil((c.D + 1) / 2);
     if (lpp_max > 64) return;
@@ -430,7 +478,7 @@ void plan_resident(demc_handle* h) {
     };
     // More groups than CUs: two 256-thread workgroups per CU keep twice as many groups in flight as one of 512 -- when
     // two of them fit in a CU's LDS (measured at 1024 groups x 64: 0.082 -> see DESIGN.md section 6).
-    const bool two_per_cu = c.n_groups > 256 && geometry(256) && bytes <= 75 * 1024;
+    const bool two_per_cu = h->geo_groups > 256 && geometry(256) && bytes <= 75 * 1024;
     if (!two_per_cu && !geometry(512)) return;
     h->res_ok = true; h->res_lpp = lpp; h->res_wg = wg; h->res_lds = bytes; h->res_scr_doubles = (int)scr_doubles;
 }
@@ -446,7 +494,7 @@ int launch_resident(demc_handle* h, long long iter0, int n_iters) {
     k.n_split = 1; k.exclude_self = 0; k.own_in_pool = 1; k.tile_rows = c.Np; k.tile_in_lds = 1;
     k.scr_doubles = h->res_scr_doubles;
     k.plan = (k.lpp >= 4) ? 1 : 0;
-    if (const char* e = std::getenv("DEMC_K1_PLAN")) k.plan = k.plan && e[0] == '1';  // A/B experiments
+    if (const char* e = experiment("DEMC_K1_PLAN")) k.plan = k.plan && e[0] == '1';  // A/B experiments
     tick(h, 0, true);
     hipLaunchKernelGGL(k1_resident_instance(h->res_wg, tail_of(k), is_plain(h, k)), dim3(k.n_groups), dim3(h->res_wg), h->res_lds,
                        h->stream, k);
@@ -466,6 +514,17 @@ int run_sweep(demc_handle* h, long long iter, unsigned sweep, const unsigned cha
         if (rc != DEMC_OK) return rc;
         k.a_lo = half; k.n_act = Np - half; k.pool_lo = 0; k.pool_n = half;
         return launch_phase(h, k);
+    }
+    if (h->c.schedule == DEMC_SCHED_SEQUENTIAL) {
+        // crossover.jl:13-15 / mutation.jl:16: particle pl of every group moves after 0..pl-1 were updated in place;
+        // the groups advance side by side (one task per group in p_update!, main.jl:135-148).  Partners come from the
+        // whole group minus self (setdiff, crossover.jl:158), snooker's three from the whole group (crossover.jl:241).
+        for (int pl = 0; pl < Np; ++pl) {
+            k.a_lo = pl; k.n_act = 1; k.pool_lo = 0; k.pool_n = Np; k.exclude_self = 1;
+            int rc = launch_phase(h, k);
+            if (rc != DEMC_OK) return rc;
+        }
+        return DEMC_OK;
     }
     return launch_phase(h, k);
 }
@@ -509,7 +568,7 @@ int size_k1_lds(demc_handle* h) {
     const size_t scr = scr_fam ? scr_rows : 0;
     const size_t tile = (size_t)c.Np * D * sizeof(double);
     h->tile_in_lds = (tile + cdf + ainv + xb + scr <= 96 * 1024) ? 1 : 0;
-    if (const char* e = std::getenv("DEMC_K1_TILE")) h->tile_in_lds = (e[0] == '1') && h->tile_in_lds;  // A/B experiments
+    if (const char* e = experiment("DEMC_K1_TILE")) h->tile_in_lds = (e[0] == '1') && h->tile_in_lds;  // A/B experiments
     h->k1_tile_bytes = h->tile_in_lds ? tile : 0;
     h->k1_scr_bytes = scr;
     h->k1_lds = h->k1_tile_bytes + cdf + ainv + xb + scr;
@@ -529,6 +588,17 @@ int size_k1_lds(demc_handle* h) {
     plan_resident(h);
     HIPCHK(hipFuncSetAttribute((const void*)k_mig_pack, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
     return DEMC_OK;
+}
+
+void free_replay(demc_handle* h) {
+    void* ptrs[] = {h->rp_group, h->rp_part, h->rp_noise, h->rp_znoise, h->rp_recomb, h->rp_partner, h->rp_mig_particle, h->rp_mig_groups};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    h->rp_group = h->rp_part = h->rp_noise = h->rp_znoise = h->rp_recomb = nullptr;
+    h->rp_partner = h->rp_mig_particle = nullptr;
+    h->rp_mig_groups = nullptr;
+    h->rp_n_mig = 0;
+    h->rp_active = h->rp_has_step = false;
 }
 
 bool chol_inv(const double* S, int d, std::vector<double>& Ainv, double& logdet) {
@@ -575,16 +645,17 @@ int32_t demc_create(const demc_config* cfg, demc_handle** out) {
     demc_handle* h = new (std::nothrow) demc_handle();
     if (!h) return DEMC_ENOMEM;
     *out = h;  // returned even on failure so that demc_last_error() can be read; caller destroys it
+    return guarded(h, [&]() -> int32_t {
     h->c = *cfg;
     demc_config& c = h->c;
     if (c.n_groups < 1 || c.Np < 3 || c.D < 1 || c.n_rows < 0)
         return fail(h, DEMC_EINVAL, "need n_groups >= 1, Np >= 3 (structs.jl:43), D >= 1, n_rows >= 0");
     if (c.n_groups_total <= 0) c.n_groups_total = c.n_groups;
     if (c.n_groups_total == 1) c.alpha = 0.0;  // structs.jl:102-105
-    if (c.schedule == DEMC_SCHED_SEQUENTIAL)
-        return fail(h, DEMC_EUNSUPPORTED, "sequential in-place sweep is the CPU reference schedule; use synchronous or two_colour");
-    if (c.schedule != DEMC_SCHED_SYNCHRONOUS && c.schedule != DEMC_SCHED_TWO_COLOUR)
+    if (c.schedule != DEMC_SCHED_SEQUENTIAL && c.schedule != DEMC_SCHED_SYNCHRONOUS && c.schedule != DEMC_SCHED_TWO_COLOUR)
         return fail(h, DEMC_EINVAL, "unknown schedule");
+    if (c.geometry_groups < 0) return fail(h, DEMC_EINVAL, "geometry_groups < 0");
+    h->geo_groups = c.geometry_groups > 0 ? c.geometry_groups : c.n_groups;
     if (c.schedule == DEMC_SCHED_TWO_COLOUR && c.partner_kind == DEMC_PARTNER_CURRENT) {
         const int need = c.theta_snooker > 0.0 ? 6 : 4;
         if (c.Np < need) return fail(h, DEMC_EINVAL, "two_colour needs Np >= 4 (>= 6 with snooker)");
@@ -638,16 +709,17 @@ int32_t demc_create(const demc_config* cfg, demc_handle** out) {
     h->lpp = pow2_ceil((c.D + 1) / 2);
     if (h->lpp > 64) h->lpp = (c.D >= 4096) ? 512 : (c.D >= 2048) ? 256 : 64;  // a whole workgroup per particle for long rows
     if (h->lpp <= 64) {
-        const int n_act = (c.schedule == DEMC_SCHED_TWO_COLOUR) ? c.Np / 2 : c.Np;  // moving particles per group and phase
+        // moving particles per group and launch
+        const int n_act = (c.schedule == DEMC_SCHED_TWO_COLOUR) ? c.Np / 2 : (c.schedule == DEMC_SCHED_SEQUENTIAL) ? 1 : c.Np;
         for (int l = 4; l < h->lpp; l *= 2) {
             const int ppp = 256 / l;
-            if (ppp <= n_act && (long long)c.n_groups * ((n_act + ppp - 1) / ppp) >= 512) {
+            if (ppp <= n_act && (long long)h->geo_groups * ((n_act + ppp - 1) / ppp) >= 512) {
                 h->lpp = l;
                 break;
             }
         }
     }
-    if (const char* e = std::getenv("DEMC_LPP")) {  // A/B experiments: fewer lanes per particle = less replicated scalar work
+    if (const char* e = experiment("DEMC_LPP")) {  // A/B experiments: fewer lanes per particle = less replicated scalar work
         const int v = std::atoi(e);
         if (v >= 1 && v <= 512 && v != 128 && (v & (v - 1)) == 0 && (v <= h->lpp || v == 256 || v == 512)) h->lpp = v;
     }
@@ -655,9 +727,11 @@ int32_t demc_create(const demc_config* cfg, demc_handle** out) {
     if (rc_lds != DEMC_OK) return rc_lds;
     if (2 * (size_t)c.n_groups_total * sizeof(int) > 48 * 1024) return fail(h, DEMC_EINVAL, "n_groups_total too large");
     return DEMC_OK;
+    });
 }
 
 int32_t demc_destroy(demc_handle* h) {
+    return guarded(nullptr, [&]() -> int32_t {
     if (!h) return DEMC_OK;
     if (h->stream) hipStreamSynchronize(h->stream);
     drain_events(h);
@@ -669,12 +743,15 @@ int32_t demc_destroy(demc_handle* h) {
         if (p) hipFree(p);
     if (h->user_module) hipModuleUnload(h->user_module);
     if (h->user_hyper) hipFree(h->user_hyper);
+    free_replay(h);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
     return DEMC_OK;
+    });
 }
 
 int32_t demc_set_stream(demc_handle* h, void* hip_stream) {
+    return guarded(h, [&]() -> int32_t {
     if (!h) return DEMC_EINVAL;
     USE_DEVICE(h);
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -687,10 +764,12 @@ int32_t demc_set_stream(demc_handle* h, void* hip_stream) {
         h->own_stream = true;
     }
     return DEMC_OK;
+    });
 }
 
 int32_t demc_set_model(demc_handle* h, int32_t family, const double* data, const int64_t* dims, int32_t ndims,
                        const double* hyper, int32_t nhyper) {
+    return guarded(h, [&]() -> int32_t {
     if (!h) return DEMC_EINVAL;
     USE_DEVICE(h);
     if (ndims < 0 || ndims > 4 || (ndims > 0 && !dims)) return fail(h, DEMC_EINVAL, "bad dims");
@@ -832,10 +911,12 @@ int32_t demc_set_model(demc_handle* h, int32_t family, const double* data, const
     }
     h->family = family;
     return size_k1_lds(h);
+    });
 }
 
 int32_t demc_set_model_source(demc_handle* h, const char* hip_source, const double* data, const int64_t* dims, int32_t ndims,
                               const double* hyper, int32_t nhyper) {
+    return guarded(h, [&]() -> int32_t {
     if (!h || !hip_source) return DEMC_EINVAL;
     USE_DEVICE(h);
     if (ndims < 1 || !dims || dims[0] < 1 || !data) return fail(h, DEMC_EINVAL, "user model: dims[0] = number of observations, data required");
@@ -851,7 +932,7 @@ int32_t demc_set_model_source(demc_handle* h, const char* hip_source, const doub
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "demc_user_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         return fail(h, DEMC_EHIP, "hiprtcCreateProgram failed");
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+    const char* opts[] = {"--offload-arch=" DEMC_ARCH_STR, "-O3", "-std=c++17"};
     const hiprtcResult cr = hiprtcCompileProgram(prog, 3, opts);
     if (cr != HIPRTC_SUCCESS) {
         size_t ls = 0;
@@ -878,6 +959,7 @@ int32_t demc_set_model_source(demc_handle* h, const char* hip_source, const doub
     }
     h->family = FAM_USER;
     return size_k1_lds(h);
+    });
 }
 
 int upload_dimtab(demc_handle* h) {
@@ -887,6 +969,7 @@ int upload_dimtab(demc_handle* h) {
 }
 
 int32_t demc_set_priors(demc_handle* h, const int32_t* kind, const double* a, const double* b, const int32_t* ref) {
+    return guarded(h, [&]() -> int32_t {
     if (!h || !kind) return DEMC_EINVAL;
     USE_DEVICE(h);
     const size_t D = (size_t)h->c.D;
@@ -908,9 +991,11 @@ int32_t demc_set_priors(demc_handle* h, const int32_t* kind, const double* a, co
         t.c = prior_const(kind[j], aj, bj);
     }
     return upload_dimtab(h);
+    });
 }
 
 int32_t demc_set_bounds(demc_handle* h, const double* lo, const double* hi) {
+    return guarded(h, [&]() -> int32_t {
     if (!h || !lo || !hi) return DEMC_EINVAL;
     USE_DEVICE(h);
     const size_t D = (size_t)h->c.D;
@@ -919,9 +1004,11 @@ int32_t demc_set_bounds(demc_handle* h, const double* lo, const double* hi) {
         h->h_tab[j].hi = hi[j];
     }
     return upload_dimtab(h);
+    });
 }
 
 int32_t demc_set_blocks(demc_handle* h, const uint8_t* masks, int32_t n_blocks) {
+    return guarded(h, [&]() -> int32_t {
     if (!h || n_blocks < 0 || (n_blocks > 0 && !masks)) return DEMC_EINVAL;
     USE_DEVICE(h);
     if (h->masks) { hipFree(h->masks); h->masks = nullptr; }
@@ -931,9 +1018,11 @@ int32_t demc_set_blocks(demc_handle* h, const uint8_t* masks, int32_t n_blocks) 
         HIPCHK(hipMemcpy(h->masks, masks, (size_t)n_blocks * h->c.D, hipMemcpyHostToDevice));
     }
     return DEMC_OK;
+    });
 }
 
 int32_t demc_set_state(demc_handle* h, const double* theta, const double* weight, const int64_t* id) {
+    return guarded(h, [&]() -> int32_t {
     if (!h || !theta) return DEMC_EINVAL;
     USE_DEVICE(h);
     const size_t P = (size_t)h->P, D = (size_t)h->c.D;
@@ -950,9 +1039,11 @@ int32_t demc_set_state(demc_handle* h, const double* theta, const double* weight
         HIPCHK(hipGetLastError());
     }
     return DEMC_OK;
+    });
 }
 
 int32_t demc_get_state(demc_handle* h, double* theta, double* weight, int64_t* id) {
+    return guarded(h, [&]() -> int32_t {
     if (!h) return DEMC_EINVAL;
     USE_DEVICE(h);
     const size_t P = (size_t)h->P, D = (size_t)h->c.D;
@@ -961,9 +1052,11 @@ int32_t demc_get_state(demc_handle* h, double* theta, double* weight, int64_t* i
     if (weight) HIPCHK(hipMemcpy(weight, h->weight, P * sizeof(double), hipMemcpyDeviceToHost));
     if (id) HIPCHK(hipMemcpy(id, h->id, P * sizeof(long long), hipMemcpyDeviceToHost));
     return DEMC_OK;
+    });
 }
 
 int32_t demc_set_history_rows(demc_handle* h, int64_t row0, int64_t nrows, const double* rows) {
+    return guarded(h, [&]() -> int32_t {
     if (!h || !rows) return DEMC_EINVAL;
     USE_DEVICE(h);
     if (!h->hist) return fail(h, DEMC_EINVAL, "history is not stored on this handle");
@@ -972,9 +1065,11 @@ int32_t demc_set_history_rows(demc_handle* h, int64_t row0, int64_t nrows, const
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(h->hist + (size_t)row0 * PD, rows, (size_t)nrows * PD * sizeof(double), hipMemcpyHostToDevice));
     return DEMC_OK;
+    });
 }
 
 int32_t demc_get_history(demc_handle* h, int64_t row0, int64_t row1, double* th, uint8_t* acc, double* lp, int64_t* idh) {
+    return guarded(h, [&]() -> int32_t {
     if (!h) return DEMC_EINVAL;
     USE_DEVICE(h);
     if (!h->hist) return fail(h, DEMC_EINVAL, "history is not stored on this handle");
@@ -990,9 +1085,11 @@ int32_t demc_get_history(demc_handle* h, int64_t row0, int64_t row1, double* th,
         for (size_t i = 0; i < n * P; ++i) idh[i] = tmp[i];
     }
     return DEMC_OK;
+    });
 }
 
 int32_t demc_export_chains(demc_handle* h, int64_t row0, int64_t row1, int32_t layout, double* out) {
+    return guarded(h, [&]() -> int32_t {
     if (!h || !out) return DEMC_EINVAL;
     USE_DEVICE(h);
     if (!h->hist) return fail(h, DEMC_EINVAL, "history is not stored on this handle");
@@ -1014,9 +1111,20 @@ int32_t demc_export_chains(demc_handle* h, int64_t row0, int64_t row1, int32_t l
     hipFree(dev);
     if (e != hipSuccess) return fail(h, DEMC_EHIP, std::string("demc_export_chains: ") + hipGetErrorString(e));
     return DEMC_OK;
+    });
+}
+
+// the alpha coin of iteration `iter` as this handle sees it: the replayed uniform while one is set (main.jl:85)
+static bool migration_due_h(demc_handle* h, int64_t iter) {
+    if (h->rp_active && h->rp_has_step) {
+        const int ngt = h->c.n_groups_total > 0 ? h->c.n_groups_total : h->c.n_groups;
+        return h->rp_u_step <= (ngt == 1 ? 0.0 : h->c.alpha);
+    }
+    return demc_migration_due(&h->c, iter) != 0;
 }
 
 static int32_t step_impl(demc_handle* h, int64_t iter0, int32_t n_iters, bool with_migration) {
+    return guarded(h, [&]() -> int32_t {
     if (!h) return DEMC_EINVAL;
     USE_DEVICE(h);
     if (h->family < 0) return fail(h, DEMC_EINVAL, "demc_set_model has not been called");
@@ -1026,14 +1134,14 @@ static int32_t step_impl(demc_handle* h, int64_t iter0, int32_t n_iters, bool wi
         return fail(h, DEMC_EINVAL, "history partners need at least one stored row (n_initial > 0)");
     const int n_sweeps = c.n_blocks > 0 ? c.n_blocks : 1;  // block_update! main.jl:174-179
     for (int64_t iter = iter0; iter < iter0 + n_iters; ++iter) {
-        if (with_migration && demc_migration_due(&c, iter)) {  // main.jl:85
+        if (with_migration && migration_due_h(h, iter)) {  // main.jl:85
             if (c.n_groups_total != c.n_groups)
                 return fail(h, DEMC_EINVAL, "sharded handle: drive the exchange with demc_migration_pack/apply + demc_update");
             migration_enqueue(h, iter, h->mig_rows, h->mig_rows, true, true);
         }
-        if (h->res_ok) {  // every iteration up to the next migration in one launch
+        if (h->res_ok && !h->rp_active) {  // every iteration up to the next migration in one launch
             int run = 1;  // capped so that a single launch stays in the millisecond range whatever the caller asks for
-            while (run < 1024 && iter + run < iter0 + n_iters && !(with_migration && demc_migration_due(&c, iter + run))) ++run;
+            while (run < 1024 && iter + run < iter0 + n_iters && !(with_migration && migration_due_h(h, iter + run))) ++run;
             int rc = launch_resident(h, iter, run);
             if (rc != DEMC_OK) return rc;
             iter += run - 1;
@@ -1050,6 +1158,7 @@ static int32_t step_impl(demc_handle* h, int64_t iter0, int32_t n_iters, bool wi
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
     return DEMC_OK;
+    });
 }
 
 int32_t demc_step(demc_handle* h, int64_t iter0, int32_t n_iters) { return step_impl(h, iter0, n_iters, true); }
@@ -1064,15 +1173,18 @@ int32_t demc_migration_due(const demc_config* cfg, int64_t iter) {
 }
 
 int32_t demc_migration_pack(demc_handle* h, int64_t iter, double* dev_rows) {
+    return guarded(h, [&]() -> int32_t {
     if (!h) return DEMC_EINVAL;
     USE_DEVICE(h);
     migration_enqueue(h, iter, dev_rows ? dev_rows : h->mig_rows, nullptr, true, false);
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
     return DEMC_OK;
+    });
 }
 
 int32_t demc_migration_apply(demc_handle* h, int64_t iter, const double* dev_all_rows) {
+    return guarded(h, [&]() -> int32_t {
     if (!h) return DEMC_EINVAL;
     USE_DEVICE(h);
     if (!dev_all_rows && h->c.n_groups_total != h->c.n_groups)
@@ -1081,9 +1193,11 @@ int32_t demc_migration_apply(demc_handle* h, int64_t iter, const double* dev_all
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
     return DEMC_OK;
+    });
 }
 
 int32_t demc_apply_migration(demc_handle* h, const int32_t* src_slot, const int32_t* dst_slot, int32_t n) {
+    return guarded(h, [&]() -> int32_t {
     if (!h || n < 0 || (n > 0 && (!src_slot || !dst_slot))) return DEMC_EINVAL;
     USE_DEVICE(h);
     if (n == 0) return DEMC_OK;
@@ -1117,6 +1231,7 @@ int32_t demc_apply_migration(demc_handle* h, const int32_t* src_slot, const int3
     hipFree(d_slots);
     hipFree(d_stage);
     return rc;
+    });
 }
 
 int32_t demc_get_weights(demc_handle* h, double* weight) {
@@ -1125,6 +1240,7 @@ int32_t demc_get_weights(demc_handle* h, double* weight) {
 }
 
 int32_t demc_logpost(demc_handle* h, const double* theta, int64_t n, double* out) {
+    return guarded(h, [&]() -> int32_t {
     if (!h || !theta || !out || n < 0) return DEMC_EINVAL;
     USE_DEVICE(h);
     if (h->family < 0) return fail(h, DEMC_EINVAL, "demc_set_model has not been called");
@@ -1143,9 +1259,66 @@ int32_t demc_logpost(demc_handle* h, const double* theta, int64_t n, double* out
         std::memcpy(out + off, w.data(), m * sizeof(double));
     }
     return DEMC_OK;
+    });
+}
+
+int32_t demc_set_replay(demc_handle* h, const demc_replay* r) {
+    return guarded(h, [&]() -> int32_t {
+    if (!h) return DEMC_EINVAL;
+    USE_DEVICE(h);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    free_replay(h);
+    if (!r) return DEMC_OK;
+    const demc_config& c = h->c;
+    const size_t P = (size_t)h->P, D = (size_t)c.D, G = (size_t)c.n_groups;
+    if (r->partner)
+        for (size_t i = 0; i < 3 * P; ++i)
+            if (r->partner[i] >= c.Np) return fail(h, DEMC_EINVAL, "replay: partner row outside the group");
+    if (r->mig_particle)
+        for (size_t g = 0; g < G; ++g)
+            if (r->mig_particle[g] >= c.Np) return fail(h, DEMC_EINVAL, "replay: migration particle outside the group");
+    if (r->n_mig_groups < 0 || r->n_mig_groups > c.n_groups_total || (r->n_mig_groups > 0 && !r->mig_groups))
+        return fail(h, DEMC_EINVAL, "replay: bad migration sub-group");
+    {
+        std::vector<char> seen((size_t)c.n_groups_total, 0);
+        for (int i = 0; i < r->n_mig_groups; ++i) {
+            const int g = r->mig_groups[i];
+            if (g < 0 || g >= c.n_groups_total || seen[(size_t)g]) return fail(h, DEMC_EINVAL, "replay: migration groups must be distinct and in range");
+            seen[(size_t)g] = 1;
+        }
+    }
+    auto up = [&](auto** dst, const auto* src, size_t n) -> int {
+        if (!src || n == 0) return DEMC_OK;
+        int rc = dev_alloc(h, dst, n);
+        if (rc != DEMC_OK) return rc;
+        HIPCHK(hipMemcpy(*dst, src, n * sizeof(**dst), hipMemcpyHostToDevice));
+        return DEMC_OK;
+    };
+    int rc = DEMC_OK;
+    if (rc == DEMC_OK) rc = up(&h->rp_group, r->u_group, G);
+    if (rc == DEMC_OK) rc = up(&h->rp_part, r->u_part, 5 * P);
+    if (rc == DEMC_OK) rc = up(&h->rp_partner, reinterpret_cast<const long long*>(r->partner), 3 * P);
+    if (rc == DEMC_OK) rc = up(&h->rp_noise, r->u_noise, P * D);
+    if (rc == DEMC_OK) rc = up(&h->rp_znoise, r->z_noise, P * D);
+    if (rc == DEMC_OK) rc = up(&h->rp_recomb, r->u_recomb, P * D);
+    if (rc == DEMC_OK) rc = up(&h->rp_mig_particle, reinterpret_cast<const long long*>(r->mig_particle), G);
+    if (rc == DEMC_OK) rc = up(&h->rp_mig_groups, r->mig_groups, (size_t)r->n_mig_groups);
+    if (rc != DEMC_OK) {
+        free_replay(h);
+        return rc;
+    }
+    h->rp_n_mig = r->n_mig_groups;
+    if (r->u_step && r->u_step[0] == r->u_step[0]) {
+        h->rp_has_step = true;
+        h->rp_u_step = r->u_step[0];
+    }
+    h->rp_active = true;
+    return DEMC_OK;
+    });
 }
 
 int32_t demc_get_trace(demc_handle* h, double* proposal, double* w_prop, double* log_adj, int32_t* idx, uint8_t* accepted) {
+    return guarded(h, [&]() -> int32_t {
     if (!h) return DEMC_EINVAL;
     USE_DEVICE(h);
     const size_t P = (size_t)h->P, D = (size_t)h->c.D;
@@ -1156,18 +1329,22 @@ int32_t demc_get_trace(demc_handle* h, double* proposal, double* w_prop, double*
     if (idx) HIPCHK(hipMemcpy(idx, h->tr_idx, P * 4 * sizeof(int), hipMemcpyDeviceToHost));
     if (accepted) HIPCHK(hipMemcpy(accepted, h->tr_acc, P, hipMemcpyDeviceToHost));
     return DEMC_OK;
+    });
 }
 
 int32_t demc_timing_enable(demc_handle* h, int32_t on) {
+    return guarded(h, [&]() -> int32_t {
     if (!h) return DEMC_EINVAL;
     USE_DEVICE(h);
     HIPCHK(hipStreamSynchronize(h->stream));
     drain_events(h);
     h->timing = on != 0;
     return DEMC_OK;
+    });
 }
 
 int32_t demc_timing_read(demc_handle* h, double* out10, int32_t reset) {
+    return guarded(h, [&]() -> int32_t {
     if (!h || !out10) return DEMC_EINVAL;
     USE_DEVICE(h);
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1179,6 +1356,7 @@ int32_t demc_timing_read(demc_handle* h, double* out10, int32_t reset) {
     if (reset)
         for (int i = 0; i < 5; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
     return DEMC_OK;
+    });
 }
 
 }  // extern "C"

@@ -104,7 +104,23 @@ struct KParams {
     const double* data;       // family specific
     const double* data2;
     double c0, c1, c2;        // family constants
+    // replay (demc_set_replay, test mode): device copies of the caller's draws, null = addressed Philox as usual
+    const double* rp_group;         // [n_groups]
+    const double* rp_part;          // [P][5] snooker coin, select_base, gamma_1, gamma_2, accept
+    const long long* rp_partner;    // [P][3] rows inside the group
+    const double* rp_noise;         // [P][D]
+    const double* rp_znoise;        // [P][D]
+    const double* rp_recomb;        // [P][D]
+    const int* rp_mig_groups;       // [rp_n_mig] global groups
+    const long long* rp_mig_particle;  // [n_groups]
+    int rp_n_mig;
 };
+// a replayed uniform replaces the drawn one unless it is NaN
+__device__ inline double replayed(const double* tab, size_t i, double drawn) {
+    if (!tab) return drawn;
+    const double v = tab[i];
+    return v == v ? v : drawn;
+}
 
 typedef double d4 __attribute__((ext_vector_type(4)));  // C/D fragment of v_mfma_f64_16x16x4_f64
 
@@ -583,7 +599,9 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
     bool is_mut = false;  // the group's coin, drawn while those loads are in flight
     if (p.mode == MODE_STEP) {
         const U4 r = draw_block(p.seed, S_GROUP, p.sweep, (uint64_t)p.iter, (uint32_t)g_glob, 0);
-        is_mut = u53(r.x, r.y) <= p.beta;  // mutate_or_crossover! main.jl:199-207
+        double u_coin = u53(r.x, r.y);
+        if (!PLAIN) u_coin = replayed(p.rp_group, (size_t)g, u_coin);
+        is_mut = u_coin <= p.beta;  // mutate_or_crossover! main.jl:199-207
     }
     const bool de_any = (p.mode == MODE_STEP) && !is_mut;
     const bool use_base = de_any && maybe_base;
@@ -824,6 +842,8 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
         double g1 = 0.0, g2 = 0.0, cm = 0.0, cn = 0.0;
         bool base_on = false;
         double u_acc = u53(ra.x, ra.y);
+        if (!PLAIN) u_acc = replayed(p.rp_part, slot * 5 + 4, u_acc);
+        const long long* rpi = (!PLAIN && p.rp_partner) ? p.rp_partner + slot * 3 : nullptr;
         if (planned) {
             const int ql = valid ? q - q_lo : 0;
             kind = plan_i[4 * ql + 0];
@@ -852,8 +872,14 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
             if (is_mut)
                 kind = 2;
             else {
-                const double u_snk = u53(r0.x, r0.y), u_base = u53(r0.z, r0.w);
-                const double u_g1 = u53(rg.x, rg.y), u_g2 = u53(rg.z, rg.w);
+                double u_snk = u53(r0.x, r0.y), u_base = u53(r0.z, r0.w);
+                double u_g1 = u53(rg.x, rg.y), u_g2 = u53(rg.z, rg.w);
+                if (!PLAIN && p.rp_part) {
+                    u_snk = replayed(p.rp_part, slot * 5 + 0, u_snk);
+                    u_base = replayed(p.rp_part, slot * 5 + 1, u_base);
+                    u_g1 = replayed(p.rp_part, slot * 5 + 2, u_g1);
+                    u_g2 = replayed(p.rp_part, slot * 5 + 3, u_g2);
+                }
                 const bool snooker = !PLAIN && u_snk <= p.theta_snooker;  // crossover.jl:31
                 kind = snooker ? 1 : 0;
                 if (hist_partners) {
@@ -879,6 +905,11 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
                     uint32_t a, b, c;  // snooker_update! draws 3 from the whole pool (crossover.jl:241)
                     pick_triple(ri.x, ri.y, ri.z, (uint32_t)p.pool_n, a, b, c);
                     a += p.pool_lo; b += p.pool_lo; c += p.pool_lo;
+                    if (rpi) {
+                        if (rpi[0] >= 0) a = (uint32_t)rpi[0];
+                        if (rpi[1] >= 0) b = (uint32_t)rpi[1];
+                        if (rpi[2] >= 0) c = (uint32_t)rpi[2];
+                    }
                     Pa = rows + (size_t)a * D; Pb2 = rows + (size_t)b * D; Pc = rows + (size_t)c * D;
                     i0 = (int)a; i1 = (int)b; i2 = (int)c;
                 } else {
@@ -890,6 +921,10 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
                     } else
                         pick_pair(ri.x, ri.y, (uint32_t)p.pool_n, a, b);
                     a += p.pool_lo; b += p.pool_lo;
+                    if (rpi) {
+                        if (rpi[0] >= 0) a = (uint32_t)rpi[0];
+                        if (rpi[1] >= 0) b = (uint32_t)rpi[1];
+                    }
                     Pa = rows + (size_t)a * D; Pb2 = rows + (size_t)b * D;
                     i0 = (int)a; i1 = (int)b;
                 }
@@ -926,6 +961,7 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
                                 b = cnt < n_cdf ? cnt : n_cdf - 1;
                             }
                             b += p.pool_lo;
+                            if (rpi && rpi[2] >= 0) b = (int)rpi[2];
                             Pbase = rows + (size_t)b * D;
                             i2 = b;
                             base_on = true;
@@ -975,21 +1011,35 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
                 keep1 = has1 && !p.mask[j1];
             }
             const U4 nz = draw_block(p.seed, S_NOISE, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)k);
-            const double u0 = u53(nz.x, nz.y), u1 = u53(nz.z, nz.w);
+            double u0 = u53(nz.x, nz.y), u1 = u53(nz.z, nz.w);
             if (kind == 2) {  // pt + Normal(0, sigma): mutation.jl:15-18 (block mask ignored, main.jl:205)
                 const double rad = sqrt(-2.0 * log(1.0 - u0));
                 double sn, cs;
                 sincospi(2.0 * u1, &sn, &cs);  // Box-Muller angle 2*pi*u1
-                v0 = t0 + p.sigma * (rad * cs);
-                v1 = t1 + p.sigma * (rad * sn);
+                double z0 = rad * cs, z1 = rad * sn;
+                if (!PLAIN && p.rp_znoise) {
+                    z0 = replayed(p.rp_znoise, slot * D + j0, z0);
+                    if (has1) z1 = replayed(p.rp_znoise, slot * D + j1, z1);
+                }
+                v0 = t0 + p.sigma * z0;
+                v1 = t1 + p.sigma * z1;
                 return;
+            }
+            if (!PLAIN && p.rp_noise) {
+                u0 = replayed(p.rp_noise, slot * D + j0, u0);
+                if (has1) u1 = replayed(p.rp_noise, slot * D + j1, u1);
             }
             v0 = cross(j0, t0, u0);
             if (has1) v1 = cross(j1, t1, u1);
             if (!PLAIN && p.kappa != 1.0) {  // recombination! crossover.jl:301-312
                 const U4 rc = draw_block(p.seed, S_RECOMB, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)k);
-                if (u53(rc.x, rc.y) <= 1.0 - p.kappa) v0 = t0;
-                if (u53(rc.z, rc.w) <= 1.0 - p.kappa) v1 = t1;
+                double c0u = u53(rc.x, rc.y), c1u = u53(rc.z, rc.w);
+                if (p.rp_recomb) {
+                    c0u = replayed(p.rp_recomb, slot * D + j0, c0u);
+                    if (has1) c1u = replayed(p.rp_recomb, slot * D + j1, c1u);
+                }
+                if (c0u <= 1.0 - p.kappa) v0 = t0;
+                if (c1u <= 1.0 - p.kappa) v1 = t1;
             }
             if (keep0) v0 = t0;
             if (keep1) v1 = t1;
@@ -1443,7 +1493,8 @@ __global__ __launch_bounds__(256) void k_accept_store(KParams p) {
             wp = oob ? -INFINITY : p.prop_prior[slot] + finalize_loglike(p, slot, s_sum);
         const uint32_t eslot = (uint32_t)(p.group_offset + g) * (uint32_t)p.Np + (uint32_t)pl;
         const U4 ra = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, 3);
-        acc = decide(p, u53(ra.x, ra.y), wp, w, p.prop_adj[slot]);  // mh_update! / maximize! / minimize!
+        const double u_acc = replayed(p.rp_part, slot * 5 + 4, u53(ra.x, ra.y));
+        acc = decide(p, u_acc, wp, w, p.prop_adj[slot]);  // mh_update! / maximize! / minimize!
         w_new = acc ? wp : w;
         if (acc) p.weight[slot] = wp;
         if (p.trace) {
@@ -1491,7 +1542,8 @@ __global__ __launch_bounds__(256) void k_accept_store(KParams p) {
 
 // ------------------------------------------------------------------------------------------------
 // Migration (migration.jl:11-91).  pack: one workgroup per local group picks its candidate
-// (select_particle: P(j) ~ exp(-(w_j - min w)); non-finite weights -> argmin, as findmin) and writes
+// (select_particle: P(j) ~ exp(-(w_j - min w)); where the reference's exp.(-w)/sum would hold a NaN -- a weight of -Inf
+// or NaN, or every weight +Inf -- argmin, as its findmin fallback; a single +Inf weight is just probability 0) and writes
 // the row (slot, theta[D], weight, id).  apply: every workgroup recomputes the group subset from the
 // shared Philox STEP stream (select_groups) and the i-th selected local group receives the candidate
 // of the (i-1)-th (circshift(particles, 1)).
@@ -1511,7 +1563,7 @@ __global__ __launch_bounds__(256) void k_mig_pack(KParams p, double* __restrict_
     if (tid == 0) s_bad = 0;
     for (int i = tid; i < Np; i += 256) {
         const double w = gw[i];
-        if (!(w > -INFINITY && w < INFINITY)) bad = 1;
+        if (!(w > -INFINITY)) bad = 1;  // -Inf or NaN: exp(-w)/sum is NaN in the reference (migration.jl:66-69)
         if (w < m) { m = w; am = i; }
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -1528,7 +1580,7 @@ __global__ __launch_bounds__(256) void k_mig_pack(KParams p, double* __restrict_
         const int a2 = s_redi[k];
         if (m2 < m || (m2 == m && a2 < am)) { m = m2; am = a2; }
     }
-    if (s_bad) {
+    if (s_bad || !(m < INFINITY)) {  // (all weights +Inf: 0/0 there too)
         if (tid == 0) s_pick = am < Np ? am : 0;
     } else {
         // P(j) ~ exp(-(w_j - min w)); cumulative weights in the fixed two-level order shared with the oracle
@@ -1570,7 +1622,8 @@ __global__ __launch_bounds__(256) void k_mig_pack(KParams p, double* __restrict_
         }
     }
     __syncthreads();
-    const int j = s_pick;
+    int j = s_pick;
+    if (p.rp_mig_particle && p.rp_mig_particle[g] >= 0) j = (int)p.rp_mig_particle[g];  // replayed select_particle
     const size_t slot = (size_t)g * Np + j;
     double* o = rows + (size_t)g * (D + 3);
     if (tid == 0) {
@@ -1618,7 +1671,10 @@ __global__ __launch_bounds__(256) void k_mig_apply(KParams p, const double* __re
     }
     for (int i = tid; i < ng; i += 256) perm[i] = i;
     __syncthreads();
-    if (tid == 0) {
+    if (p.rp_n_mig > 0) {  // replayed select_groups: the caller's ordered sub-group
+        for (int i = tid; i < p.rp_n_mig; i += 256) perm[i] = p.rp_mig_groups[i];
+        if (tid == 0) s_ns = p.rp_n_mig;
+    } else if (tid == 0) {
         const U4 r = draw_block(p.seed, S_STEP, 0, (uint64_t)p.iter, 0, 0);
         const int ns = 2 + (int)mulhi32(r.z, (uint32_t)(ng - 1));
         for (int i = 0; i < ns; ++i) {

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DEMC_VERSION 100 /* 0.1.0 */
+#define DEMC_VERSION 110 /* 0.1.1 */
 
 enum {
     DEMC_OK = 0,
@@ -56,7 +56,11 @@ enum { DEMC_FITNESS_POSTERIOR = 0, DEMC_FITNESS_FUN = 1 };
  *   SYNCHRONOUS: all particles of a group propose from the sweep-start state;
  *   TWO_COLOUR : the first half of the group proposes with partners from the second half,
  *                then the halves swap (each half-update is a valid Metropolis-within-Gibbs step).
- * DEMC_SCHED_SEQUENTIAL is defined for the CPU oracle only and is rejected here. */
+ *   SEQUENTIAL : the reference's own sweep -- particle k of every group moves after particles 0..k-1 of its group have
+ *                been updated in place.  On the device this is Np dependent launches per sweep (all groups in
+ *                parallel, one particle of each at a time, like one task per group in p_update!, main.jl:135-148):
+ *                slow by construction; it exists so that, together with demc_set_replay, a run can follow the
+ *                reference's schedule with the reference's random numbers. */
 enum { DEMC_SCHED_SEQUENTIAL = 0, DEMC_SCHED_SYNCHRONOUS = 1, DEMC_SCHED_TWO_COLOUR = 2 };
 /* How Gaussian-family likelihoods are evaluated.
  *   STREAMING : every proposal visits every observation, as model.loglike does
@@ -127,6 +131,11 @@ typedef struct demc_config {
                                 2: fuse, but one launch per colour phase (no resident form).  Same samples in all three; a
                                 log-density can differ in its last bits between them (a particle may be split over a
                                 different number of lanes, which changes the order of the sums). */
+    int32_t geometry_groups; /* 0: size the kernels' lane geometry (lanes per particle) for this shard's n_groups.  > 0: size
+                                it as if the handle owned this many groups -- shards of one population then all use the
+                                geometry of the unsharded run, and an N-shard run reproduces the 1-shard run bit for bit
+                                (without it the log-densities can differ in their last bits, see `fuse`). */
+    int32_t reserved0;
 } demc_config;
 
 typedef struct demc_handle demc_handle;
@@ -206,6 +215,29 @@ int32_t demc_logpost(demc_handle* h, const double* theta, int64_t n, double* out
  * partner indices [P][4] = (kind 0 DE / 1 snooker / 2 mutation, i0, i1, i2) and accept flags. */
 int32_t demc_get_trace(demc_handle* h, double* proposal, double* w_prop, double* log_adj, int32_t* idx,
                        uint8_t* accepted);
+
+/* Test mode: caller-supplied random numbers in place of the library's addressed Philox draws, so that a
+ * host that owns the reference's RNG (Julia's task-local stream) can feed ITS draws -- in the order of SURVEY Appendix A
+ * -- and compare index bookkeeping and proposals bit for bit.  All pointers are HOST arrays, copied at the call; a NULL
+ * member, a NaN uniform or a negative index means "draw as usual".  The replay stays in force for every following sweep
+ * until demc_set_replay(h, NULL).  While it is set the general (unfused-plan) form of the kernels runs.
+ * Partner rows are 0-based positions INSIDE the particle's group and are the caller's responsibility to keep legal for
+ * the schedule (two_colour: rows of the resting half); they are range-checked against [0, Np). */
+typedef struct demc_replay {
+    const double* u_step;        /* [1]       alpha coin of step! (main.jl:85)                                              */
+    const double* u_group;       /* [n_groups] beta coin of mutate_or_crossover! for each local group (main.jl:200)         */
+    const double* u_part;        /* [P][5]    snooker coin (crossover.jl:31), select_base uniform (:156), gamma_1 uniform
+                                              (:162, snooker gamma :249), gamma_2 uniform (:164), accept uniform (utilities.jl:57) */
+    const int64_t* partner;      /* [P][3]    DE: (Pm, Pn, Pb) (crossover.jl:156-160); snooker: (Pz, Pm, Pn) (:241)         */
+    const double* u_noise;       /* [P][D]    uniforms behind b ~ Uniform(-eps, eps), Theta order (crossover.jl:166)        */
+    const double* z_noise;       /* [P][D]    standard normals of mutation! (mutation.jl:15; utilities.jl:291-306)          */
+    const double* u_recomb;      /* [P][D]    recombination! uniforms (crossover.jl:308,318)                                */
+    const int32_t* mig_groups;   /* [n_mig_groups] select_groups' ordered sub-group, GLOBAL group indices (migration.jl:31-35) */
+    int32_t n_mig_groups;        /* 0: draw the sub-group as usual                                                          */
+    int32_t reserved;
+    const int64_t* mig_particle; /* [n_groups] select_particle's pick for each local group (migration.jl:64-70)             */
+} demc_replay;
+int32_t demc_set_replay(demc_handle* h, const demc_replay* replay);
 
 /* Device time (ms) spent in each kernel class since the last reset, measured with HIP events on the handle's
  * stream when timing is enabled: out[0]=propose (K1), [1]=likelihood preparation, [2]=main likelihood kernel (K2),

@@ -95,6 +95,13 @@ struct orc_handle {
     double *tr_prop, *tr_w, *tr_adj;
     int32_t* tr_idx;
     uint8_t* tr_acc;
+    /* replay (orc_set_replay): copies of the caller's draws; NULL = addressed Philox */
+    double *rp_group, *rp_part, *rp_noise, *rp_znoise, *rp_recomb;
+    int64_t *rp_partner, *rp_mig_particle;
+    int32_t* rp_mig_groups;
+    int32_t rp_n_mig;
+    int rp_has_step;
+    double rp_u_step;
     char err[256];
 };
 
@@ -145,8 +152,56 @@ int orc_create(const orc_config* cfg, orc_handle** out) {
     return ORC_OK;
 }
 
+static void free_replay(orc_handle* h) {
+    free(h->rp_group); free(h->rp_part); free(h->rp_noise); free(h->rp_znoise); free(h->rp_recomb);
+    free(h->rp_partner); free(h->rp_mig_particle); free(h->rp_mig_groups);
+    h->rp_group = h->rp_part = h->rp_noise = h->rp_znoise = h->rp_recomb = NULL;
+    h->rp_partner = h->rp_mig_particle = NULL;
+    h->rp_mig_groups = NULL;
+    h->rp_n_mig = 0;
+    h->rp_has_step = 0;
+}
+static void* dup_mem(const void* src, size_t bytes) {
+    if (!src || !bytes) return NULL;
+    void* d = malloc(bytes);
+    if (d) memcpy(d, src, bytes);
+    return d;
+}
+/* Test mode: caller-supplied draws in place of the addressed Philox draws -- same contract as
+ * demc_set_replay (include/demc.h): NULL member / NaN uniform / negative index = draw as usual. */
+int orc_set_replay(orc_handle* h, const orc_replay* r) {
+    if (!h) return ORC_EINVAL;
+    free_replay(h);
+    if (!r) return ORC_OK;
+    const size_t P = (size_t)h->P, D = (size_t)h->c.D, G = (size_t)h->c.n_groups;
+    if (r->partner)
+        for (size_t i = 0; i < 3 * P; ++i)
+            if (r->partner[i] >= h->c.Np) return fail(h, ORC_EINVAL, "replay: partner row outside the group");
+    if (r->n_mig_groups < 0 || r->n_mig_groups > h->c.n_groups_total) return fail(h, ORC_EINVAL, "replay: bad migration sub-group");
+    h->rp_group = (double*)dup_mem(r->u_group, G * sizeof(double));
+    h->rp_part = (double*)dup_mem(r->u_part, 5 * P * sizeof(double));
+    h->rp_partner = (int64_t*)dup_mem(r->partner, 3 * P * sizeof(int64_t));
+    h->rp_noise = (double*)dup_mem(r->u_noise, P * D * sizeof(double));
+    h->rp_znoise = (double*)dup_mem(r->z_noise, P * D * sizeof(double));
+    h->rp_recomb = (double*)dup_mem(r->u_recomb, P * D * sizeof(double));
+    h->rp_mig_particle = (int64_t*)dup_mem(r->mig_particle, G * sizeof(int64_t));
+    h->rp_mig_groups = (int32_t*)dup_mem(r->mig_groups, (size_t)r->n_mig_groups * sizeof(int32_t));
+    h->rp_n_mig = r->mig_groups ? r->n_mig_groups : 0;
+    if (r->u_step && r->u_step[0] == r->u_step[0]) {
+        h->rp_has_step = 1;
+        h->rp_u_step = r->u_step[0];
+    }
+    return ORC_OK;
+}
+static inline double replayed(const double* tab, size_t i, double drawn) {
+    if (!tab) return drawn;
+    const double v = tab[i];
+    return v == v ? v : drawn;
+}
+
 void orc_destroy(orc_handle* h) {
     if (!h) return;
+    free_replay(h);
     free(h->theta); free(h->weight); free(h->id); free(h->lo); free(h->hi); free(h->blocks);
     free(h->pk); free(h->pa); free(h->pb); free(h->pref); free(h->data); free(h->hyper);
     free(h->Z); free(h->L); free(h->lgc); free(h->hist); free(h->acc_hist); free(h->lp_hist); free(h->id_hist);
@@ -737,16 +792,17 @@ static int32_t select_base_stable(const double* w, int32_t n, double u) {
     free(cdf);
     return r;
 }
-/* Stabilised select_particle: P(j) ~ exp(-(w_j - wmin)); non-finite weights -> argmin (first), like findmin. */
+/* Stabilised select_particle: P(j) ~ exp(-(w_j - wmin)); where the reference's normalised weights would hold a NaN
+ * (a -Inf or NaN weight, or all +Inf) -> argmin (first), like its findmin fallback. */
 static int32_t select_particle_stable(const double* w, int32_t n, double u) {
     double wmin = INFINITY;
     int32_t amin = 0;
     int bad = 0;
     for (int i = 0; i < n; ++i) {
-        if (!(w[i] > -INFINITY && w[i] < INFINITY)) bad = 1;
+        if (!(w[i] > -INFINITY)) bad = 1; /* -Inf or NaN: exp.(-w)/sum holds a NaN -> findmin (migration.jl:66-69) */
         if (w[i] < wmin) { wmin = w[i]; amin = i; }
     }
-    if (bad) return amin;
+    if (bad || !(wmin < INFINITY)) return amin; /* every weight +Inf: 0/0 as well; one +Inf weight is just probability 0 */
     /* cumulative weights exp(wmin - w_i) in the same fixed two-level order as select_base_stable */
     double* cdf = (double*)malloc(sizeof(double) * (size_t)n);
     double off = 0.0;
@@ -813,6 +869,8 @@ static void propose(orc_handle* h, int64_t iter, uint32_t sweep, int32_t g_glob,
                     int32_t idx[4]) {
     const int D = h->c.D, Np = h->c.Np;
     const uint32_t slot = (uint32_t)g_glob * (uint32_t)Np + (uint32_t)p;
+    const int64_t lslot = (int64_t)(g_glob - h->c.group_offset) * Np + p; /* local slot: index into the replay tables */
+    const int64_t* rpi = h->rp_partner ? h->rp_partner + lslot * 3 : NULL;
     const uint64_t seed = h->c.seed;
     uint32_t r[4];
     *log_adj = 0.0;
@@ -824,18 +882,22 @@ static void propose(orc_handle* h, int64_t iter, uint32_t sweep, int32_t g_glob,
             draw_block(seed, S_NOISE, sweep, (uint64_t)iter, slot, (uint32_t)k, r);
             const double u1 = orc_u53(r[0], r[1]), u2 = orc_u53(r[2], r[3]);
             const double rad = sqrt(-2.0 * log(1.0 - u1));
-            const double z0 = rad * cos(2.0 * PI_D * u2), z1 = rad * sin(2.0 * PI_D * u2);
+            double z0 = rad * cos(2.0 * PI_D * u2), z1 = rad * sin(2.0 * PI_D * u2);
+            z0 = replayed(h->rp_znoise, (size_t)lslot * D + 2 * k, z0);
+            if (2 * k + 1 < D) z1 = replayed(h->rp_znoise, (size_t)lslot * D + 2 * k + 1, z1);
             prop[2 * k] = pt[2 * k] + h->c.sigma * z0;
             if (2 * k + 1 < D) prop[2 * k + 1] = pt[2 * k + 1] + h->c.sigma * z1;
         }
         return;
     }
     draw_block(seed, S_PART, sweep, (uint64_t)iter, slot, 0, r);
-    const double u_snk = orc_u53(r[0], r[1]), u_base = orc_u53(r[2], r[3]);
+    const double u_snk = replayed(h->rp_part, (size_t)lslot * 5 + 0, orc_u53(r[0], r[1]));
+    const double u_base = replayed(h->rp_part, (size_t)lslot * 5 + 1, orc_u53(r[2], r[3]));
     uint32_t ri[4];
     draw_block(seed, S_PART, sweep, (uint64_t)iter, slot, 1, ri);
     draw_block(seed, S_PART, sweep, (uint64_t)iter, slot, 2, r);
-    const double u_g1 = orc_u53(r[0], r[1]), u_g2 = orc_u53(r[2], r[3]);
+    const double u_g1 = replayed(h->rp_part, (size_t)lslot * 5 + 2, orc_u53(r[0], r[1]));
+    const double u_g2 = replayed(h->rp_part, (size_t)lslot * 5 + 3, orc_u53(r[2], r[3]));
     const int snooker = (u_snk <= h->c.theta_snooker); /* crossover.jl:31 */
     const int from_hist = (h->c.partner_kind == ORC_PARTNER_HISTORY);
     const double *P1 = NULL, *P2 = NULL, *P3 = NULL;
@@ -866,32 +928,34 @@ static void propose(orc_handle* h, int64_t iter, uint32_t sweep, int32_t g_glob,
             uint32_t a, b, c;
             pick_triple(ri[0], ri[1], ri[2], (uint32_t)gv->pool_n, &a, &b, &c);
             a += gv->pool_lo; b += gv->pool_lo; c += gv->pool_lo;
+            if (rpi) {
+                if (rpi[0] >= 0) a = (uint32_t)rpi[0];
+                if (rpi[1] >= 0) b = (uint32_t)rpi[1];
+                if (rpi[2] >= 0) c = (uint32_t)rpi[2];
+            }
             P1 = gv->rows + (int64_t)a * D; P2 = gv->rows + (int64_t)b * D; P3 = gv->rows + (int64_t)c * D;
             idx[1] = (int32_t)a; idx[2] = (int32_t)b; idx[3] = (int32_t)c;
         }
         const double *Pz = P1, *Pm = P2, *Pn = P3;
-        double vm = 0.0, vn = 0.0, vd = 0.0;
-        for (int j = 0; j < D; ++j) { /* project: sum over all scalars, utilities.jl:240-244 */
-            const double d = pt[j] - Pz[j];
-            vm += Pm[j] * d;
-            vn += Pn[j] * d;
-            vd += d * d;
-        }
-        const double cm = vm / vd, cn = vn / vd;
+        /* Pd = Pt - Pz; Pr1 = project(Pm, Pd); Pr2 = project(Pn, Pd)  (crossover.jl:243-247): the KAT-checked helpers */
+        double* tmp = (double*)malloc(sizeof(double) * (size_t)D * 4);
+        double *Pd = tmp, *Pr1 = tmp + D, *Pr2 = tmp + 2 * D, *dif = tmp + 3 * D;
+        orc_axpby(pt, Pz, 1.0, -1.0, D, Pd);
+        orc_project(Pm, Pd, D, Pr1);
+        orc_project(Pn, Pd, D, Pr2);
         const double gam = 1.2 + (2.2 - 1.2) * u_g1; /* rand(Uniform(1.2,2.2)) crossover.jl:249 */
-        double s1 = 0.0, s2 = 0.0;
+        /* (Pt + gamma*(Pr1 - Pr2)) + b  crossover.jl:253 */
+        orc_axpby(Pr1, Pr2, 1.0, -1.0, D, dif);
+        orc_axpby(pt, dif, 1.0, gam, D, prop);
+        free(tmp);
         for (int k = 0; 2 * k < D; ++k) {
             draw_block(seed, S_NOISE, sweep, (uint64_t)iter, slot, (uint32_t)k, r);
             const double uu[2] = {orc_u53(r[0], r[1]), orc_u53(r[2], r[3])};
             for (int q = 0; q < 2 && 2 * k + q < D; ++q) {
                 const int j = 2 * k + q;
-                const double d = pt[j] - Pz[j];
-                const double pr1 = d * cm, pr2 = d * cn;
-                const double t1 = pr1 - pr2;
-                const double t2 = t1 * gam;
-                const double t3 = pt[j] + t2;
-                const double bj = -eps + (eps - (-eps)) * uu[q];
-                prop[j] = t3 + bj;
+                const double u = replayed(h->rp_noise, (size_t)lslot * D + j, uu[q]);
+                const double bj = -eps + (eps - (-eps)) * u; /* rand(Uniform(-eps, eps)) */
+                prop[j] = prop[j] + bj;
             }
         }
         /* recombination! then reset! then adjust_loglike (crossover.jl:255, :84-85) */
@@ -900,15 +964,10 @@ static void propose(orc_handle* h, int64_t iter, uint32_t sweep, int32_t g_glob,
                 draw_block(seed, S_RECOMB, sweep, (uint64_t)iter, slot, (uint32_t)k, r);
                 const double uu[2] = {orc_u53(r[0], r[1]), orc_u53(r[2], r[3])};
                 for (int q = 0; q < 2 && 2 * k + q < D; ++q)
-                    if (uu[q] <= 1.0 - h->c.kappa) prop[2 * k + q] = pt[2 * k + q];
+                    if (replayed(h->rp_recomb, (size_t)lslot * D + 2 * k + q, uu[q]) <= 1.0 - h->c.kappa) prop[2 * k + q] = pt[2 * k + q];
             }
         if (mask) orc_reset(prop, pt, mask, D);
-        for (int j = 0; j < D; ++j) {
-            const double a = prop[j] - Pz[j], b = pt[j] - Pz[j];
-            s1 += a * a;
-            s2 += b * b;
-        }
-        *log_adj = (double)(D - 1) * (0.5 * log(s1) - 0.5 * log(s2));
+        *log_adj = orc_adjust_loglike(pt, prop, Pz, D, 0); /* crossover.jl:84-85: after reset! */
         return;
     }
     /* DE branch: random_gamma / fixed_gamma / variable_gamma  crossover.jl:154-226 */
@@ -919,7 +978,8 @@ static void propose(orc_handle* h, int64_t iter, uint32_t sweep, int32_t g_glob,
     if (use_base) {
         /* crossover.jl:156.  The base is drawn from the partner pool: the whole group in the reference schedules;
          * in two_colour the fixed half, so that a moving particle reads nothing that can move in the same phase */
-        const int32_t b = gv->pool_lo + select_base_stable(gv->w + gv->pool_lo, gv->pool_n, u_base);
+        int32_t b = gv->pool_lo + select_base_stable(gv->w + gv->pool_lo, gv->pool_n, u_base);
+        if (rpi && rpi[2] >= 0) b = (int32_t)rpi[2];
         Pb = gv->rows + (int64_t)b * D;
         idx[3] = b;
     }
@@ -933,6 +993,10 @@ static void propose(orc_handle* h, int64_t iter, uint32_t sweep, int32_t g_glob,
         } else
             pick_pair(ri[0], ri[1], (uint32_t)gv->pool_n, &a, &b);
         a += gv->pool_lo; b += gv->pool_lo;
+        if (rpi) {
+            if (rpi[0] >= 0) a = (uint32_t)rpi[0];
+            if (rpi[1] >= 0) b = (uint32_t)rpi[1];
+        }
         P1 = gv->rows + (int64_t)a * D; P2 = gv->rows + (int64_t)b * D;
         idx[1] = (int32_t)a; idx[2] = (int32_t)b;
     }
@@ -945,22 +1009,27 @@ static void propose(orc_handle* h, int64_t iter, uint32_t sweep, int32_t g_glob,
         g1 = 2.38; /* crossover.jl:191 */
     else
         g1 = 2.38 / sqrt(2.0 * (double)D); /* crossover.jl:218 */
+    /* ((Pt + g1*(Pm-Pn)) + g2*(Pb-Pt)) + b  crossover.jl:168, operand order per utilities.jl:319-325 -- through the
+     * KAT-checked particle algebra (x*a + y*b: x*1.0 and y*-1.0 are exact, so these are the same roundings as
+     * t1 = Pm-Pn; t2 = t1*g1; t3 = Pt+t2; t4 = Pb-Pt; t5 = t4*g2; t6 = t3+t5) */
+    {
+        double* dif = (double*)malloc(sizeof(double) * (size_t)D);
+        orc_axpby(Pm, Pn, 1.0, -1.0, D, dif);
+        orc_axpby(pt, dif, 1.0, g1, D, prop);
+        if (use_base) { /* after burn-in gamma_2 = 0: the term is skipped rather than multiplied by zero */
+            orc_axpby(Pb, pt, 1.0, -1.0, D, dif);
+            orc_axpby(prop, dif, 1.0, g2, D, prop);
+        }
+        free(dif);
+    }
     for (int k = 0; 2 * k < D; ++k) {
         draw_block(seed, S_NOISE, sweep, (uint64_t)iter, slot, (uint32_t)k, r);
         const double uu[2] = {orc_u53(r[0], r[1]), orc_u53(r[2], r[3])};
         for (int q = 0; q < 2 && 2 * k + q < D; ++q) {
             const int j = 2 * k + q;
-            /* ((Pt + g1*(Pm-Pn)) + g2*(Pb-Pt)) + b  crossover.jl:168, operand order per utilities.jl:319-325 */
-            const double t1 = Pm[j] - Pn[j];
-            const double t2 = t1 * g1;
-            double t6 = pt[j] + t2;
-            if (use_base) {
-                const double t4 = Pb[j] - pt[j];
-                const double t5 = t4 * g2;
-                t6 = t6 + t5;
-            }
-            const double bj = -eps + (eps - (-eps)) * uu[q];
-            prop[j] = t6 + bj;
+            const double u = replayed(h->rp_noise, (size_t)lslot * D + j, uu[q]);
+            const double bj = -eps + (eps - (-eps)) * u; /* rand(Uniform(-eps, eps)) crossover.jl:166 */
+            prop[j] = prop[j] + bj;
         }
     }
     if (h->c.kappa != 1.0) /* recombination! crossover.jl:301-312 */
@@ -968,18 +1037,18 @@ static void propose(orc_handle* h, int64_t iter, uint32_t sweep, int32_t g_glob,
             draw_block(seed, S_RECOMB, sweep, (uint64_t)iter, slot, (uint32_t)k, r);
             const double uu[2] = {orc_u53(r[0], r[1]), orc_u53(r[2], r[3])};
             for (int q = 0; q < 2 && 2 * k + q < D; ++q)
-                if (uu[q] <= 1.0 - h->c.kappa) prop[2 * k + q] = pt[2 * k + q];
+                if (replayed(h->rp_recomb, (size_t)lslot * D + 2 * k + q, uu[q]) <= 1.0 - h->c.kappa) prop[2 * k + q] = pt[2 * k + q];
         }
     if (mask) orc_reset(prop, pt, mask, D); /* crossover.jl:93 */
 }
 
 /* accept / mh_update! / maximize! / minimize!  utilities.jl:55-58, :201-226 */
-static int decide(const orc_handle* h, int64_t iter, uint32_t sweep, uint32_t slot, double w_prop, double w_cur, double adj) {
+static int decide(const orc_handle* h, int64_t iter, uint32_t sweep, uint32_t slot, int64_t lslot, double w_prop, double w_cur, double adj) {
     if (h->c.update_kind == ORC_UPDATE_MAXIMIZE) return w_prop > w_cur;
     if (h->c.update_kind == ORC_UPDATE_MINIMIZE) return w_prop < w_cur;
     uint32_t r[4];
     draw_block(h->c.seed, S_PART, sweep, (uint64_t)iter, slot, 3, r);
-    const double u = orc_u53(r[0], r[1]);
+    const double u = replayed(h->rp_part, (size_t)lslot * 5 + 4, orc_u53(r[0], r[1]));
     /* p = min(1, exp(..)) with Julia's NaN-propagating min: NaN -> `rand() <= NaN` is false -> reject.
      * (C's fmin would drop the NaN, so spell it out.) */
     const double e = exp(w_prop - w_cur + adj);
@@ -996,7 +1065,7 @@ static void sweep_group(orc_handle* h, int64_t iter, uint32_t sweep, int32_t g, 
     const int64_t row = iter - 1;
     uint32_t r[4];
     draw_block(h->c.seed, S_GROUP, sweep, (uint64_t)iter, (uint32_t)g_glob, 0, r);
-    const int is_mut = (orc_u53(r[0], r[1]) <= h->c.beta); /* mutate_or_crossover! main.jl:199-207 */
+    const int is_mut = (replayed(h->rp_group, (size_t)g, orc_u53(r[0], r[1])) <= h->c.beta); /* mutate_or_crossover! main.jl:199-207 */
     const int sched = h->c.schedule;
     const int half = Np / 2;
     const int n_phase = (sched == ORC_SCHED_TWO_COLOUR) ? 2 : 1;
@@ -1024,7 +1093,7 @@ static void sweep_group(orc_handle* h, int64_t iter, uint32_t sweep, int32_t g, 
             /* snooker draws from the whole pool incl. Pt in the reference schedules (crossover.jl:241) */
             propose(h, iter, sweep, g_glob, p, &gv, pt, is_mut, is_mut ? NULL : mask, prop, &adj, idx);
             const double w_prop = fitness(h, prop);
-            const int acc = decide(h, iter, sweep, slot, w_prop, w_cur, adj);
+            const int acc = decide(h, iter, sweep, slot, s, w_prop, w_cur, adj);
             memcpy(h->tr_prop + s * D, prop, sizeof(double) * (size_t)D);
             h->tr_w[s] = w_prop; h->tr_adj[s] = adj; h->tr_acc[s] = (uint8_t)acc;
             memcpy(h->tr_idx + s * 4, idx, sizeof idx);
@@ -1050,6 +1119,14 @@ int orc_migration_due(const orc_config* c, int64_t iter) {
     return orc_u53(r[0], r[1]) <= alpha; /* main.jl:85 */
 }
 /* select_groups migration.jl:31-35: N = rand(2:n_groups); ordered sample without replacement (Fisher-Yates) */
+static int migration_plan_h(const orc_handle* h, int64_t iter, int32_t* sel, int32_t* n_sel) {
+    if (h->rp_n_mig > 0) { /* replayed select_groups */
+        for (int i = 0; i < h->rp_n_mig; ++i) sel[i] = h->rp_mig_groups[i];
+        *n_sel = h->rp_n_mig;
+        return ORC_OK;
+    }
+    return orc_migration_plan(&h->c, iter, sel, n_sel);
+}
 int orc_migration_plan(const orc_config* c, int64_t iter, int32_t* sel, int32_t* n_sel) {
     const int ng = c->n_groups_total > 0 ? c->n_groups_total : c->n_groups;
     if (ng < 2) { *n_sel = 0; return ORC_OK; }
@@ -1074,7 +1151,8 @@ int orc_migration_pack(orc_handle* h, int64_t iter, double* rows) {
     for (int g = 0; g < h->c.n_groups; ++g) {
         uint32_t r[4];
         draw_block(h->c.seed, S_MIG, 0, (uint64_t)iter, (uint32_t)(h->c.group_offset + g), 0, r);
-        const int32_t j = select_particle_stable(h->weight + (int64_t)g * Np, Np, orc_u53(r[0], r[1]));
+        int32_t j = select_particle_stable(h->weight + (int64_t)g * Np, Np, orc_u53(r[0], r[1]));
+        if (h->rp_mig_particle && h->rp_mig_particle[g] >= 0) j = (int32_t)h->rp_mig_particle[g]; /* replayed select_particle */
         const int64_t s = (int64_t)g * Np + j;
         double* o = rows + (int64_t)g * (D + 3);
         o[0] = (double)j;
@@ -1089,18 +1167,23 @@ int orc_migration_apply(orc_handle* h, int64_t iter, const double* all_rows) {
     const int ng = h->c.n_groups_total;
     int32_t* sel = (int32_t*)malloc(sizeof(int32_t) * (size_t)ng);
     int32_t ns = 0;
-    orc_migration_plan(&h->c, iter, sel, &ns);
+    migration_plan_h(h, iter, sel, &ns);
+    /* shift_particles! migration.jl:84-91: the candidates (theta, weight, id) of the selected groups, in sub-group
+     * order, are rotated by one (circshift(particles, 1)) with the KAT-checked helper and written back to the slot each
+     * group's own candidate came from */
+    const int W = D + 2;
+    double* cand = (double*)malloc(sizeof(double) * (size_t)(ns > 0 ? ns : 1) * W);
+    for (int i = 0; i < ns; ++i) memcpy(cand + (size_t)i * W, all_rows + (int64_t)sel[i] * (D + 3) + 1, sizeof(double) * (size_t)W);
+    orc_shift_particles(cand, ns, W);
     for (int i = 0; i < ns; ++i) {
-        const int gd = sel[i], gs = sel[(i + ns - 1) % ns]; /* circshift(particles, 1) migration.jl:86 */
-        const int gl = gd - h->c.group_offset;
-        if (gl < 0 || gl >= h->c.n_groups) continue;
-        const double* dst = all_rows + (int64_t)gd * (D + 3);
-        const double* src = all_rows + (int64_t)gs * (D + 3);
-        const int64_t s = (int64_t)gl * Np + (int64_t)dst[0];
-        memcpy(h->theta + s * D, src + 1, sizeof(double) * (size_t)D);
-        h->weight[s] = src[D + 1];
-        h->id[s] = (int64_t)src[D + 2];
+        const int gl = sel[i] - h->c.group_offset;
+        if (gl < 0 || gl >= h->c.n_groups) continue; /* another shard's group */
+        const int64_t s = (int64_t)gl * Np + (int64_t)all_rows[(int64_t)sel[i] * (D + 3)];
+        memcpy(h->theta + s * D, cand + (size_t)i * W, sizeof(double) * (size_t)D);
+        h->weight[s] = cand[(size_t)i * W + D];
+        h->id[s] = (int64_t)cand[(size_t)i * W + D + 1];
     }
+    free(cand);
     free(sel);
     return ORC_OK;
 }
@@ -1120,7 +1203,8 @@ static int step_impl(orc_handle* h, int64_t iter0, int32_t n_iters, int with_mig
     for (int64_t iter = iter0; iter < iter0 + n_iters; ++iter) {
         if (h->c.partner_kind == ORC_PARTNER_HISTORY && (iter < 2 || !h->hist))
             return fail(h, ORC_EINVAL, "history partners need n_initial > 0 and stored history");
-        if (with_migration && orc_migration_due(&h->c, iter)) { /* main.jl:85 */
+        const int due = h->rp_has_step ? (h->rp_u_step <= (h->c.n_groups_total == 1 ? 0.0 : h->c.alpha)) : orc_migration_due(&h->c, iter);
+        if (with_migration && due) { /* main.jl:85 */
             if (h->c.n_groups_total != h->c.n_groups)
                 return fail(h, ORC_EINVAL, "sharded handle: drive migration with pack/apply");
             double* rows = (double*)malloc(sizeof(double) * (size_t)h->c.n_groups * (D + 3));

@@ -49,6 +49,16 @@ class OrcConfig(C.Structure):
     ]
 
 
+class OrcReplay(C.Structure):
+    """orc_replay (demc_oracle.h)"""
+    _fields_ = [
+        ("u_step", C.POINTER(C.c_double)), ("u_group", C.POINTER(C.c_double)), ("u_part", C.POINTER(C.c_double)),
+        ("partner", C.POINTER(C.c_int64)), ("u_noise", C.POINTER(C.c_double)), ("z_noise", C.POINTER(C.c_double)),
+        ("u_recomb", C.POINTER(C.c_double)), ("mig_groups", C.POINTER(C.c_int32)), ("n_mig_groups", C.c_int32),
+        ("reserved", C.c_int32), ("mig_particle", C.POINTER(C.c_int64)),
+    ]
+
+
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
 _lp = C.POINTER(C.c_int64)
@@ -83,6 +93,7 @@ def lib():
         L.orc_loglike.argtypes = [C.c_void_p, _dp, C.c_int64, _dp]
         L.orc_prior.argtypes = [C.c_void_p, _dp, C.c_int64, _dp]
         L.orc_get_trace.argtypes = [C.c_void_p, _dp, _dp, _dp, _ip, _bp]
+        L.orc_set_replay.argtypes = [C.c_void_p, C.POINTER(OrcReplay)]
         L.orc_migration_due.argtypes = [C.POINTER(OrcConfig), C.c_int64]
         L.orc_migration_pack.argtypes = [C.c_void_p, C.c_int64, _dp]
         L.orc_migration_apply.argtypes = [C.c_void_p, C.c_int64, _dp]
@@ -238,6 +249,36 @@ class Oracle:
         self._ck(self.L.orc_get_trace(self.h, _d(prop), _d(w), _d(adj), idx.ctypes.data_as(_ip),
                                       acc.ctypes.data_as(_bp)))
         return dict(proposal=prop, w_prop=w, log_adj=adj, idx=idx, accepted=acc)
+
+    def set_replay(self, **draws):
+        """caller-supplied draws; same keywords as HipEngine.set_replay; no arguments -> back to Philox"""
+        if not draws:
+            self._ck(self.L.orc_set_replay(self.h, None))
+            return
+        r = OrcReplay()
+        P, D, G = self.P, self.D, self.cfg.n_groups
+
+        def ptr(x, dtype, shape, ct):
+            if x is None:
+                return None, None
+            a = np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=dtype), shape))
+            return a, a.ctypes.data_as(C.POINTER(ct))
+
+        keep = []
+        for name, dtype, shape, ct in (("u_step", np.float64, (1,), C.c_double), ("u_group", np.float64, (G,), C.c_double),
+                                       ("u_part", np.float64, (P, 5), C.c_double), ("partner", np.int64, (P, 3), C.c_int64),
+                                       ("u_noise", np.float64, (P, D), C.c_double), ("z_noise", np.float64, (P, D), C.c_double),
+                                       ("u_recomb", np.float64, (P, D), C.c_double),
+                                       ("mig_particle", np.int64, (G,), C.c_int64)):
+            a, q = ptr(draws.get(name), dtype, shape, ct)
+            keep.append(a)
+            setattr(r, name, q)
+        mg = draws.get("mig_groups")
+        if mg is not None:
+            mg = np.ascontiguousarray(mg, dtype=np.int32)
+            r.mig_groups = mg.ctypes.data_as(C.POINTER(C.c_int32))
+            r.n_mig_groups = int(mg.size)
+        self._ck(self.L.orc_set_replay(self.h, C.byref(r)))
 
     def migration_due(self, it):
         return bool(self.L.orc_migration_due(C.byref(self.cfg), it))

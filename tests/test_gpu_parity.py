@@ -74,6 +74,9 @@ def teacher_forced(demc, orc, prob, n_iter, n_initial=0, masks=None, check_hist=
             first = (np.arange(P) % Np) < Np // 2
             if not (kind[first] == 0).all():
                 exact &= first
+        if cfg["schedule"] == 0 and not (kind == 0).all():
+            # sequential: particle k reads rows that 0..k-1 may have accepted from a snooker / mutation proposal
+            exact[:] = False
         assert np.array_equal(tg["proposal"][exact], to["proposal"][exact]), f"iter {it}: DE proposals not bit-exact"
         np.testing.assert_allclose(tg["proposal"], to["proposal"], rtol=1e-11, atol=1e-13)
         np.testing.assert_allclose(tg["log_adj"], to["log_adj"], rtol=1e-9, atol=1e-9)
@@ -125,14 +128,14 @@ def test_logpost_matches_oracle(demc, orc, family):
 
 
 @pytest.mark.parametrize("family", FAMILIES)
-@pytest.mark.parametrize("schedule", [1, 2])
+@pytest.mark.parametrize("schedule", [0, 1, 2])
 def test_step_parity_default_sampler(demc, orc, family, schedule):
     """defaults of DE(): random_gamma, alpha = beta = 0.1, kappa = 1, no snooker; burn-in covers the base term"""
     prob = make_problem(family, np.random.default_rng(11))
     teacher_forced(demc, orc, prob, n_iter=12, n_groups=4, Np=8, schedule=schedule, burnin=6)
 
 
-@pytest.mark.parametrize("schedule", [1, 2])
+@pytest.mark.parametrize("schedule", [0, 1, 2])
 @pytest.mark.parametrize("proposal_kind", [0, 1, 2])
 def test_step_parity_snooker_recombination(demc, orc, schedule, proposal_kind):
     prob = make_problem("mvn_iso", np.random.default_rng(12), d=6)
@@ -164,10 +167,26 @@ def test_step_parity_history_partners(demc, orc, schedule):
                    theta_snooker=0.3, partner_kind=1, alpha=0.0, exact_de=False)
 
 
-def test_migration_parity(demc, orc):
+@pytest.mark.parametrize("schedule", [0, 2])
+def test_migration_parity(demc, orc, schedule):
     """alpha = 1: every iteration migrates; ids travel with the particles (migration.jl:84-91)"""
     prob = make_problem("gaussian", np.random.default_rng(15))
-    teacher_forced(demc, orc, prob, n_iter=15, n_groups=6, Np=6, schedule=2, burnin=5, alpha=1.0)
+    teacher_forced(demc, orc, prob, n_iter=15, n_groups=6, Np=6, schedule=schedule, burnin=5, alpha=1.0)
+
+
+def test_reference_schedule_blocks_and_suffstat(demc, orc):
+    """the reference's own schedule (sequential in-place sweep, crossover.jl:13-15) on the device: with block updates
+    (one sweep per block, main.jl:174-179) and in SUFFSTAT mode (the whole update in the fused K1 tail, one particle of
+    every group per launch)"""
+    prob = make_problem("hier_gaussian", np.random.default_rng(13), S=6, n=5)
+    D = prob["D"]
+    m0 = np.zeros(D, np.uint8)
+    m0[[0, 1, D - 1]] = 1
+    teacher_forced(demc, orc, prob, n_iter=6, n_groups=3, Np=8, schedule=0, burnin=3, theta_snooker=0.2,
+                   masks=np.stack([m0, 1 - m0]), exact_de=False)
+    prob = make_problem("mvn_full", np.random.default_rng(21), N=300, d=7)
+    teacher_forced(demc, orc, prob, n_iter=8, n_groups=4, Np=12, schedule=0, burnin=4, theta_snooker=0.2,
+                   loglike_mode=1, alpha=0.5)
 
 
 def test_optimize_modes(demc, orc):
@@ -308,7 +327,7 @@ def test_resident_form_with_block_updates(demc):
 
 def test_rejects_unsupported(demc):
     with pytest.raises(demc.DemcError):
-        demc.HipEngine(n_groups=2, Np=8, D=2, schedule=0)  # sequential sweep is CPU-oracle only
+        demc.HipEngine(n_groups=2, Np=8, D=2, schedule=3)  # unknown schedule
     with pytest.raises(demc.DemcError):
         demc.HipEngine(n_groups=2, Np=2, D=2, schedule=1)  # Np >= 3
     eng = demc.HipEngine(n_groups=2, Np=8, D=2, schedule=1)
