@@ -1,137 +1,318 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MI355X DE-MCMC hot path.
+"""bench.py -- benchmark of the MI355X DE-MCMC hot path.
 
 Metric (BASELINE.json): particle-updates/sec (proposal + loglike + accept) at D=32, N=1e5.
-Workload at N=1 (BASELINE.json configs[2], "cfg3"): Multivariate Gaussian D=32 full-Sigma, n_groups=256, Np=256,
-N=1e5 observations, sampler defaults (alpha=beta=0.1, eps=1e-3, sigma=0.05, kappa=1, no snooker, burnin=1000),
-two_colour schedule, STREAMING likelihood (every proposal visits every observation, as the reference's loglike does).
-One "step" = one DE-MCMC iteration over all P = n_groups*Np particles (migration when the alpha coin fires,
-proposal, prior+loglike, Metropolis accept, history store).  N>1: weak scaling, every rank owns 256 groups.
+Default workload (BASELINE.json configs[2], "cfg3", the configuration the metric is quoted on): Multivariate Gaussian D=32
+full-Sigma, n_groups=256, Np=256, N=1e5 observations, sampler defaults (alpha=beta=0.1, eps=1e-3, sigma=0.05, kappa=1, no
+snooker, burnin=1000), two_colour schedule, STREAMING likelihood (every proposal visits every observation, as the
+reference's loglike does).  One "step" = one DE-MCMC iteration over all P = n_groups*Np particles (migration when the alpha
+coin fires, proposal, prior+loglike, Metropolis accept, history store).
+
+--config cfg2 | cfg4 | cfg5 run the other BASELINE configs (their own roofline definition, same JSON contract); they are
+measured rows of SURVEY 8(d), not the headline.
+
+--gpus N: weak scaling, every rank owns the config's groups (256 for cfg3); groups are sharded, the only collective is
+one all-gather per migration.  Started by a launcher (RANK / WORLD_SIZE in the environment, e.g. torch.distributed.run)
+the process is one rank; started bare with N > 1 it spawns its N ranks itself -- as fresh child processes, before this
+process has touched the GPU.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X datasheet FP64 matrix (= vector) peak; BASELINE.md section 5
-PEAK_HBM_GBS = 8000.0          # MI355X HBM3E nominal; /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_FP64_TFLOPS = 78.6   # MI355X FP64 matrix = vector peak: 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (datasheet)
+PEAK_HBM_GBS = 8000.0     # MI355X HBM3E nominal; /opt/skills/guides/MI355X_MICROARCH.md
+PROFILE_ROUND = "r02"     # profiles/<round>/ holds the rocprofv3 PMC passes `traffic` is read from
 
 
-def measured_traffic(kernel, a):
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
+    ap.add_argument("--mode", default="streaming", choices=["streaming", "suffstat"])
+    ap.add_argument("--schedule", default="two_colour", choices=["two_colour", "synchronous"])
+    ap.add_argument("--n-groups", type=int, default=None, help="groups per GPU (default: the config's)")
+    ap.add_argument("--np", type=int, default=None, dest="Np")
+    ap.add_argument("--nobs", type=int, default=None, help="observations / subjects / trials (default: the config's)")
+    ap.add_argument("--dim", type=int, default=None, help="data dimension of cfg2 / cfg3")
+    ap.add_argument("--burnin", type=int, default=1000, help="DE burnin (reference default 1000)")
+    ap.add_argument("--fuse", type=int, default=0, help="demc_config.fuse (0 auto, 1 never, 2 per phase)")
+    ap.add_argument("--accuracy-iters", type=int, default=1500, help="length of the untimed accuracy leg (0: skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children (one process per GPU), before this
+    process has imported torch or made any HIP call; rank 0's stdout (the JSON line) is passed through."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    raise SystemExit(rc)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# workloads and their rooflines
+# ----------------------------------------------------------------------------------------------------------------
+def build_workload(a):
+    from demc_amd import workloads as W
+    kw = {}
+    if a.n_groups is not None:
+        kw["G"] = a.n_groups
+    if a.Np is not None:
+        kw["Np"] = a.Np
+    if a.config in ("cfg2", "cfg3"):
+        if a.nobs is not None:
+            kw["N"] = a.nobs
+        if a.dim is not None:
+            kw["d"] = a.dim
+    elif a.config == "cfg4":
+        if a.nobs is not None:
+            kw["S"] = a.nobs
+    elif a.nobs is not None:
+        kw["N"] = a.nobs
+    return W.BUILDERS[a.config](**kw)
+
+
+def describe(a, w, world):
+    G, Np, D = w["G"], w["Np"], w["D"]
+    if a.config in ("cfg2", "cfg3"):
+        return (f"{a.config}: MvNormal full-Sigma D={D}, N={w['dims'][0]} obs, n_groups={G}x{world}, Np={Np}, sampler defaults, "
+                f"schedule={a.schedule}, loglike={a.mode}")
+    if a.config == "cfg4":
+        return (f"cfg4: hierarchical Binomial (Hierarchical_Example.jl shape), S={w['dims'][0]} subjects, D={D}, blocks [hyper; subject], "
+                f"n_groups={G}x{world} (BASELINE: 128 groups over 8 GPUs), Np={Np}, schedule={a.schedule}")
+    return (f"cfg5: LBA 3 accumulators (Run_LBA.jl), D={D}, N={w['dims'][0]} trials simulated from nu=(3,2,1) A=.8 k=.2 tau=.3, "
+            f"n_groups={G}x{world} (BASELINE: 512 groups over 8 GPUs), Np={Np}, snooker 0.1, schedule={a.schedule}")
+
+
+def measured_traffic(a, w, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01/*_pmc.json: FETCH_SIZE and WRITE_SIZE in KB, separate --pmc passes).  On gfx950 FETCH_SIZE counts
-    half the bytes of wide streaming reads (MI355X_MICROARCH.md, HBM section), hence the factor 2.  Only valid for
-    the default workload; otherwise None."""
-    if (a.n_groups, a.Np, a.nobs, a.dim, a.schedule) != (256, 256, 100000, 32, "two_colour"):
+    (profiles/<round>/bench_<config>_<mode>_pmc.json: FETCH_SIZE and WRITE_SIZE in KB, separate --pmc passes).  On gfx950
+    FETCH_SIZE counts half the bytes of wide streaming reads (MI355X_MICROARCH.md, HBM section), hence the factor 2.
+    Only for the config's default shape; otherwise None.  NOT measured in the run that prints it."""
+    from demc_amd import workloads as W
+    ref = W.BUILDERS[a.config].__defaults__
+    if a.n_groups is not None or a.Np is not None or a.nobs is not None or a.dim is not None or a.schedule != "two_colour":
+        return None, None
+    for rnd in (PROFILE_ROUND, "r01"):
+        path = os.path.join(ROOT, "profiles", rnd, f"bench_{a.config}_{a.mode}_pmc.json")
+        try:
+            rec = json.load(open(path))[kernel]
+        except (OSError, KeyError, ValueError):
+            continue
+        if "bytes" in rec:  # already reduced by tools/collect_profiles.py (e.g. per iteration for a resident kernel)
+            return float(rec["bytes"]), f"profiles/{rnd}/" + os.path.basename(path)
+        return (2.0 * rec["FETCH_SIZE_KB_mean"] + rec["WRITE_SIZE_KB_mean"]) * 1024.0, f"profiles/{rnd}/" + os.path.basename(path)
+    return None, None
+
+
+def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
+    """`roofline` object for the dominant kernel.  tm = per-class device time from HIP events recorded on the TIMED
+    iterations (on the stream the kernels run on); k_iters = the timed iterations; dt_per_iter = wall seconds per step."""
+    D = w["D"]
+    phases = 2 if a.schedule == "two_colour" else 1
+    sweeps = 1 if w["masks"] is None else len(w["masks"])
+    per_kernel = {n: v["ms"] / k_iters for n, v in tm.items()}
+    launches = {n: v["launches"] for n, v in tm.items()}
+    fused_ms = tm["propose"]["ms"] + tm["loglike_prep"]["ms"] + tm["accept_store"]["ms"]
+    if a.config in ("cfg2", "cfg3"):
+        N, d = w["dims"]
+        if a.mode == "streaming":
+            streamed_in_k1 = tm["loglike"]["launches"] == 0  # the observation stream ran inside the resident proposal kernel
+            t_s = (fused_ms if streamed_in_k1 else tm["loglike"]["ms"]) * 1e-3
+            n_launch = max(1, tm["propose"]["launches"] if streamed_in_k1 else tm["loglike"]["launches"])
+            executed = 2.0 * N * d * P * k_iters          # expanded quadratic form: 2ND flop per particle-update
+            survey = (3.0 * N * d + 2.0 * d * d) * P * k_iters  # SURVEY 8d's whitened-form count, for comparison only
+            ach = executed / t_s / 1e12
+            kern = ("k_propose<...,RES> with the observation stream inside (v_mfma_f64_16x16x4_f64)" if streamed_in_k1
+                    else f"k_cross_mfma<{max(1, 1 << max(0, (max(1, (d + 3) // 4) - 1).bit_length())) if d <= 64 else 16},4> (v_mfma_f64_16x16x4_f64)")
+            traffic, src = measured_traffic(a, w, "streaming_kernel")
+            alg_bytes = 8.0 * N * d + P / phases * 8.0 * d  # operands of one launch: X once + the proposals' y rows
+            rf = dict(bound="mfma", kernel=kern, achieved=ach, peak=PEAK_FP64_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP64_TFLOPS,
+                      flop_counted="executed 2*N*D per particle-update (every proposal x observation pair on the matrix cores)",
+                      survey_equivalent_tflops=survey / t_s / 1e12,
+                      survey_note="SURVEY 8d counts the whitened form 3ND+2D^2; the expanded form executes 2/3 of it for the same result",
+                      launch_ms=t_s / n_launch * 1e3, launches=n_launch, updates_per_launch=P * k_iters / n_launch,
+                      traffic=traffic, traffic_source=src,
+                      wasted_traffic_ratio=None if traffic is None else traffic / alg_bytes)
+        else:
+            t_s = fused_ms * 1e-3
+            n_launch = max(1, tm["propose"]["launches"])
+            byts = (24.0 * D + 17.0) * P * k_iters
+            ach = byts / t_s / 1e9
+            traffic, src = measured_traffic(a, w, "k_propose_fused_per_iteration")
+            rf = dict(bound="hbm", kernel="k_propose with the fused prep/accept/store tail" +
+                      (", resident form (one launch per run of iterations between migrations)" if n_launch < phases * k_iters else ""),
+                      achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
+                      bytes_counted="24*D+17 per particle-update (SURVEY 8d)", launch_ms=t_s / n_launch * 1e3, launches=n_launch,
+                      updates_per_launch=P * k_iters / n_launch,
+                      traffic=None if traffic is None else traffic * k_iters / n_launch, traffic_source=src,
+                      wasted_traffic_ratio=None if traffic is None else traffic / ((24.0 * D + 17.0) * P))
+    elif a.config == "cfg4":
+        S = w["dims"][0]
+        t_s = (fused_ms + tm["loglike"]["ms"]) * 1e-3
+        n_launch = max(1, tm["propose"]["launches"])
+        byts = sweeps * (24.0 * D + 17.0 + 16.0 * S) * P * k_iters
+        ach = byts / t_s / 1e9
+        traffic, src = measured_traffic(a, w, "k_propose_per_iteration")
+        rf = dict(bound="hbm", kernel="k_propose<512,...,TAIL_OBS> (a workgroup per particle; subject terms, accept and store fused)",
+                  achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
+                  bytes_counted=f"{sweeps} block sweeps x (24*D+17 + 16*S) per particle-update and iteration (SURVEY 8d)",
+                  launch_ms=t_s / n_launch * 1e3, launches=n_launch, updates_per_launch=sweeps * P * k_iters / n_launch,
+                  traffic=None if traffic is None else traffic * k_iters / n_launch, traffic_source=src,
+                  wasted_traffic_ratio=None if traffic is None else traffic / (byts / k_iters))
+    else:  # cfg5
+        N, na = w["dims"]
+        t_s = tm["loglike"]["ms"] * 1e-3
+        n_launch = max(1, tm["loglike"]["launches"])
+        evals = float(N) * P * k_iters
+        # algorithmic FP64 flop per (trial, proposal): per accumulator 2 x (phi, Phi) pairs = 2 x [exp ~ 24 + erfcx
+        # polynomial 2*(deg+1) + 8] + density/cdf algebra 14, plus the product, floor and log ~ 30  
+        flop_per_eval = na * (2 * (24 + 2 * 13 + 8) + 14) + 30
+        ach = evals * flop_per_eval / t_s / 1e12
+        rf = dict(bound="valu", kernel="k_obs_loglike (LBA: thread per proposal, wave-uniform trial loads, erfcx table in LDS)",
+                  achieved=ach, peak=PEAK_FP64_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP64_TFLOPS,
+                  flop_counted=f"{flop_per_eval} FP64 flop per (trial, proposal) evaluation x N x proposals",
+                  trial_proposal_evaluations_per_s=evals / t_s, launch_ms=t_s / n_launch * 1e3, launches=n_launch,
+                  updates_per_launch=P * k_iters / n_launch, traffic=None, traffic_source=None, wasted_traffic_ratio=None)
+    rf["timing"] = "HIP events recorded on the timed iterations, on the stream the kernels run on"
+    rf["per_kernel_ms_per_iter"] = per_kernel
+    rf["launches_by_class"] = launches
+    rf["device_ms_per_iter"] = sum(per_kernel.values())
+    rf["ms_per_step"] = dt_per_iter * 1e3
+    return rf
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# accuracy half of the metric
+# ----------------------------------------------------------------------------------------------------------------
+def accuracy_leg(a, w, demc_amd, local, rng):
+    """posterior-mean L1 against the closed-form conjugate posterior (MvNormal configs), from an UNTIMED run that does not
+    depend on --steps: the same sampler configuration run past the reference's burn-in in SUFFSTAT mode, which makes the
+    same accept decisions as STREAMING (same proposals, log-posteriors equal to rounding) at a
+    fraction of the cost.  The ensemble of all particles is averaged over the last iterations."""
+    if a.accuracy_iters <= 0 or "posterior_mean" not in w:
         return None
-    path = os.path.join(ROOT, "profiles", "r01", f"bench_cfg3_{a.mode}_pmc.json")
-    try:
-        rec = json.load(open(path))[kernel]
-        if "bytes" in rec:  # already reduced by tools/collect_profiles.py (e.g. per iteration for the resident K1)
-            return float(rec["bytes"])
-        return (2.0 * rec["FETCH_SIZE_KB_mean"] + rec["WRITE_SIZE_KB_mean"]) * 1024.0
-    except (OSError, KeyError):
-        return None
+    from demc_amd import workloads as W
+    G, Np, D = w["G"], w["Np"], w["D"]
+    P = G * Np
+    n_it = max(a.accuracy_iters, a.burnin + 200)
+    eng = demc_amd.HipEngine(n_groups=G, Np=Np, D=D, n_rows=0, store_history=0, schedule=2 if a.schedule == "two_colour" else 1,
+                             seed=20260001, device_id=local, burnin=a.burnin, loglike_mode=1, trace=0, **w["engine"])
+    W.configure(eng, w)
+    eng.set_state(w["init"](P, rng))
+    t0 = time.perf_counter()
+    n_snap = 10
+    eng.step(1, n_it - n_snap * 10)
+    snaps = []
+    it = 1 + n_it - n_snap * 10
+    for _ in range(n_snap):
+        eng.step(it, 10)
+        it += 10
+        snaps.append(eng.get_state()[0])
+    dt = time.perf_counter() - t0
+    eng.close()
+    import numpy as np
+    th = np.concatenate(snaps)
+    m, sd = w["posterior_mean"], w["posterior_sd"]
+    return dict(posterior_mean_l1_rel=float(np.abs(th.mean(0) - m).sum() / np.abs(m).sum()),
+                max_abs_err_in_posterior_sd=float(np.max(np.abs(th.mean(0) - m) / sd)),
+                ensemble_sd_over_posterior_sd=float(np.median(th.std(0) / sd)),
+                leg=f"untimed run of {n_it} iterations (burn-in {a.burnin}) of the same sampler on this GPU, SUFFSTAT likelihood "
+                    f"(accept decisions identical to STREAMING); all {P} particles at {n_snap} snapshots 10 iterations apart",
+                seconds=dt, reference="closed-form Gaussian posterior (conjugate: prior N(0,I), known Sigma)")
 
 
-def make_cfg3(n_groups, Np, N, d, seed=20260002):
-    """Sigma = A A'/d + 0.5 I, X rows ~ N(mu*, Sigma), prior mu_j ~ N(0,1)"""
-    rng = np.random.default_rng(seed)
-    A = rng.normal(0, 1, (d, d))
-    Sigma = A @ A.T / d + 0.5 * np.eye(d)
-    mu = rng.normal(0, 1, d)
-    L = np.linalg.cholesky(Sigma)
-    X = mu + rng.normal(0, 1, (N, d)) @ L.T
-    return dict(Sigma=Sigma, X=np.ascontiguousarray(X), mu=mu)
-
-
-def init_theta(P, d, rank, seed=20260003):
-    return np.random.default_rng(seed + rank).normal(0, 1, (P, d))
-
-
-def configure(eng, prob, d):
-    from demc_amd import families as F
-    eng.set_model(F.FAM_MVN_FULL, prob["X"], [prob["X"].shape[0], d], prob["Sigma"])
-    eng.set_priors([F.PRIOR_NORMAL] * d, [0.0] * d, [1.0] * d)
-    eng.set_bounds([-np.inf] * d, [np.inf] * d)
-
-
-def cpu_baseline(prob, Np, N, d, seconds_target=20.0):
-    """C restatement of the reference algorithm and schedule (sequential in-place sweep per group, groups across
-    OpenMP threads like p_update!, src/main.jl:135-148) on a bounded sample of the same workload."""
+# ----------------------------------------------------------------------------------------------------------------
+# CPU baseline: the C restatement of the reference algorithm and schedule on the host cores
+# ----------------------------------------------------------------------------------------------------------------
+def cpu_baseline(a, w, seconds_target=14.0):
+    """oracle source built -O3 -march=native -fopenmp on this host, reference schedule (sequential in-place sweep per group,
+    one group per OpenMP thread like p_update!, src/main.jl:135-148) on a bounded sample of the same workload: timed on
+    ONE thread and on all the cores this process may use."""
+    import numpy as np
+    from demc_amd import workloads as W
     from oracle import oracle as O
-    from demc_amd import families as F
-    O.use_native_build()  # -O3 -march=native -fopenmp build of the same C source, compiled on this host
-    # threads actually used: the process's CPU share, at most 16 (a 1-GPU box's share of the host)
+    O.use_native_build()
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))
-    ng = max(2, cores)
+    Np, D = w["Np"], w["D"]
+    rng = np.random.default_rng(1234)
+
     def run(n_groups, threads, seconds):
-        o = O.Oracle(n_groups=n_groups, Np=Np, D=d, schedule=0, n_rows=0, store_history=0, seed=7, n_threads=threads)
-        o.set_model(F.FAM_MVN_FULL, prob["X"], [N, d], prob["Sigma"])
-        o.set_priors([F.PRIOR_NORMAL] * d, [0.0] * d, [1.0] * d)
-        o.set_bounds([-np.inf] * d, [np.inf] * d)
-        o.set_state(init_theta(n_groups * Np, d, 1234))
+        o = O.Oracle(n_groups=n_groups, Np=Np, D=D, schedule=0, n_rows=0, store_history=0, seed=7, n_threads=threads,
+                     burnin=a.burnin, **w["engine"])
+        W.configure(o, w)
+        o.set_state(w["init"](n_groups * Np, rng))
         t0 = time.time()
         o.step(1, 1)
         t1 = time.time() - t0
-        iters = int(max(1, min(20, seconds / max(t1, 1e-3))))
+        iters = int(max(1, min(50, seconds / max(t1, 1e-4))))
         t0 = time.time()
         o.step(2, iters)
         dt = time.time() - t0
         o.close()
         return n_groups * Np * iters / dt, iters
 
-    one_thread, _ = run(1, 1, 3.0)  # one group on one thread, ~3 s
+    one_thread, it1 = run(1, 1, 3.0)
+    ng = max(2, min(cores, 4 * w["G"]))
     value, iters = run(ng, cores, seconds_target)
-    dt = ng * Np * iters / value
-    cpu_model = "unknown"
+    cpu_model, host_cores = "unknown", os.cpu_count()
     try:
         with open("/proc/cpuinfo") as f:
             cpu_model = next(ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name"))
     except (OSError, StopIteration):
         pass
+    sweeps = 1 if w["masks"] is None else len(w["masks"])
     return dict(value=value, unit="particle-updates/s", cores=cores, kind="port", value_single_thread=one_thread,
-                cpu_model=cpu_model,
-                sample=f"cfg3 shape (D={d}, N={N}, Np={Np}) on {ng} of the groups, {iters} iterations, reference "
-                       f"schedule (sequential in-group sweep, one group per OpenMP thread), whitened O(N*D) "
-                       f"likelihood per proposal; gcc -O3 -march=native -fopenmp")
+                cpu_model=cpu_model, host_logical_cpus=host_cores,
+                sample=f"{w['name']} shape (D={D}, data {list(w['dims'])}, Np={Np}, {sweeps} sweep(s) per iteration) on {ng} groups, "
+                       f"{iters} iterations on {cores} threads (= every core this process may use) and 1 group x {it1} iterations "
+                       f"on one thread; reference schedule (sequential in-group sweep, one group per OpenMP thread), every "
+                       f"proposal visits every observation; gcc -O3 -march=native -fopenmp")
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--mode", default="streaming", choices=["streaming", "suffstat"])
-    ap.add_argument("--schedule", default="two_colour", choices=["two_colour", "synchronous"])
-    ap.add_argument("--n-groups", type=int, default=256)
-    ap.add_argument("--np", type=int, default=256, dest="Np")
-    ap.add_argument("--nobs", type=int, default=100000)
-    ap.add_argument("--dim", type=int, default=32)
-    ap.add_argument("--burnin", type=int, default=1000, help="DE burnin (reference default 1000)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    a = ap.parse_args()
-
-    import torch
-    import demc_amd
-    from demc_amd.distributed import ShardedDriver
-
+    a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)  # does not return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+
+    import numpy as np
+    import torch
+    import demc_amd
+    from demc_amd import workloads as W
+    from demc_amd.distributed import ShardedDriver
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible and there is no CPU fallback")
     torch.cuda.set_device(local)
@@ -143,17 +324,17 @@ def main():
         dist_.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         dist = dist_
 
-    d, N, G, Np = a.dim, a.nobs, a.n_groups, a.Np
+    w = build_workload(a)
+    G, Np, D = w["G"], w["Np"], w["D"]
     P = G * Np
     n_rows = a.warmup + a.steps
-    prob = make_cfg3(G, Np, N, d)
-    eng = demc_amd.HipEngine(n_groups=G, Np=Np, D=d, n_rows=n_rows, schedule=2 if a.schedule == "two_colour" else 1,
+    eng = demc_amd.HipEngine(n_groups=G, Np=Np, D=D, n_rows=n_rows, schedule=2 if a.schedule == "two_colour" else 1,
                              group_offset=rank * G, n_groups_total=G * world, seed=20260001, device_id=local, burnin=a.burnin,
-                             loglike_mode=0 if a.mode == "streaming" else 1, trace=0)
+                             loglike_mode=0 if a.mode == "streaming" else 1, trace=0, fuse=a.fuse, **w["engine"])
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    configure(eng, prob, d)
-    eng.set_state(init_theta(P, d, rank))
-    drv = ShardedDriver(eng, dist, torch.device("cuda", local))
+    W.configure(eng, w)
+    eng.set_state(w["init"](P, np.random.default_rng(20260003 + rank)))
+    drv = ShardedDriver(eng, dist, torch.device("cuda", local), stream_ordered=True)
 
     def sync():
         if dist:
@@ -162,90 +343,63 @@ def main():
 
     drv.step(1, a.warmup)
     sync()
+    if not a.no_roofline:
+        eng.timing_enable(True)  # HIP events on the handle's stream around every launch of the timed iterations
     t0 = time.perf_counter()
     drv.step(1 + a.warmup, a.steps)
     sync()
     dt = time.perf_counter() - t0
+    tm = None
+    if not a.no_roofline:
+        tm = eng.timing_read()
+        eng.timing_enable(False)
     if dist:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    value = P * world * a.steps / dt
+    sweeps = 1 if w["masks"] is None else len(w["masks"])  # block_update!: every block sweep updates every particle once
+    value = P * world * sweeps * a.steps / dt
 
-    # accuracy half of the metric ("posterior-mean L1 vs ref"): mu | X is Gaussian in closed form for this model
-    # (prior mu ~ N(0, I), known Sigma): precision N Sigma^-1 + I, mean (N Sigma^-1 + I)^-1 N Sigma^-1 xbar.
-    acc_stats = None
+    out = None
     if rank == 0:
         k_last = min(10, a.steps)
         th_h, acc_h, _, _ = eng.get_history(n_rows - k_last, n_rows)
-        Ainv = np.linalg.inv(prob["Sigma"])
-        post_mean = np.linalg.solve(N * Ainv + np.eye(d), N * Ainv @ prob["X"].mean(0))
-        post_sd = np.sqrt(np.diag(np.linalg.inv(N * Ainv + np.eye(d))))
-        chain_mean = th_h.reshape(-1, d).mean(0)
-        acc_stats = dict(posterior_mean_l1_rel=float(np.abs(chain_mean - post_mean).sum() / np.abs(post_mean).sum()),
-                         max_abs_err_in_posterior_sd=float(np.max(np.abs(chain_mean - post_mean) / post_sd)),
-                         # the timed iterations lie inside the reference's burn-in (burnin = 1000: the gamma_2 pull towards
-                         # high-weight particles is active, crossover.jl:164), so the ensemble is still contracting
-                         ensemble_sd_over_posterior_sd_in_burnin=float(np.median(th_h.reshape(-1, d).std(0) / post_sd)),
-                         accept_rate=float(acc_h.mean()), rows_used=k_last,
-                         reference="closed-form Gaussian posterior of cfg3 (conjugate)")
-
+        th_now, w_now, ids = eng.get_state()
+        timed_chain = dict(accept_rate=float(acc_h.mean()), rows_used=k_last, finite_weights=bool(np.isfinite(w_now).all()),
+                           note="the timed iterations lie inside the reference's burn-in (burnin = 1000); acceptance and spread "
+                                "say what the sampler did, they are not a throughput claim (ESS/s is not particle-updates/s)")
+        if "posterior_sd" in w:
+            timed_chain["ensemble_sd_over_posterior_sd"] = float(np.median(th_h.reshape(-1, D).std(0) / w["posterior_sd"]))
+        if "truth" in w and "posterior_mean" not in w:
+            timed_chain["ensemble_mean"] = th_now.mean(0).tolist()
+            timed_chain["generating_parameters"] = np.asarray(w["truth"]).tolist()
     roofline = None
-    if not a.no_roofline:
-        # dominant kernel, timed live with HIP events on the stream the kernels run on (same process, extra iterations
-        # overwrite the last history rows)
-        k = min(20, a.steps)
-        eng.timing_enable(True)
-        eng.update(n_rows - k + 1, k)
-        tm = eng.timing_read()
-        eng.timing_enable(False)
-        phases = 2 if a.schedule == "two_colour" else 1
-        units = P / phases  # particle-updates per launch of the likelihood kernel
-        if a.mode == "streaming":
-            t_launch = tm["loglike"]["ms"] / max(1, tm["loglike"]["launches"]) * 1e-3
-            flops = (3.0 * N * d + 2.0 * d * d) * units  # algorithmic flops per particle-update
-            ach = flops / t_launch / 1e12
-            roofline = dict(bound="mfma", kernel="k_cross_mfma<8,4> (v_mfma_f64_16x16x4_f64)", achieved=ach,
-                            peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP64_MFMA_TFLOPS,
-                            traffic=measured_traffic("demc::k_cross_mfma<8, 4>", a),
-                            launch_ms=t_launch * 1e3, executed_tflops=2.0 * N * d * units / t_launch / 1e12)
-        else:
-            # fused K1 does the whole update.  Resident form: ONE launch runs all k iterations (both colour phases each), so
-            # the rate is taken over the iterations, not per launch; launch_ms and updates_per_launch say what one launch was.
-            t_total = (tm["propose"]["ms"] + tm["loglike_prep"]["ms"] + tm["accept_store"]["ms"]) * 1e-3
-            launches = max(1, tm["propose"]["launches"])
-            byts = (24.0 * d + 17.0) * P * k  # algorithmic bytes per particle-update x updates in the k iterations
-            ach = byts / t_total / 1e9
-            resident = launches < phases * k
-            tr = measured_traffic("k_propose_fused_per_iteration", a)
-            roofline = dict(bound="hbm",
-                            kernel="k_propose, fused prep/accept/store tail, " +
-                                   ("resident form (one launch per run of iterations between migrations)" if resident
-                                    else "one launch per colour phase"),
-                            achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
-                            traffic=None if tr is None else tr * k / launches, launch_ms=t_total / launches * 1e3,
-                            updates_per_launch=P * k / launches)
-        roofline["per_kernel_ms_per_iter"] = {n: v["ms"] / k for n, v in tm.items()}
-
-    cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(prob, Np, N, d)
-
+    if tm is not None:
+        roofline = roofline_of(a, w, tm, a.steps, P, dt / a.steps)
     eng.close()
+
     if rank == 0:
+        acc = accuracy_leg(a, w, demc_amd, local, np.random.default_rng(20260003))
+        accuracy = dict(timed_chain=timed_chain)
+        if acc is not None:
+            accuracy.update(acc)
+        cpu = None
+        if world == 1 and not a.no_cpu_baseline:
+            cpu = cpu_baseline(a, w)
         out = {
-            "metric": "particle-updates/sec (proposal+loglike+accept) at D=32, N=1e5",
+            "metric": "particle-updates/sec (proposal+loglike+accept) at D=32, N=1e5" if a.config == "cfg3" else
+                      f"particle-updates/sec (proposal+loglike+accept), {a.config}",
             "value": value, "unit": "particle-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"cfg3: MvNormal full-Sigma D={d}, N={N} obs, n_groups={G}x{world}, Np={Np}, "
-                                   f"sampler defaults, schedule={a.schedule}, loglike={a.mode}",
-                       "particles_per_gpu": P, "parallelism": f"groups sharded x{world}, migration all-gather"},
-            "particle_parameter_updates_per_s": value * d,
-            "accuracy": acc_stats, "roofline": roofline, "cpu_baseline": cpu,
+            "config": {"workload": describe(a, w, world), "particles_per_gpu": P, "block_sweeps_per_step": sweeps,
+                       "parallelism": f"groups sharded x{world}, one all-gather per migration"},
+            "particle_parameter_updates_per_s": value * D,
+            "accuracy": accuracy, "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

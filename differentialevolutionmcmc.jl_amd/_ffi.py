@@ -18,7 +18,7 @@ EXPORTS = [
     "demc_version", "demc_create", "demc_destroy", "demc_last_error", "demc_set_stream", "demc_set_model",
     "demc_set_model_source", "demc_set_priors", "demc_set_bounds", "demc_set_blocks", "demc_set_state", "demc_get_state",
     "demc_set_history_rows", "demc_get_history", "demc_export_chains", "demc_step", "demc_update", "demc_migration_due",
-    "demc_migration_pack", "demc_migration_apply", "demc_apply_migration", "demc_get_weights", "demc_logpost",
+    "demc_migration_pack", "demc_migration_apply", "demc_migration_pack_async", "demc_migration_apply_async", "demc_apply_migration", "demc_get_weights", "demc_logpost",
     "demc_get_trace", "demc_set_replay", "demc_timing_enable", "demc_timing_read",
 ]
 
@@ -136,6 +136,8 @@ def load():
     L.demc_migration_due.argtypes = [C.POINTER(DemcConfig), C.c_int64]
     L.demc_migration_pack.argtypes = [H, C.c_int64, C.c_void_p]
     L.demc_migration_apply.argtypes = [H, C.c_int64, C.c_void_p]
+    L.demc_migration_pack_async.argtypes = [H, C.c_int64, C.c_void_p]
+    L.demc_migration_apply_async.argtypes = [H, C.c_int64, C.c_void_p]
     L.demc_logpost.argtypes = [H, _dp, C.c_int64, _dp]
     L.demc_get_trace.argtypes = [H, _dp, _dp, _dp, _ip, _bp]
     L.demc_set_replay.argtypes = [H, C.POINTER(DemcReplay)]
@@ -324,6 +326,13 @@ class HipEngine:
     def migration_apply_dev(self, it, dev_ptr):
         """shift_particles! given the all-gathered rows [n_groups_total][D+3] at the device address dev_ptr."""
         self._ck(self.L.demc_migration_apply(self.h, it, C.c_void_p(dev_ptr)))
+
+    def migration_pack_enqueue(self, it, dev_ptr):
+        """as migration_pack_dev, but only enqueued on the handle's stream (no drain)"""
+        self._ck(self.L.demc_migration_pack_async(self.h, it, C.c_void_p(dev_ptr)))
+
+    def migration_apply_enqueue(self, it, dev_ptr):
+        self._ck(self.L.demc_migration_apply_async(self.h, it, C.c_void_p(dev_ptr)))
 
     def timing_enable(self, on=True):
         self._ck(self.L.demc_timing_enable(self.h, 1 if on else 0))

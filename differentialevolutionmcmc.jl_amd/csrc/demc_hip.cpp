@@ -88,6 +88,7 @@ struct demc_handle {
     // timing
     bool timing = false;
     std::vector<Timed> events;
+    std::vector<hipEvent_t> event_pool;  // recycled events: a timed launch costs two hipEventRecord, no create/destroy
     double t_ms[5] = {0, 0, 0, 0, 0};
     long long t_n[5] = {0, 0, 0, 0, 0};
 };
@@ -162,8 +163,15 @@ void tick(demc_handle* h, int cls, bool begin) {
     if (!h->timing) return;
     if (begin) {
         Timed t;
-        hipEventCreate(&t.a);
-        hipEventCreate(&t.b);
+        auto take = [&](hipEvent_t* e) {
+            if (!h->event_pool.empty()) {
+                *e = h->event_pool.back();
+                h->event_pool.pop_back();
+            } else
+                hipEventCreate(e);
+        };
+        take(&t.a);
+        take(&t.b);
         t.cls = cls;
         hipEventRecord(t.a, h->stream);
         h->events.push_back(t);
@@ -178,8 +186,8 @@ void drain_events(demc_handle* h) {
         hipEventElapsedTime(&ms, t.a, t.b);
         h->t_ms[t.cls] += ms;
         h->t_n[t.cls] += 1;
-        hipEventDestroy(t.a);
-        hipEventDestroy(t.b);
+        h->event_pool.push_back(t.a);
+        h->event_pool.push_back(t.b);
     }
     h->events.clear();
 }
@@ -735,6 +743,8 @@ int32_t demc_destroy(demc_handle* h) {
     if (!h) return DEMC_OK;
     if (h->stream) hipStreamSynchronize(h->stream);
     drain_events(h);
+    for (hipEvent_t e : h->event_pool) hipEventDestroy(e);
+    h->event_pool.clear();
     void* ptrs[] = {h->theta, h->weight, h->prop, h->prop_prior, h->prop_adj, h->tr_w, h->partial, h->aux,
                     h->dimtab, h->hist, h->lp_hist, h->mig_rows, h->scratch_theta, h->scratch_w, h->id, h->prop_oob,
                     h->tr_acc, h->masks, h->acc_hist, h->tr_idx, h->id_hist, h->data, h->Ainv, h->Ypad,
@@ -1191,6 +1201,26 @@ int32_t demc_migration_apply(demc_handle* h, int64_t iter, const double* dev_all
         return fail(h, DEMC_EINVAL, "sharded handle needs the all-gathered rows");
     migration_enqueue(h, iter, nullptr, dev_all_rows ? dev_all_rows : h->mig_rows, false, true);
     HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    return DEMC_OK;
+    });
+}
+
+int32_t demc_migration_pack_async(demc_handle* h, int64_t iter, double* dev_rows) {
+    return guarded(h, [&]() -> int32_t {
+    if (!h || !dev_rows) return DEMC_EINVAL;
+    USE_DEVICE(h);
+    migration_enqueue(h, iter, dev_rows, nullptr, true, false);
+    HIPCHK(hipGetLastError());
+    return DEMC_OK;
+    });
+}
+
+int32_t demc_migration_apply_async(demc_handle* h, int64_t iter, const double* dev_all_rows) {
+    return guarded(h, [&]() -> int32_t {
+    if (!h || !dev_all_rows) return DEMC_EINVAL;
+    USE_DEVICE(h);
+    migration_enqueue(h, iter, nullptr, dev_all_rows, false, true);
     HIPCHK(hipGetLastError());
     return DEMC_OK;
     });

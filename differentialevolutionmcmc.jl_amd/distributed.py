@@ -17,7 +17,7 @@ class ShardedDriver:
     """Drives one engine shard.  `engine` follows the engine interface (HipEngine, or the CPU oracle when a TEST
     injects it); `dist` is torch.distributed (or None for a single shard)."""
 
-    def __init__(self, engine, dist=None, device=None):
+    def __init__(self, engine, dist=None, device=None, stream_ordered=False):
         import torch
         self.torch = torch
         self.eng = engine
@@ -31,25 +31,36 @@ class ShardedDriver:
         self.rows = torch.zeros((G, D + 3), dtype=torch.float64, device=self.device)
         self.all_rows = torch.zeros((Gt, D + 3), dtype=torch.float64, device=self.device)
         self.on_device = self.device.type == "cuda"
+        # True: the engine's stream IS torch's current stream (engine.set_stream(torch.cuda.current_stream().cuda_stream))
+        self.stream_ordered = bool(stream_ordered) and self.on_device
         self.n_exchanges = 0
 
     def _exchange(self, it):
         t = self.torch
         if self.on_device:
-            self.eng.migration_pack_dev(it, self.rows.data_ptr())  # returns after the engine's stream drained
+            # Stream-ordered, no host synchronisation: the engine enqueues on the stream the collective is issued from
+            # (`stream_ordered`: the caller gave the engine torch's current stream with set_stream), so
+            # pack -> all-gather -> apply -> the next update simply queue behind each other.  torch's process group runs
+            # the collective on its own stream, fenced against the current stream by events on both sides.
+            if self.stream_ordered:
+                self.eng.migration_pack_enqueue(it, self.rows.data_ptr())
+            else:
+                self.eng.migration_pack_dev(it, self.rows.data_ptr())  # returns after the engine's own stream drained
+            if self.dist:
+                self.dist.all_gather_into_tensor(self.all_rows, self.rows)  # the one collective (RCCL over xGMI)
+            else:
+                self.all_rows.copy_(self.rows)
+            if self.stream_ordered:
+                self.eng.migration_apply_enqueue(it, self.all_rows.data_ptr())
+            else:
+                t.cuda.current_stream().synchronize()
+                self.eng.migration_apply_dev(it, self.all_rows.data_ptr())
         else:
             self.rows.copy_(t.from_numpy(self.eng.migration_pack(it)))
-        if self.dist:
-            self.dist.all_gather_into_tensor(self.all_rows, self.rows)  # the one collective (RCCL over xGMI)
-            if self.on_device:
-                t.cuda.current_stream().synchronize()
-        else:
-            self.all_rows.copy_(self.rows)
-            if self.on_device:
-                t.cuda.current_stream().synchronize()
-        if self.on_device:
-            self.eng.migration_apply_dev(it, self.all_rows.data_ptr())
-        else:
+            if self.dist:
+                self.dist.all_gather_into_tensor(self.all_rows, self.rows)
+            else:
+                self.all_rows.copy_(self.rows)
             self.eng.migration_apply(it, self.all_rows.numpy())
         self.n_exchanges += 1
 

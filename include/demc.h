@@ -199,6 +199,11 @@ int32_t demc_update(demc_handle* h, int64_t iter0, int32_t n_iters);
 int32_t demc_migration_due(const demc_config* cfg, int64_t iter);
 int32_t demc_migration_pack(demc_handle* h, int64_t iter, double* dev_rows);
 int32_t demc_migration_apply(demc_handle* h, int64_t iter, const double* dev_all_rows);
+/* The same two halves ENQUEUED ONLY (no stream drain): for a driver whose collective runs stream-ordered on the handle's
+ * stream (demc_set_stream with the stream the collective is issued from) -- pack -> all-gather -> apply -> the next
+ * demc_update then need no host synchronisation in between.  dev pointers must stay valid until the stream has passed. */
+int32_t demc_migration_pack_async(demc_handle* h, int64_t iter, double* dev_rows);
+int32_t demc_migration_apply_async(demc_handle* h, int64_t iter, const double* dev_all_rows);
 /* shift_particles! (migration.jl:84-91) with a HOST-drawn plan: for every k, slot dst_slot[k] receives the row
  * (theta, weight, id) that slot src_slot[k] held BEFORE the call -- all reads precede all writes, so a cycle is a
  * rotation.  For a caller that keeps migration!'s own random choices (select_groups / select_particles,

@@ -456,7 +456,8 @@ def test_bench_contract_on_a_small_workload(mode):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--mode", mode,
-                          "--n-groups", "16", "--np", "32", "--nobs", "4000", "--dim", "8"], capture_output=True, text=True, timeout=600)
+                          "--n-groups", "16", "--np", "32", "--nobs", "4000", "--dim", "8", "--accuracy-iters", "300", "--burnin", "100"],
+                         capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -471,4 +472,100 @@ def test_bench_contract_on_a_small_workload(mode):
     assert rf["bound"] == ("mfma" if mode == "streaming" else "hbm") and rf["unit"] == ("TFLOP/s" if mode == "streaming" else "GB/s")
     assert rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and "traffic" in rf
     cb = r["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"] and cb["value_single_thread"] > 0
+    assert rf["frac"] <= 1.0, "a roofline fraction above 1 means the numerator counts work the kernel does not execute"
+    assert rf["device_ms_per_iter"] <= rf["ms_per_step"] * 1.02, "kernel time of the timed iterations cannot exceed their wall time"
+    acc = r["accuracy"]
+    assert "timed_chain" in acc and "posterior_mean_l1_rel" in acc and "leg" in acc  # the steps-independent accuracy leg
+
+
+@pytest.mark.parametrize("config,extra", [("cfg2", ["--nobs", "2000"]), ("cfg4", ["--nobs", "600", "--n-groups", "4", "--np", "8"]),
+                                          ("cfg5", ["--nobs", "500", "--n-groups", "4", "--np", "16"])])
+def test_bench_lines_of_the_other_configs(config, extra):
+    """--config cfg2 / cfg4 / cfg5 print the same contract with their own roofline definition"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--config", config,
+                          "--accuracy-iters", "0"] + extra, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    rf = r["roofline"]
+    assert r["n_gpus"] == 1 and config in r["config"]["workload"] and r["value"] > 0
+    assert rf["bound"] == {"cfg2": "mfma", "cfg4": "hbm", "cfg5": "valu"}[config]
+    assert 0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert r["cpu_baseline"]["value"] > 0 and r["accuracy"]["timed_chain"]["finite_weights"]
+    sweeps = r["config"]["block_sweeps_per_step"]
+    assert sweeps == (2 if config == "cfg4" else 1)
+    assert abs(r["value"] - r["config"]["particles_per_gpu"] * sweeps * 6 / (r["ms_per_step"] * 6e-3)) <= 1e-6 * r["value"]
+
+
+def test_rccl_all_gather_path_at_world_size_one():
+    """the ShardedDriver with a REAL process group (backend nccl = RCCL) at world_size 1: pack -> all_gather_into_tensor ->
+    apply, enqueued stream-ordered on torch's current stream, reproduces demc_step's on-device migration bit for bit"""
+    import os
+    import torch
+    import torch.distributed as dist
+    from demc_amd.distributed import ShardedDriver
+    from conftest import make_problem, setup_engine
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        prob = make_problem("mvn_full", np.random.default_rng(31), N=200, d=6)
+        G, Np, d, n_it = 6, 16, 6, 40
+        th0 = prob["init"](G * Np)
+        outs = []
+        for sharded in (False, True):
+            eng = D.HipEngine(n_groups=G, Np=Np, D=d, n_rows=n_it, schedule=2, seed=17, alpha=0.4, burnin=10, trace=0)
+            setup_engine(eng, prob)
+            if sharded:
+                eng.set_stream(torch.cuda.current_stream().cuda_stream)
+            eng.set_state(th0)
+            if sharded:
+                drv = ShardedDriver(eng, dist, torch.device("cuda", 0), stream_ordered=True)
+                drv.step(1, n_it)
+                torch.cuda.synchronize()
+                assert drv.n_exchanges >= 5 and drv.dist is not None
+            else:
+                eng.step(1, n_it)
+            outs.append(eng.get_history(0, n_it) + eng.get_state())
+            eng.close()
+        for x, y in zip(*outs):
+            assert np.array_equal(x, y)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_geometry_groups_makes_shards_reproduce_the_unsharded_run():
+    """Lanes per particle are chosen from the population, so a shard of 128 groups would pick a different
+    split than the 256-group run it is a part of, and its log-densities would differ in their last bits (sum order).
+    demc_config.geometry_groups pins the geometry of the unsharded run: two handles of 128 groups == one of 256, bit for bit,
+    at a size that straddles a threshold (per-phase form, D = 32, Np = 128: 256 groups -> 8 lanes per particle, 128 groups
+    -> 16)."""
+    from conftest import make_problem, setup_engine
+    prob = make_problem("mvn_full", np.random.default_rng(41), N=300, d=32)
+    G, Np, d, n_it = 256, 128, 32, 6
+    th0 = prob["init"](G * Np)
+
+    def run(groups, offset, geometry_groups):
+        eng = D.HipEngine(n_groups=groups, Np=Np, D=d, n_rows=n_it, schedule=2, seed=5, alpha=0.0, burnin=3, trace=0, loglike_mode=1,
+                          fuse=2, group_offset=offset, n_groups_total=G, geometry_groups=geometry_groups)
+        setup_engine(eng, prob)
+        eng.set_state(th0[offset * Np:(offset + groups) * Np])
+        eng.update(1, n_it)
+        out = eng.get_history(0, n_it)[:3] + eng.get_state()[:2]
+        eng.close()
+        return out
+
+    whole = run(G, 0, 0)
+    halves = [run(G // 2, 0, G), run(G // 2, G // 2, G)]
+    for i, x in enumerate(whole):
+        y = np.concatenate([h[i] for h in halves], axis=1 if i < 3 else 0)
+        assert np.array_equal(x, y), f"array {i}"
+    # without the pin the accept decisions still agree, the log-densities only to rounding
+    loose = [run(G // 2, 0, 0), run(G // 2, G // 2, 0)]
+    np.testing.assert_allclose(np.concatenate([h[4] for h in loose]), whole[4], rtol=1e-11)

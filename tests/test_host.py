@@ -165,3 +165,26 @@ def test_particle_algebra_mirror():
     np.testing.assert_allclose((3 * (p1 - p2) + p3).flat(), [7, 0])
     pr = D.project(D.Particle(Θ=[[-1.0], 4.0]), D.Particle(Θ=[[2.0], 7.0]))
     np.testing.assert_allclose(pr.flat(), [52 / 53, 182 / 53])
+
+
+def test_bench_spawns_its_own_ranks_when_started_bare():
+    """`python bench.py --gpus N` without a launcher starts N rank processes itself (before touching the GPU) and fails
+    loudly if any of them fails.  Here (no GPU) both ranks stop at "needs an MI355X"; the parent returns non-zero."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is visible: the multi-rank launch is the driver's to run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert out.stderr.count("bench.py needs an MI355X") == 2, out.stderr[-1500:]
+    # a launcher that started a different number of ranks than --gpus is an error, not a silent 1-GPU run
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env2, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr

@@ -16,7 +16,7 @@ subprocess.check_call(["make", "-B", "-C", csrc, "-s", "STAMPS=1", "OUT=../libde
                       (["STAMP_PASS=" + os.environ["STAMP_PASS"]] if "STAMP_PASS" in os.environ else []))
 import demc_amd  # noqa: E402
 demc_amd._ffi.LIB_PATH = os.path.join(ROOT, "differentialevolutionmcmc.jl_amd", "libdemc_hip_stamps.so")
-import bench  # noqa: E402
+from demc_amd import workloads as W  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n-groups", type=int, default=256)
@@ -42,11 +42,11 @@ if a.config:  # one of tools/run_configs.py's BASELINE shapes (e.g. cfg4: a whol
     eng.step(1, 30)
     n_wg = c["G"] * c["Np"] // 2  # upper bound on the workgroups of a launch; unused stamp slots are filtered out below
 else:
-    prob = bench.make_cfg3(a.n_groups, a.Np, a.nobs, a.dim)
+    prob = W.cfg3(N=a.nobs, d=a.dim, G=a.n_groups, Np=a.Np)
     eng = demc_amd.HipEngine(n_groups=a.n_groups, Np=a.Np, D=a.dim, n_rows=40, schedule=2, seed=1,
                              loglike_mode=1 if a.mode == "suffstat" else 0, trace=0)
-    bench.configure(eng, prob, a.dim)
-    eng.set_state(bench.init_theta(a.n_groups * a.Np, a.dim, 0))
+    W.configure(eng, prob)
+    eng.set_state(prob["init"](a.n_groups * a.Np, np.random.default_rng(20260003)))
     eng.step(1, 30)
     n_wg = min(512, (a.n_groups * a.Np) // 16) if os.environ.get('DEMC_RESIDENT') == '0' else a.n_groups  # resident: one per group
 w_prop = eng.get_trace()["w_prop"]

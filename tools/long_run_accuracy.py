@@ -13,19 +13,19 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench  # noqa: E402
+from demc_amd import workloads as W  # noqa: E402
 import demc_amd  # noqa: E402
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "suffstat"
 G, Np, N, d, iters, keep = 256, 256, 100000, 32, 3000, 1000
 P = G * Np
-prob = bench.make_cfg3(G, Np, N, d)
+prob = W.cfg3(N=N, d=d, G=G, Np=Np)
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else iters
 kw = dict(n_groups=G, Np=Np, D=d, schedule=2, seed=20260001, burnin=1000, loglike_mode=0 if mode == "streaming" else 1, trace=0)
 # stage 1: everything before the kept window, no history; stage 2: the kept window with history
 pre = demc_amd.HipEngine(n_rows=0, store_history=0, **kw)
-bench.configure(pre, prob, d)
-pre.set_state(bench.init_theta(P, d, 0))
+W.configure(pre, prob)
+pre.set_state(prob["init"](P, np.random.default_rng(20260003)))
 t0 = time.perf_counter()
 pre.step(1, iters - keep)
 state = pre.get_state()
@@ -36,7 +36,7 @@ if eng is None:  # long runs: history rows are indexed by iteration, so the wind
     first = 1001
 else:
     first = iters - keep + 1
-bench.configure(eng, prob, d)
+W.configure(eng, prob)
 eng.set_state(*state)
 eng.step(first, keep)
 dt = time.perf_counter() - t0

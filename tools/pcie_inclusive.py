@@ -12,18 +12,18 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench  # noqa: E402
+from demc_amd import workloads as W  # noqa: E402
 import demc_amd  # noqa: E402
 
 G, Np, N, d, iters = 256, 256, 100000, 32, 250
 mode = sys.argv[1] if len(sys.argv) > 1 else "streaming"
 P = G * Np
-prob = bench.make_cfg3(G, Np, N, d)
-th0 = bench.init_theta(P, d, 0)
+prob = W.cfg3(N=N, d=d, G=G, Np=Np)
+th0 = prob["init"](P, np.random.default_rng(20260003))
 eng = demc_amd.HipEngine(n_groups=G, Np=Np, D=d, n_rows=iters, schedule=2, seed=20260001, loglike_mode=0 if mode == "streaming" else 1,
                          trace=0)
 t0 = time.perf_counter()
-bench.configure(eng, prob, d)          # X upload (25.6 MB) + fragment reorder + priors
+W.configure(eng, prob)          # X upload (25.6 MB) + fragment reorder + priors
 eng.set_state(th0)                     # theta upload (16.8 MB) + initial evaluation
 t1 = time.perf_counter()
 eng.step(1, iters)
