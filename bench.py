@@ -249,6 +249,28 @@ def accuracy_leg(a, w, demc_amd, local, rng):
 # ----------------------------------------------------------------------------------------------------------------
 # CPU baseline: the C restatement of the reference algorithm and schedule on the host cores
 # ----------------------------------------------------------------------------------------------------------------
+def usable_cores():
+    """host cores this process may actually use: the scheduler affinity, cut down to the cgroup's CPU quota (a 1-GPU box
+    shows all 256 logical CPUs of the host in its affinity mask but is given 16 CPUs' worth of time)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(a, w, seconds_target=14.0):
     """oracle source built -O3 -march=native -fopenmp on this host, reference schedule (sequential in-place sweep per group,
     one group per OpenMP thread like p_update!, src/main.jl:135-148) on a bounded sample of the same workload: timed on
@@ -257,10 +279,7 @@ def cpu_baseline(a, w, seconds_target=14.0):
     from demc_amd import workloads as W
     from oracle import oracle as O
     O.use_native_build()
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = usable_cores()
     Np, D = w["Np"], w["D"]
     rng = np.random.default_rng(1234)
 
@@ -292,7 +311,7 @@ def cpu_baseline(a, w, seconds_target=14.0):
     return dict(value=value, unit="particle-updates/s", cores=cores, kind="port", value_single_thread=one_thread,
                 cpu_model=cpu_model, host_logical_cpus=host_cores,
                 sample=f"{w['name']} shape (D={D}, data {list(w['dims'])}, Np={Np}, {sweeps} sweep(s) per iteration) on {ng} groups, "
-                       f"{iters} iterations on {cores} threads (= every core this process may use) and 1 group x {it1} iterations "
+                       f"{iters} iterations on {cores} threads (= every core this process may use: affinity cut to the cgroup CPU quota) and 1 group x {it1} iterations "
                        f"on one thread; reference schedule (sequential in-group sweep, one group per OpenMP thread), every "
                        f"proposal visits every observation; gcc -O3 -march=native -fopenmp")
 

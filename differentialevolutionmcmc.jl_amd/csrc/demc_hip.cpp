@@ -76,6 +76,13 @@ struct demc_handle {
     bool res_ok = false;  // resident K1 (plan_resident)
     int res_lpp = 0, res_wg = 0, res_scr_doubles = 0;
     size_t res_lds = 0;
+    // streaming-resident form (plan_stream): the MvNormal observation stream inside the resident kernel
+    bool st_ok = false;
+    int st_C = 0, st_nact_max = 0, st_rows = 0, st_x_lds = 0, st_chunk_tiles = 0, st_lpp = 0, st_scr_doubles = 0, st_wg = 512;
+    size_t st_lds = 0;
+    unsigned long long* st_gran = nullptr;  // hand-over granules (device)
+    unsigned* st_err = nullptr;             // time-out flag (host-mapped, zero-copy)
+    int n_cus = 0;
     std::string err;
     // replay (demc_set_replay): device copies of the caller's draws
     double *rp_group = nullptr, *rp_part = nullptr, *rp_noise = nullptr, *rp_znoise = nullptr, *rp_recomb = nullptr;
@@ -510,6 +517,93 @@ int launch_resident(demc_handle* h, long long iter0, int n_iters) {
     return DEMC_OK;
 }
 
+// ---- streaming-resident form: resident K1 with the observation stream inside (k_propose<..., STREAM>) ----
+// 256-thread form: one wave per SIMD, i.e. the whole register file (512 per lane, AGPRs included) behind each wave -- what does
+// not fit the 256 architectural VGPRs spills to AGPRs instead of scratch memory; 512 threads when a colour needs the lanes.
+K1Fn k1_stream_instance(int wg, int tail, bool plain) {
+    static const K1Fn tab[2][2][2] = {
+        {{k_propose<256, true, TAIL_PREP, true, false, true>, k_propose<256, true, TAIL_PREP_MFMA, true, false, true>},
+         {k_propose<256, true, TAIL_PREP, true, true, true>, k_propose<256, true, TAIL_PREP_MFMA, true, true, true>}},
+        {{k_propose<512, true, TAIL_PREP, true, false, true>, k_propose<512, true, TAIL_PREP_MFMA, true, false, true>},
+         {k_propose<512, true, TAIL_PREP, true, true, true>, k_propose<512, true, TAIL_PREP_MFMA, true, true, true>}}};
+    return tab[wg == 512 ? 1 : 0][plain ? 1 : 0][tail == TAIL_PREP_MFMA ? 1 : 0];
+}
+
+// Decides once per model whether the streaming-resident form applies.  It is for populations too small to fill the chip
+// with one K1 -> K2 -> K3 chain per colour phase (launch- and latency-bound): MvNormal family, STREAMING likelihood,
+// two_colour, current-population partners, at most one group per CU, the group and its per-particle scratch in LDS, and a
+// colour phase whose matrix work is in the launch-overhead range.  Large populations keep the per-phase chain, whose
+// k_cross_mfma runs at the matrix peak.
+void plan_stream(demc_handle* h) {
+    const demc_config& c = h->c;
+    h->st_ok = false;
+    if (!is_mvn(h->family) || c.loglike_mode != DEMC_LOGLIKE_STREAMING || c.fuse != 0 || c.schedule != DEMC_SCHED_TWO_COLOUR ||
+        c.partner_kind != DEMC_PARTNER_CURRENT || c.Np < 4 || h->n_cus < 1 || c.n_groups > h->n_cus || h->dpad > 64 || h->n_kpass != 1)
+        return;
+    if (const char* e = experiment("DEMC_STREAM_RES"))  // A/B experiments
+        if (e[0] == '0') return;
+    const int nact_max = c.Np - c.Np / 2;
+    if (nact_max > 512) return;
+    const double phase_flop = 2.0 * (double)nact_max * c.n_groups * (double)h->N * h->dpad;
+    if (phase_flop / 78.6e12 > 300e-6) return;
+    int lpp_max = pow2_ceil((c.D + 1) / 2);
+    if (lpp_max > 64) return;
+    int lpp = 4;
+    while (lpp * 2 <= lpp_max && nact_max * lpp * 2 <= 512) lpp *= 2;
+    if (lpp > lpp_max) lpp = lpp_max;
+    const int wg = nact_max * lpp <= 256 ? 256 : 512, ppp = wg / lpp;
+    const int rows = ((nact_max + ppp - 1) / ppp) * ppp;
+    int C = 1;
+    while (2 * C * c.n_groups <= h->n_cus && h->n_tiles / (2 * C) >= 8 && 2 * C <= 32) C *= 2;
+    const int chunk = (h->n_tiles + C - 1) / C;
+    const size_t D = (size_t)c.D, Np = (size_t)c.Np, d = (size_t)h->d;
+    const size_t scr_doubles = (size_t)rows * (D + 6);
+    const size_t doubles = Np * D + Np + (Np + (Np + 15) / 16) + (h->family == FAM_MVN_FULL ? d * d : 0) + d + scr_doubles +
+                           (size_t)rows * h->dpad + (size_t)(wg / 64) * nact_max;
+    size_t bytes = doubles * sizeof(double) + (size_t)nact_max * (4 * sizeof(double) + 4 * sizeof(int)) +
+                   2 * sizeof(unsigned) * (size_t)C * nact_max + 16;
+    if (bytes > kMaxDynLds) return;
+    const size_t xbytes = (size_t)(chunk + 1) * (h->dpad / 4) * 64 * sizeof(double);  // + the all-zero tail tile
+    const int x_lds = (bytes + xbytes <= kMaxDynLds) ? 1 : 0;
+    if (x_lds) bytes += xbytes;
+    // hand-over granules [2][n_groups][C][nact_max][2] and the time-out word
+    if (h->st_gran) { hipFree(h->st_gran); h->st_gran = nullptr; }
+    if (hipMalloc((void**)&h->st_gran, 2 * (size_t)c.n_groups * C * nact_max * 2 * sizeof(unsigned long long)) != hipSuccess) return;
+    if (!h->st_err) {
+        if (hipHostMalloc((void**)&h->st_err, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) return;
+        *h->st_err = 0u;
+    }
+    h->st_ok = true; h->st_C = C; h->st_nact_max = nact_max; h->st_rows = rows; h->st_x_lds = x_lds; h->st_chunk_tiles = chunk;
+    h->st_lpp = lpp; h->st_scr_doubles = (int)scr_doubles; h->st_lds = bytes; h->st_wg = wg;
+}
+
+int launch_stream(demc_handle* h, long long iter0, int n_iters) {
+    const demc_config& c = h->c;
+    KParams k = base_params(h);
+    k.lpp = h->st_lpp;
+    set_tail_flags(h, k);
+    k.sx = nullptr; k.fuse_accept = 1; k.write_prop = k.trace ? 1 : 0;  // STREAMING: the cross term comes from the tiles
+    k.iter = iter0; k.n_iters = n_iters; k.n_sweeps = c.n_blocks > 0 ? c.n_blocks : 1;
+    k.mask = c.n_blocks > 0 ? h->masks : nullptr;
+    k.n_rows = h->hist ? c.n_rows : 0;
+    k.n_split = 1; k.exclude_self = 0; k.own_in_pool = 1; k.tile_rows = c.Np; k.tile_in_lds = 1;
+    k.scr_doubles = h->st_scr_doubles;
+    k.plan = (k.lpp >= 4) ? 1 : 0;
+    k.st_C = h->st_C; k.st_nact_max = h->st_nact_max; k.st_rows = h->st_rows; k.st_x_lds = h->st_x_lds;
+    k.st_chunk_tiles = h->st_chunk_tiles; k.n_tiles = h->n_tiles; k.Xf = h->Xf; k.st_gran = h->st_gran; k.st_err = h->st_err;
+    // epoch tags restart at 1 in every launch: the granules of the previous launch must not match them
+    HIPCHK(hipMemsetAsync(h->st_gran, 0, 2 * (size_t)c.n_groups * h->st_C * h->st_nact_max * 2 * sizeof(unsigned long long), h->stream));
+    tick(h, 0, true);
+    void* args[] = {&k};
+    // cooperative launch: not for a grid barrier, but for its launch-time check that every workgroup of the grid is
+    // co-resident (the hand-over between the workgroups of a group spins on their progress)
+    hipError_t e = hipLaunchCooperativeKernel((const void*)k1_stream_instance(h->st_wg, tail_of(k), is_plain(h, k)),
+                                              dim3(c.n_groups * h->st_C), dim3(h->st_wg), args, (unsigned)h->st_lds, h->stream);
+    tick(h, 0, false);
+    if (e != hipSuccess) return fail(h, DEMC_EHIP, std::string("streaming-resident launch: ") + hipGetErrorString(e));
+    return DEMC_OK;
+}
+
 // one sweep of every group: mutate_or_crossover! for all groups (main.jl:161-167, 199-207)
 int run_sweep(demc_handle* h, long long iter, unsigned sweep, const unsigned char* mask, long long store_row) {
     const int Np = h->c.Np;
@@ -593,7 +687,13 @@ int size_k1_lds(demc_handle* h) {
                 HIPCHK(hipFuncSetAttribute((const void*)k1_instance(false, tail, false, 512),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
             }
+    for (int wgs = 256; wgs <= 512; wgs += 256)
+        for (int tail = 1; tail <= 2; ++tail)
+            for (int plain = 0; plain < 2; ++plain)
+                HIPCHK(hipFuncSetAttribute((const void*)k1_stream_instance(wgs, tail, plain != 0),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
     plan_resident(h);
+    plan_stream(h);
     HIPCHK(hipFuncSetAttribute((const void*)k_mig_pack, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
     return DEMC_OK;
 }
@@ -677,6 +777,7 @@ int32_t demc_create(const demc_config* cfg, demc_handle** out) {
     HIPCHK(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(h, DEMC_EHIP, "no HIP device visible");
     HIPCHK(hipSetDevice(c.device_id));
+    HIPCHK(hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, c.device_id));
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->own_stream = true;
     h->P = (long long)c.n_groups * c.Np;
@@ -754,6 +855,8 @@ int32_t demc_destroy(demc_handle* h) {
     if (h->user_module) hipModuleUnload(h->user_module);
     if (h->user_hyper) hipFree(h->user_hyper);
     free_replay(h);
+    if (h->st_gran) hipFree(h->st_gran);
+    if (h->st_err) hipHostFree(h->st_err);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
     return DEMC_OK;
@@ -1149,10 +1252,11 @@ static int32_t step_impl(demc_handle* h, int64_t iter0, int32_t n_iters, bool wi
                 return fail(h, DEMC_EINVAL, "sharded handle: drive the exchange with demc_migration_pack/apply + demc_update");
             migration_enqueue(h, iter, h->mig_rows, h->mig_rows, true, true);
         }
-        if (h->res_ok && !h->rp_active) {  // every iteration up to the next migration in one launch
+        if ((h->res_ok || h->st_ok) && !h->rp_active) {  // every iteration up to the next migration in one launch
             int run = 1;  // capped so that a single launch stays in the millisecond range whatever the caller asks for
-            while (run < 1024 && iter + run < iter0 + n_iters && !(with_migration && migration_due_h(h, iter + run))) ++run;
-            int rc = launch_resident(h, iter, run);
+            const int cap = h->st_ok ? 64 : 1024;
+            while (run < cap && iter + run < iter0 + n_iters && !(with_migration && migration_due_h(h, iter + run))) ++run;
+            int rc = h->st_ok ? launch_stream(h, iter, run) : launch_resident(h, iter, run);
             if (rc != DEMC_OK) return rc;
             iter += run - 1;
             continue;
@@ -1167,6 +1271,10 @@ static int32_t step_impl(demc_handle* h, int64_t iter0, int32_t n_iters, bool wi
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
+    if (h->st_err && *h->st_err) {
+        *h->st_err = 0u;
+        return fail(h, DEMC_EHIP, "streaming-resident kernel: a hand-over between the workgroups of a group timed out");
+    }
     return DEMC_OK;
     });
 }

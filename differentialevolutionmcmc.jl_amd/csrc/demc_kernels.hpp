@@ -114,6 +114,16 @@ struct KParams {
     const int* rp_mig_groups;       // [rp_n_mig] global groups
     const long long* rp_mig_particle;  // [n_groups]
     int rp_n_mig;
+    // streaming-resident form (STREAM instances of k_propose): the MvNormal observation stream inside the resident kernel
+    int st_C;                       // workgroups per group: each streams 1/C of the observation tiles for ALL moving particles
+    int st_nact_max;                // moving particles of the larger colour phase
+    int st_rows;                    // rows of the theta' scratch (st_nact_max rounded up to whole passes)
+    int st_x_lds;                   // this workgroup's chunk of Xf is held in LDS for the whole launch
+    int st_chunk_tiles;             // observation tiles per workgroup chunk
+    int n_tiles;                    // observation tiles of 16 in Xf
+    const double* Xf;               // [n_tiles+1][dpad/4][64] fragment-ordered data (demc_set_model)
+    unsigned long long* st_gran;    // [2][n_groups][st_C][st_nact_max][2] hand-over granules {epoch:32 | half of a double:32}
+    unsigned* st_err;               // set to 1 if a hand-over timed out (never, with co-resident workgroups)
 };
 // a replayed uniform replaces the drawn one unless it is NaN
 __device__ inline double replayed(const double* tab, size_t i, double drawn) {
@@ -411,7 +421,7 @@ __device__ inline double prior_term(const DimTab& t, double x, double inv_sref, 
 }
 
 // In-kernel stamps (diagnostic build only: make STAMPS=1; tools/k1_stamps.py reads them back through the trace).
-// Thread 0 of every workgroup (as many as fit in the P-long trace array) stores the s_memtime delta since kernel start into tr_w[16*blockIdx.x + i]; the
+// Thread 0 of every workgroup (as many as fit in the P-long trace array) stores the s_memtime delta since kernel start into tr_w[24*blockIdx.x + i]; the
 // product build compiles them away.
 #ifndef DEMC_STAMP_PASS
 #define DEMC_STAMP_PASS 1  // which pass of the workgroup the per-pass stamps sample (0 = the cold first pass)
@@ -419,8 +429,8 @@ __device__ inline double prior_term(const DimTab& t, double x, double inv_sref, 
 #ifdef DEMC_STAMPS
 #define DEMC_STAMP(i)                                                                                              \
     do {                                                                                                           \
-        if (threadIdx.x == 0 && ((long long)blockIdx.x + 1) * 16 <= p.P)                                          \
-            p.tr_w[blockIdx.x * 16 + (i)] = (double)(__builtin_amdgcn_s_memtime() - t_start__);                   \
+        if (threadIdx.x == 0 && ((long long)blockIdx.x + 1) * 24 <= p.P)                                          \
+            p.tr_w[blockIdx.x * 24 + (i)] = (double)(__builtin_amdgcn_s_memtime() - t_start__);                   \
     } while (0)
 #define DEMC_STAMP_INIT() unsigned long long t_start__ = __builtin_amdgcn_s_memtime()
 #define DEMC_STAMP_RESET() t_start__ = __builtin_amdgcn_s_memtime()  // resident form: stamps are relative to the step's start
@@ -481,6 +491,108 @@ __device__ inline void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// ---- streaming-resident form: cross term S_p = sum_i y_p . x~_i of the workgroup's observation chunk on the matrix cores.
+// One wave: MT particle tiles of 16 (A fragments from the y rows in LDS, kept in registers) x the observation tiles
+// [t_lo, t_hi) of `xsrc` (fragment order [tile][kstep][64 lanes], LDS copy or global Xf), accumulated inside the MFMA
+// accumulators; the 16 columns of each result are folded on the DPP network and lane (l & 15) == 0 of every row leaves the
+// per-particle sums in out[particle].  Same operand layout as k_cross_mfma below.
+typedef __attribute__((address_space(3))) const double* lds_cptr;
+typedef __attribute__((address_space(3))) double* lds_ptr;
+typedef __attribute__((address_space(1))) const double* glb_cptr;
+// XP = lds_cptr or glb_cptr: the address space is part of the type so that the B loads are ds_read / global_load (a generic
+// pointer makes them flat loads, which wait on both memory counters and serialise the prefetch against the MFMAs).
+// `zt` = index (relative to xsrc) of an all-zero tile that absorbs the odd tail of the two-tile ping-pong.
+template <int KS, int MT, typename XP>
+__device__ inline void cross_tiles(lds_cptr ybuf, int dpad, int n_act, int ptile0, XP xsrc, int ksx, int t_lo, int t_hi, int zt,
+                                   lds_ptr out, int lane) {
+    double a[MT][KS];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int q = (ptile0 + mt) * 16 + (lane & 15);
+        lds_cptr yrow = ybuf + (q < n_act ? q : 0) * dpad + (lane >> 4);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const double v = yrow[4 * ks];
+            a[mt][ks] = q < n_act ? v : 0.0;
+        }
+    }
+    d4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int tstride = ksx * 64;
+    XP xb = xsrc + lane;
+    double b0[KS], b1[KS];
+    {
+        XP x = xb + (t_lo < t_hi ? t_lo : zt) * tstride;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) b0[ks] = x[ks * 64];
+    }
+    // two register sets in ping-pong: the loads of tile t+1 are in flight while tile t feeds the matrix core
+    for (int t = t_lo; t < t_hi; t += 2) {
+        {
+            XP x = xb + (t + 1 < t_hi ? t + 1 : zt) * tstride;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) b1[ks] = x[ks * 64];
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt][ks], b0[ks], acc[mt], 0, 0, 0);
+        {
+            XP x = xb + (t + 2 < t_hi ? t + 2 : zt) * tstride;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) b0[ks] = x[ks * 64];
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt][ks], b1[ks], acc[mt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double v = subgroup_sum(acc[mt][r], 16);
+            const int q = (ptile0 + mt) * 16 + (lane >> 4) + 4 * r;
+            if ((lane & 15) == 0 && q < n_act) out[q] = v;
+        }
+}
+// particle tiles in groups of MT (registers: KS x MT fragments), as few accumulators as the tiles need
+template <int KS, typename XP>
+__device__ inline void cross_ks(lds_cptr ybuf, int dpad, int n_act, XP xsrc, int t_lo, int t_hi, int zt, lds_ptr out, int lane) {
+    const int n_pt = (n_act + 15) >> 4;
+    constexpr int MTMAX = KS >= 16 ? 2 : 4;
+    int p0 = 0;
+    for (; p0 + MTMAX <= n_pt; p0 += MTMAX) cross_tiles<KS, MTMAX, XP>(ybuf, dpad, n_act, p0, xsrc, KS, t_lo, t_hi, zt, out, lane);
+    const int rest = n_pt - p0;
+    if (MTMAX == 4 && rest == 3) cross_tiles<KS, 4, XP>(ybuf, dpad, n_act, p0, xsrc, KS, t_lo, t_hi, zt, out, lane);
+    else if (MTMAX == 4 && rest == 2) cross_tiles<KS, 2, XP>(ybuf, dpad, n_act, p0, xsrc, KS, t_lo, t_hi, zt, out, lane);
+    else if (rest >= 1) cross_tiles<KS, 1, XP>(ybuf, dpad, n_act, p0, xsrc, KS, t_lo, t_hi, zt, out, lane);
+}
+// dispatch on the number of k-steps (dpad / 4)
+template <typename XP>
+__device__ inline void cross_stage(lds_cptr ybuf, int dpad, int n_act, XP xsrc, int t_lo, int t_hi, int zt, lds_ptr out, int lane) {
+    switch (dpad >> 2) {
+        case 1: cross_ks<1, XP>(ybuf, dpad, n_act, xsrc, t_lo, t_hi, zt, out, lane); break;
+        case 2: cross_ks<2, XP>(ybuf, dpad, n_act, xsrc, t_lo, t_hi, zt, out, lane); break;
+        case 4: cross_ks<4, XP>(ybuf, dpad, n_act, xsrc, t_lo, t_hi, zt, out, lane); break;
+        case 8: cross_ks<8, XP>(ybuf, dpad, n_act, xsrc, t_lo, t_hi, zt, out, lane); break;
+        default: cross_ks<16, XP>(ybuf, dpad, n_act, xsrc, t_lo, t_hi, zt, out, lane); break;
+    }
+}
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+// One hand-over granule: {epoch, 32 bits of payload}, written by ONE write-through (sc1) 8-byte store, so the data is its
+// own flag (cdna_hip_programming.md section 6, Guideline 16, form R2): no release fence, no separate flag word.
+__device__ inline void store_granule(unsigned long long* g, unsigned epoch, unsigned value) {
+    __hip_atomic_store((gu64*)g, ((unsigned long long)epoch << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline unsigned long long load_granule(const unsigned long long* g) {
+    return __hip_atomic_load((gu64*)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // TAIL selects the fused tail compiled into the instance (the host passes the matching flags in KParams): registers
 // are allocated for the worst path of a kernel, so the tails a model cannot take are kept out of its instance.
 enum K1Tail : int { TAIL_NONE = 0, TAIL_PREP = 1, TAIL_PREP_MFMA = 2, TAIL_OBS = 3 };
@@ -491,12 +603,21 @@ enum K1Tail : int { TAIL_NONE = 0, TAIL_PREP = 1, TAIL_PREP_MFMA = 2, TAIL_OBS =
 // two_colour, current-population partners.  RES = false is the one-phase-per-launch form with n_split workgroups per group.
 // PLAIN = the default sampler and nothing else (random_gamma, no snooker, kappa = 1, no block masks, posterior + Metropolis,
 // no trace): the branches of everything else are compiled out of the instance (6 % at cfg3 SUFFSTAT).
-template <int WG, bool TILE, int TAIL, bool RES, bool PLAIN>
-__global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
+// STREAM = streaming-resident form (MvNormal families, STREAMING likelihood, small populations): the resident kernel with
+// the observation stream inside.  p.st_C workgroups per group each hold the whole group in LDS and make every proposal of
+// the phase (redundantly -- it is cheap), but stream only their own 1/st_C of the observation tiles through the matrix
+// cores for all of the phase's proposals; the per-chunk cross terms are handed over between the st_C workgroups of the group
+// (8-byte write-through granules that carry their own epoch tag, polled with sc1 loads), summed by every one of them in the
+// same fixed order, and every one then makes the same accept decisions and keeps its LDS copy of the group current;
+// workgroup 0 of the group writes HBM (state, weights, history).  Every proposal still visits every observation, as the
+// reference's loglike does; what disappears is the K1 -> K2 -> K3 launch chain per colour phase.
+template <int WG, bool TILE, int TAIL, bool RES, bool PLAIN, bool STREAM = false>
+__global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(KParams p0) {
     constexpr bool FUSE_PREP = TAIL == TAIL_PREP || TAIL == TAIL_PREP_MFMA;
     constexpr bool PREP_MFMA = TAIL == TAIL_PREP_MFMA;
     constexpr bool FUSE_OBS = TAIL == TAIL_OBS;
     static_assert(!RES || TILE, "the resident form keeps the group in LDS");
+    static_assert(!STREAM || (RES && FUSE_PREP), "the streaming-resident form is a resident MvNormal instance");
     extern __shared__ double lds[];
     DEMC_STAMP_INIT();
     __shared__ double s_total;
@@ -507,8 +628,19 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
     // Workgroups are dealt to the 8 XCDs round-robin by blockIdx, and each XCD has its own L2.  The n_split workgroups of
     // a group copy the same partner pool, so they are given blockIdx values 8 apart: same XCD, dispatched back to back,
     // and the second copy is served by that XCD's L2 instead of HBM.  (Plain order when the groups do not divide by 8.)
-    int g, sp;
-    if (!RES && (p.n_groups & 7) == 0) {
+    int g, sp, c_idx = 0;  // c_idx: which of the st_C workgroups of the group (STREAM)
+    if (STREAM) {
+        // the st_C workgroups of a group get blockIdx values 8 apart -> one XCD, one L2 for their hand-over granules
+        if ((p.n_groups & 7) == 0) {
+            const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+            c_idx = j % p.st_C;
+            g = (j / p.st_C) * 8 + xcd;
+        } else {
+            g = blockIdx.x / p.st_C;
+            c_idx = blockIdx.x % p.st_C;
+        }
+        sp = 0;
+    } else if (!RES && (p.n_groups & 7) == 0) {
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
         sp = j % p.n_split;
         g = (j / p.n_split) * 8 + xcd;
@@ -532,12 +664,24 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
     double* w_s = tile + (TILE ? (size_t)p.tile_rows * D : 0);
     double* cdf = w_s + (RES ? Np : 0);
     double* ainv_s = cdf + Np + ((Np + 15) >> 4);
-    const int scr_stride = D + 2;
+    // STREAM keeps theta' of EVERY moving particle until the cross terms are in: one scratch row per particle, with room for
+    // the scalars the accept needs later (aux, S, prior, out-of-bounds flag, snooker adjustment, accept uniform)
+    const int scr_stride = STREAM ? D + 6 : D + 2;
     double* xb_s = ainv_s + (ld_ainv ? (size_t)dd : 0);
     double* scr = xb_s + (FUSE_PREP ? d : 0);
     const bool use_scr = FUSE_PREP || FUSE_OBS;  // theta' of the pass kept in LDS for the fused tails
     double* plan_d = scr + p.scr_doubles;  // [plan_cap][4]: g1, g2, accept uniform, select_base uniform
     int* plan_i = reinterpret_cast<int*>(plan_d + 4 * (size_t)plan_cap);  // [plan_cap][4]: snooker?, three row indices
+    // STREAM: y rows [st_rows][dpad] | per-wave partial sums [WG/64][st_nact_max] | granule payloads [st_C][st_nact_max] (as
+    // 2 x u32) | this workgroup's chunk of Xf (if it fits)
+    double* ybuf = reinterpret_cast<double*>(plan_i + 4 * (size_t)plan_cap);
+    double* part_l = ybuf + (STREAM ? (size_t)p.st_rows * p.dpad : 0);
+    unsigned* part_c = reinterpret_cast<unsigned*>(part_l + (STREAM ? (size_t)(WG / 64) * p.st_nact_max : 0));
+    // (16-byte aligned: the chunk is copied by 16-byte LDS-DMA pieces; the host leaves the slack)
+    double* xs = reinterpret_cast<double*>((reinterpret_cast<size_t>(part_c + (STREAM ? 2 * (size_t)p.st_C * p.st_nact_max : 0)) + 15) & ~(size_t)15);
+    // observation tiles of this workgroup: [xt_lo, xt_hi) of Xf
+    const int xt_lo = STREAM ? c_idx * p.st_chunk_tiles : 0;
+    const int xt_hi = STREAM ? (xt_lo + p.st_chunk_tiles < p.n_tiles ? xt_lo + p.st_chunk_tiles : p.n_tiles) : 0;
 
     if (RES) {  // once: every row and weight of the group, A^-1 and xbar
         if (even) {
@@ -551,9 +695,21 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
             for (int i = tid; i < dd; i += WG) ainv_s[i] = p.Ainv[i];
         if (FUSE_PREP)
             for (int i = tid; i < d; i += WG) xb_s[i] = p.xbar[i];
-        if (even) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (STREAM) {
+            for (int i = tid; i < p.st_rows * p.dpad; i += WG) ybuf[i] = 0.0;  // the k-step padding beyond d stays zero
+            if (p.st_x_lds && xt_lo < xt_hi) {  // Xf is contiguous per tile: a linear copy, 16 B per lane, by LDS-DMA
+                const double* src = p.Xf + (size_t)xt_lo * (p.dpad >> 2) * 64;
+                const int n16 = ((xt_hi - xt_lo) * (p.dpad >> 2) * 64) >> 1;
+                for (int c0 = wave * 64; c0 < n16; c0 += WG)
+                    if (c0 + lane < n16) lds_dma16(src + 2 * (size_t)(c0 + lane), xs + 2 * (size_t)c0);
+            }
+            if (p.st_x_lds)  // tile st_chunk_tiles of the LDS copy: all zero, absorbs the odd tail of the tile ping-pong
+                for (int i = tid; i < (p.dpad >> 2) * 64; i += WG) xs[(size_t)p.st_chunk_tiles * (p.dpad >> 2) * 64 + i] = 0.0;
+        }
+        if (even || (STREAM && p.st_x_lds)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    const bool wr_hbm = !STREAM || c_idx == 0;  // STREAM: workgroup 0 of the group owns the HBM copy
     double bfrag[2][8];  // A^-1 fragments of the MFMA preparation, loaded once (below)
 
     const long long n_steps = RES ? (long long)p0.n_iters * p0.n_sweeps * 2 : 1;
@@ -800,6 +956,63 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
             }
     }
 
+    // ---- fused tail: compute_posterior! + mh_update! + store_samples! for one particle (all lanes of its sub-group) ----
+    auto finish_particle = [&](bool valid, int pl, size_t slot, const double* pt, int srow, double prior, int oob, double adj,
+                               double aux, double S, double u_acc, int kind, int i0, int i1, int i2) {
+        const double w = RES ? w_s[pl] : gw[pl];
+        const double sg = (p.family == FAM_MVN_ISO) ? scr[srow * scr_stride + d]
+                          : (p.family == FAM_GAUSSIAN) ? scr[srow * scr_stride + 1] : 0.0;
+        double wp;
+        if (!PLAIN && p.fitness_kind == 1)
+            wp = oob ? (p.update_kind == 1 ? -INFINITY : INFINITY) : loglike_from_stats(p, S, aux, sg);
+        else
+            wp = oob ? -INFINITY : prior + loglike_from_stats(p, S, aux, sg);
+        const int acc = decide<PLAIN>(p, u_acc, wp, w, adj);  // every lane of the sub-group holds the same inputs
+        if (sl == 0 && valid) {
+            if (acc) {
+                if (wr_hbm) p.weight[slot] = wp;
+                if (RES) w_s[pl] = wp;
+            }
+            if (!PLAIN && p.trace && wr_hbm) {
+                if (!STREAM) {
+                    p.tr_idx[slot * 4 + 0] = kind; p.tr_idx[slot * 4 + 1] = i0;
+                    p.tr_idx[slot * 4 + 2] = i1; p.tr_idx[slot * 4 + 3] = i2;
+                }
+                p.tr_w[slot] = wp; p.tr_acc[slot] = (unsigned char)acc; p.prop_adj[slot] = adj;
+            }
+            if (p.store_row >= 0 && wr_hbm) {
+                const size_t hrow = (size_t)p.store_row * p.P + slot;
+                if ((PLAIN || p.update_kind == 0) && p.mode == MODE_STEP) {  // utilities.jl:207-208
+                    p.acc_hist[hrow] = (unsigned char)acc;
+                    p.lp_hist[hrow] = acc ? wp : w;
+                }
+                p.id_hist[hrow] = (int)p.id[slot];
+            }
+        }
+        if (valid) {
+            double* trow = p.theta + slot * D;
+            double* lrow = tile + (size_t)pl * D;  // RES: the group's copy in LDS moves with it
+            double* hrow = (p.store_row >= 0 && wr_hbm) ? p.hist + ((size_t)p.store_row * p.P + slot) * D : nullptr;
+            const double* th = scr + srow * scr_stride;
+            if (acc || hrow)
+                for (int k = sl; 2 * k < D; k += lpp) {
+                    const int j0 = 2 * k;
+                    const bool has1 = j0 + 1 < D;
+                    const double v0 = acc ? th[j0] : pt[j0];
+                    const double v1 = has1 ? (acc ? th[j0 + 1] : pt[j0 + 1]) : 0.0;
+                    if (even) {
+                        if (acc && wr_hbm) *reinterpret_cast<double2*>(trow + j0) = make_double2(v0, v1);  // utilities.jl:204
+                        if (RES && acc) *reinterpret_cast<double2*>(lrow + j0) = make_double2(v0, v1);
+                        if (hrow) *reinterpret_cast<double2*>(hrow + j0) = make_double2(v0, v1);  // utilities.jl:170-180
+                    } else {
+                        if (acc && wr_hbm) { trow[j0] = v0; if (has1) trow[j0 + 1] = v1; }
+                        if (RES && acc) { lrow[j0] = v0; if (has1) lrow[j0 + 1] = v1; }
+                        if (hrow) { hrow[j0] = v0; if (has1) hrow[j0 + 1] = v1; }
+                    }
+                }
+        }
+    };
+
     DEMC_STAMP(13);  // A^-1 fragments in registers
     for (int pass = 0; pass < n_pass; ++pass) {
         const int q = q_lo + pass * ppp + sub;
@@ -808,6 +1021,7 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
         const size_t slot = (size_t)g * Np + pl;
         const uint32_t eslot = (uint32_t)g_glob * (uint32_t)Np + (uint32_t)pl;
         const double* pt = (TILE && !p.own_in_pool) ? own + (size_t)(valid ? q - q_lo : 0) * D : rows + (size_t)pl * D;
+        const int srow = STREAM ? pass * ppp + sub : sub;  // scratch row: per sub-group, or per particle (STREAM)
 
         // per-particle Philox blocks: lane b of the sub-group evaluates block b (when the sub-group is wide enough)
         if (pass == DEMC_STAMP_PASS || n_pass == 1) DEMC_STAMP(2);  // top of the steady-state pass
@@ -1083,7 +1297,7 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
                     prior += prior_term(t, v, inv_sref, log_sref);
                 }
             }
-            if (valid && p.write_prop) {
+            if (valid && p.write_prop && wr_hbm) {
                 if (even)
                     *reinterpret_cast<double2*>(p.prop + slot * D + j0) = make_double2(v0, v1);
                 else {
@@ -1092,8 +1306,8 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
                 }
             }
             if (use_scr) {
-                scr[sub * scr_stride + j0] = v0;
-                if (has1) scr[sub * scr_stride + j0 + 1] = v1;
+                scr[srow * scr_stride + j0] = v0;
+                if (has1) scr[srow * scr_stride + j0 + 1] = v1;
             }
         }
         if (pass == DEMC_STAMP_PASS || n_pass == 1) DEMC_STAMP(5);  // per-dimension loop done
@@ -1114,7 +1328,7 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
             // wave execute in order, so only the compiler must be kept from reordering them.
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const double* th = scr + sub * scr_stride;
+            const double* th = scr + srow * scr_stride;
             // centred proposal mu~ = theta' - xbar (the data were centred the same way at demc_set_model)
             if (PREP_MFMA) {
                 // The wave's R = 64/lpp particles are rows 0..R-1 of the A operand (lane: row = lane&15, k = 4ks + lane>>4);
@@ -1124,14 +1338,18 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
                 // particle's own lanes pick them up.
                 const int lane = tid & 63, kq = lane >> 4, row = lane & 15;
                 const int R = 64 / lpp, wrow0 = (tid >> 6) * R;
-                const double* trow = scr + (wrow0 + (row < R ? row : 0)) * scr_stride;
+                const int srow0 = (STREAM ? pass * ppp : 0) + wrow0;  // scratch row of the wave's first particle
+                const double* trow = scr + (srow0 + (row < R ? row : 0)) * scr_stride;
                 d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+                const bool two_tiles = d > 16;  // columns 16..31 exist
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
-                    const int k = 4 * ks + kq;
-                    const double a = (row < R && k < d) ? trow[k] - xb_s[k] : 0.0;
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[0][ks], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[1][ks], acc1, 0, 0, 0);
+                    if (4 * ks < d) {  // (uniform) k-steps beyond d would multiply zeros
+                        const int k = 4 * ks + kq;
+                        const double a = (row < R && k < d) ? trow[k] - xb_s[k] : 0.0;
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[0][ks], acc0, 0, 0, 0);
+                        if (two_tiles) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[1][ks], acc1, 0, 0, 0);
+                    }
                 }
                 const int c0 = row, c1 = row + 16;
                 const double xb0 = c0 < d ? xb_s[c0] : 0.0, xb1 = c1 < d ? xb_s[c1] : 0.0;
@@ -1140,7 +1358,7 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
                 for (int r = 0; r < 4; ++r) {
                     const int pr = kq + 4 * r;  // uniform over the 16 lanes of a DPP row
                     if (pr < R) {
-                        double* tr = scr + (wrow0 + pr) * scr_stride;
+                        double* tr = scr + (srow0 + pr) * scr_stride;
                         const double y0 = c0 < d ? acc0[r] : 0.0, y1 = c1 < d ? acc1[r] : 0.0;
                         double a_ = 0.0, s_ = 0.0;
                         if (c0 < d) a_ = fma(tr[c0] - xb0, y0, a_);
@@ -1150,7 +1368,8 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
                         else {
                             const int qr = q_lo + pass * ppp + wrow0 + pr;
                             if (qr < q_hi) {
-                                double* yrow = p.Ypad + ((size_t)g * Np + p.a_lo + qr) * p.dpad;
+                                double* yrow = STREAM ? ybuf + (size_t)(qr - q_lo) * p.dpad
+                                                      : p.Ypad + ((size_t)g * Np + p.a_lo + qr) * p.dpad;
                                 if (c0 < p.dpad) yrow[c0] = y0;
                                 if (c1 < p.dpad) yrow[c1] = y1;
                             }
@@ -1191,11 +1410,12 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
                     S = fma(y0, p.sx[c0], S);
                     if (c1 < d) S = fma(y1, p.sx[c1], S);
                 } else if (valid) {
-                    p.Ypad[slot * p.dpad + c0] = y0;
-                    if (c1 < p.dpad) p.Ypad[slot * p.dpad + c1] = (c1 < d) ? y1 : 0.0;
+                    double* yrow = STREAM ? ybuf + (size_t)srow * p.dpad : p.Ypad + slot * p.dpad;
+                    yrow[c0] = y0;
+                    if (c1 < p.dpad) yrow[c1] = (c1 < d) ? y1 : 0.0;
                 }
             }
-            if (!p.sx && valid && !PREP_MFMA)  // zero the k-step padding beyond d
+            if (!p.sx && valid && !PREP_MFMA && !STREAM)  // zero the k-step padding beyond d (STREAM: zeroed once, never written)
                 for (int c = 2 * ((d + 1) / 2) + sl; c < p.dpad; c += lpp) p.Ypad[slot * p.dpad + c] = 0.0;
             if (!PREP_MFMA) {
                 aux = group_sum(aux, lpp, s_gsum);
@@ -1210,7 +1430,7 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (lpp > 64) __syncthreads();  // the row was written by all waves of the workgroup
-            S = group_sum(obs_range_sum(p, scr + sub * scr_stride, sl, p.N, lpp, nullptr), lpp, s_gsum);
+            S = group_sum(obs_range_sum(p, scr + srow * scr_stride, sl, p.N, lpp, nullptr), lpp, s_gsum);
         }
 
         if (!p.fuse_accept) {
@@ -1235,62 +1455,96 @@ __global__ __launch_bounds__(WG, WG == 256 ? 2 : 1) void k_propose(KParams p0) {
             continue;
         }
 
+        if (STREAM) {
+            // the cross terms are not in yet: park what the accept needs next to theta' (scratch row of the particle) and
+            // go on with the next pass; the second loop below finishes the particles
+            if (sl == 0 && valid) {
+                double* tr = scr + srow * scr_stride;
+                tr[D] = aux; tr[D + 2] = prior; tr[D + 3] = (double)oob; tr[D + 4] = adj; tr[D + 5] = u_acc;
+                if (!PLAIN && p.trace && wr_hbm) {
+                    p.tr_idx[slot * 4 + 0] = kind; p.tr_idx[slot * 4 + 1] = i0;
+                    p.tr_idx[slot * 4 + 2] = i1; p.tr_idx[slot * 4 + 3] = i2;
+                }
+            }
+            continue;
+        }
         if (pass == DEMC_STAMP_PASS || n_pass == 1) DEMC_STAMP(8);  // in-kernel observation loop done
-        // ---- fused tail: compute_posterior! + mh_update! + store_samples! for this particle ----
-        const double w = RES ? w_s[pl] : gw[pl];
-        const double sg = (p.family == FAM_MVN_ISO) ? scr[sub * scr_stride + d]
-                          : (p.family == FAM_GAUSSIAN) ? scr[sub * scr_stride + 1] : 0.0;
-        double wp;
-        if (!PLAIN && p.fitness_kind == 1)
-            wp = oob ? (p.update_kind == 1 ? -INFINITY : INFINITY) : loglike_from_stats(p, S, aux, sg);
-        else
-            wp = oob ? -INFINITY : prior + loglike_from_stats(p, S, aux, sg);
-        const int acc = decide<PLAIN>(p, u_acc, wp, w, adj);  // every lane of the sub-group holds the same inputs
-        if (sl == 0 && valid) {
-            if (acc) {
-                p.weight[slot] = wp;
-                if (RES) w_s[pl] = wp;
-            }
-            if (!PLAIN && p.trace) {
-                p.tr_idx[slot * 4 + 0] = kind; p.tr_idx[slot * 4 + 1] = i0;
-                p.tr_idx[slot * 4 + 2] = i1; p.tr_idx[slot * 4 + 3] = i2;
-                p.tr_w[slot] = wp; p.tr_acc[slot] = (unsigned char)acc; p.prop_adj[slot] = adj;
-            }
-            if (p.store_row >= 0) {
-                const size_t hrow = (size_t)p.store_row * p.P + slot;
-                if ((PLAIN || p.update_kind == 0) && p.mode == MODE_STEP) {  // utilities.jl:207-208
-                    p.acc_hist[hrow] = (unsigned char)acc;
-                    p.lp_hist[hrow] = acc ? wp : w;
-                }
-                p.id_hist[hrow] = (int)p.id[slot];
-            }
-        }
-        if (valid) {
-            double* trow = p.theta + slot * D;
-            double* lrow = tile + (size_t)pl * D;  // RES: the group's copy in LDS moves with it
-            double* hrow = (p.store_row >= 0) ? p.hist + ((size_t)p.store_row * p.P + slot) * D : nullptr;
-            const double* th = scr + sub * scr_stride;
-            if (acc || hrow)
-                for (int k = sl; 2 * k < D; k += lpp) {
-                    const int j0 = 2 * k;
-                    const bool has1 = j0 + 1 < D;
-                    const double v0 = acc ? th[j0] : pt[j0];
-                    const double v1 = has1 ? (acc ? th[j0 + 1] : pt[j0 + 1]) : 0.0;
-                    if (even) {
-                        if (acc) *reinterpret_cast<double2*>(trow + j0) = make_double2(v0, v1);  // utilities.jl:204
-                        if (RES && acc) *reinterpret_cast<double2*>(lrow + j0) = make_double2(v0, v1);
-                        if (hrow) *reinterpret_cast<double2*>(hrow + j0) = make_double2(v0, v1);  // utilities.jl:170-180
-                    } else {
-                        if (acc) { trow[j0] = v0; if (has1) trow[j0 + 1] = v1; }
-                        if (RES && acc) { lrow[j0] = v0; if (has1) lrow[j0 + 1] = v1; }
-                        if (hrow) { hrow[j0] = v0; if (has1) hrow[j0 + 1] = v1; }
-                    }
-                }
-        }
+        finish_particle(valid, pl, slot, pt, srow, prior, oob, adj, aux, S, u_acc, kind, i0, i1, i2);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();  // scratch rows are reused by the same sub-group in the next pass
         if (lpp > 64 && use_scr) __syncthreads();
         if (pass == DEMC_STAMP_PASS || n_pass == 1) DEMC_STAMP(9);  // accept + row moves done
+    }
+    if (STREAM) {
+        // ---- the observation stream: cross terms of ALL proposals of the phase against this workgroup's chunk of tiles ----
+        __syncthreads();  // y rows of every pass are in LDS
+        DEMC_STAMP(16);  // proposals + preparation of every moving particle done
+        const int n_act = q_hi - q_lo;  // (q_lo = 0: one workgroup moves the whole colour)
+        {
+            const int nw = WG / 64;
+            const int nt = xt_hi - xt_lo, per_w = (nt + nw - 1) / nw;
+            const int t_lo = wave * per_w < nt ? wave * per_w : nt, t_hi = t_lo + per_w < nt ? t_lo + per_w : nt;
+            lds_ptr outw = (lds_ptr)(part_l + (size_t)wave * p.st_nact_max);
+            if (p.st_x_lds)  // zero tile: the one appended to the LDS copy
+                cross_stage<lds_cptr>((lds_cptr)ybuf, p.dpad, n_act, (lds_cptr)xs, t_lo, t_hi, p.st_chunk_tiles, outw, lane);
+            else             // zero tile: tile n_tiles of Xf
+                cross_stage<glb_cptr>((lds_cptr)ybuf, p.dpad, n_act, (glb_cptr)(p.Xf + (size_t)xt_lo * (p.dpad >> 2) * 64), t_lo, t_hi,
+                                      p.n_tiles - xt_lo, outw, lane);
+        }
+        __syncthreads();
+        DEMC_STAMP(17);  // cross terms of this workgroup's chunk done
+        // this workgroup's partial per particle (waves in fixed order) -> two granules, tagged with the step's epoch
+        const unsigned epoch = (unsigned)(step + 1);
+        unsigned long long* gran = p.st_gran + (((size_t)(step & 1) * p.n_groups + g) * p.st_C) * p.st_nact_max * 2;
+        if (tid < n_act) {
+            double v = 0.0;
+            for (int wv = 0; wv < WG / 64; ++wv) v += part_l[(size_t)wv * p.st_nact_max + tid];
+            unsigned long long* mine = gran + ((size_t)c_idx * p.st_nact_max + tid) * 2;
+            store_granule(mine, epoch, (unsigned)__double2loint(v));
+            store_granule(mine + 1, epoch, (unsigned)__double2hiint(v));
+        }
+        DEMC_STAMP(18);  // granules stored
+        // every workgroup of the group collects all st_C x n_act partials: sweep until every tag carries this epoch
+        {
+            const int tot = p.st_C * n_act * 2;
+            unsigned spins = 0;
+            for (;;) {
+                int ok = 1;
+                for (int e = tid; e < tot; e += WG) {
+                    const int cc = e / (2 * n_act), r = e - cc * 2 * n_act;
+                    const unsigned long long x = load_granule(gran + (size_t)cc * p.st_nact_max * 2 + r);
+                    ok &= (unsigned)(x >> 32) == epoch;
+                    part_c[(size_t)cc * p.st_nact_max * 2 + r] = (unsigned)x;
+                }
+                if (__syncthreads_and(ok)) break;
+                if (++spins > (1u << 22)) {  // cannot happen with co-resident workgroups; never spin unbounded
+                    if (tid == 0) *p.st_err = 1u;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        DEMC_STAMP(19);  // every chunk's granules collected
+        if (tid < n_act) {  // S = sum over the chunks, in chunk order: the same bits in every workgroup of the group
+            double S = 0.0;
+            for (int cc = 0; cc < p.st_C; ++cc) {
+                const unsigned* h2 = part_c + ((size_t)cc * p.st_nact_max + tid) * 2;
+                S += __hiloint2double((int)h2[1], (int)h2[0]);
+            }
+            scr[tid * scr_stride + D + 1] = S;
+        }
+        __syncthreads();
+        for (int pass = 0; pass < n_pass; ++pass) {
+            const int q = q_lo + pass * ppp + sub;
+            const bool valid = q < q_hi;
+            const int pl = p.a_lo + (valid ? q : q_lo);
+            const size_t slot = (size_t)g * Np + pl;
+            const int srow = pass * ppp + sub;
+            const double* tr = scr + (valid ? srow : 0) * scr_stride;
+            finish_particle(valid, pl, slot, rows + (size_t)pl * D, valid ? srow : 0, tr[D + 2], (int)tr[D + 3], tr[D + 4], tr[D],
+                            tr[D + 1], tr[D + 5], 0, -1, -1, -1);
+        }
+        DEMC_STAMP(20);  // accept + row moves of every moving particle done
     }
     if (RES) __syncthreads();  // the other colour reads what this phase wrote (rows, weights); scratch and plan are reused
     DEMC_STAMP(10);  // end of the step (of the kernel in the one-phase form)

@@ -259,6 +259,46 @@ def test_fused_equals_unfused(demc):
             assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("family,G,Np,d,N,kw", [
+    ("mvn_full", 32, 64, 8, 10000, dict()),                              # BASELINE cfg2: 8 workgroups per group, X chunk in LDS
+    ("mvn_full", 5, 20, 10, 400, dict(theta_snooker=0.2)),               # odd group count (plain block order), snooker
+    ("mvn_iso", 8, 33, 5, 700, dict(kappa=0.7)),                         # iso family (sigma is a parameter), odd D, odd halves
+    ("mvn_full", 3, 300, 16, 333, dict()),                               # 150 moving particles: several particle-tile groups
+    ("mvn_full", 16, 16, 33, 2000, dict(beta=0.5)),                      # d > 32: VALU preparation, 16 k-steps, mutation
+    ("mvn_full", 200, 8, 3, 50, dict()),                                 # more groups than fit twice: one workgroup per group
+])
+def test_streaming_resident_form_equals_the_launch_chain(demc, family, G, Np, d, N, kw):
+    """STREAMING likelihood of a small population: fuse = 0 keeps the group resident AND streams the observations inside the
+    same kernel (several workgroups per group, hand-over of the per-chunk cross terms); fuse = 1 is the K1 -> K2 -> K3 chain
+    per colour phase.  Same samples, acceptances and ids across migrations and burn-in; log-densities to rounding (the
+    observation sums are split differently)."""
+    prob = make_problem(family, np.random.default_rng(81), N=N, d=d)
+    D = prob["D"]
+    th0 = prob["init"](G * Np)
+    a, b = (_run_fuse_mode(demc, prob, th0, fuse, G, Np, D, 24, alpha=0.3, burnin=10, loglike_mode=0, **kw) for fuse in (0, 1))
+    for i, (x, y) in enumerate(zip(a, b)):
+        if i in (2, 5):
+            np.testing.assert_allclose(x, y, rtol=1e-10)
+        elif i in (0, 4) and kw.get("theta_snooker", 0.0) > 0.0:
+            np.testing.assert_allclose(x, y, rtol=0, atol=1e-11)
+        else:
+            assert np.array_equal(x, y), f"array {i}"
+
+
+def test_streaming_resident_form_with_blocks_and_trace(demc, orc):
+    """the streaming-resident kernel under block updates, and teacher-forced against the oracle with the trace on"""
+    prob = make_problem("mvn_full", np.random.default_rng(82), N=500, d=6)
+    blocks = np.array([[1, 1, 0, 0, 0, 0], [0, 0, 1, 1, 1, 1]], np.uint8)
+    th0 = prob["init"](4 * 24)
+    a, b = (_run_fuse_mode(demc, prob, th0, fuse, 4, 24, 6, 20, blocks=blocks, alpha=0.2, burnin=8, loglike_mode=0) for fuse in (0, 1))
+    for i, (x, y) in enumerate(zip(a, b)):
+        if i in (2, 5):
+            np.testing.assert_allclose(x, y, rtol=1e-10)
+        else:
+            assert np.array_equal(x, y), f"array {i}"
+    teacher_forced(demc, orc, prob, n_iter=10, n_groups=4, Np=12, schedule=2, burnin=5, theta_snooker=0.2, alpha=0.5)
+
+
 @pytest.mark.parametrize("family,Np,d,kw", [
     ("mvn_full", 256, 32, dict(loglike_mode=1)),                    # 512-thread workgroups, one pass per phase, MFMA prep
     ("mvn_full", 301, 16, dict(loglike_mode=1, theta_snooker=0.3)),  # odd Np: halves of 150 / 151, two passes

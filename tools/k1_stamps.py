@@ -50,8 +50,10 @@ else:
     eng.step(1, 30)
     n_wg = min(512, (a.n_groups * a.Np) // 16) if os.environ.get('DEMC_RESIDENT') == '0' else a.n_groups  # resident: one per group
 w_prop = eng.get_trace()["w_prop"]
-n_wg = min(n_wg, len(w_prop) // 16)  # the stamps live in the P-long trace array, 16 per workgroup
-full = w_prop[: n_wg * 16].reshape(n_wg, 16)
+if a.mode == "streaming":
+    n_wg = len(w_prop) // 24  # streaming-resident form: several workgroups per group
+n_wg = min(n_wg, len(w_prop) // 24)  # the stamps live in the P-long trace array, 24 per workgroup
+full = w_prop[: n_wg * 24].reshape(n_wg, 24)
 full = full[full[:, 10] > 0]
 t = full[:, :11]
 names = ["softmax prefix sums done (tile in flight)", "plan written; tile landed (LDS-DMA wait + barrier)",
@@ -68,3 +70,7 @@ ex = np.median(full[:, [11, 13]], 0)
 print(f"  also: plan written (before the tile wait) {ex[0]:.0f}; A^-1 fragments in registers (before pass 0) {ex[1]:.0f}")
 pro = np.median(full[:, [12, 14, 15]], 0)
 print(f"  inside the prologue: group coin {pro[0]:.0f}; weights / A^-1 parked {pro[1]:.0f}; tile copy issued {pro[2]:.0f}")
+if a.mode == "streaming" and (full[:, 16] > 0).any():
+    st = np.median(full[full[:, 16] > 0][:, 16:21], 0)
+    print("  streaming-resident: all proposals prepared %.0f; chunk cross terms %.0f; granules stored %.0f; collected %.0f; "
+          "accept + moves done %.0f" % tuple(st))

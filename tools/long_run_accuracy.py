@@ -49,9 +49,9 @@ for r0 in range(iters_hist0, iters_hist0 + keep, 50):
 eng.close()
 mean = s1 / n
 sd = np.sqrt(s2 / n - mean * mean)
-Ainv = np.linalg.inv(prob["Sigma"])
+Ainv = np.linalg.inv(prob["hyper"])
 prec = N * Ainv + np.eye(d)
-post_mean = np.linalg.solve(prec, N * Ainv @ prob["X"].mean(0))
+post_mean = np.linalg.solve(prec, N * Ainv @ prob["data"].mean(0))
 post_sd = np.sqrt(np.diag(np.linalg.inv(prec)))
 print(json.dumps(dict(mode=mode, iterations=iters, kept=keep, seconds=dt,
                       posterior_mean_l1_rel=float(np.abs(mean - post_mean).sum() / np.abs(post_mean).sum()),
