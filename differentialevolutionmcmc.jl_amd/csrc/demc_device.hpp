@@ -95,6 +95,27 @@ __device__ inline double norm_logpdf(double x, double m, double s) {
 __device__ inline double Phi(double x) { return 0.5 * erfc(-x * kInvSqrt2); }
 __device__ inline double phi(double x) { return exp(-0.5 * x * x) * kInvSqrt2Pi; }
 __device__ inline double softplus(double x) { return x > 0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
+// softplus with a short log1p: for t = exp(-|x|) in (0, 1], log1p(t) = 2 atanh(z), z = t / (2 + t) in (0, 1/3], whose odd
+// series in z converges as 9^-n (17 terms reach 1e-17 relative); the quotient by reciprocal + two Newton steps (the
+// denominator lies in [2, 3]: no scaling needed).  About a third of the instructions of the library's log1p on top of
+// exp; agrees with softplus() to ~2e-16 relative (tests/test_gpu_parity.py compares the hierarchical families with the
+// oracle's libm forms at 1e-9).  The hierarchical likelihoods spend most of their instructions here.
+__device__ inline double softplus_fast(double x) {
+    const double t = exp(-fabs(x));
+    const double den = 2.0 + t;
+    double r = __builtin_amdgcn_rcp(den);
+    r = fma(fma(-den, r, 1.0), r, r);
+    r = fma(fma(-den, r, 1.0), r, r);
+    double z = t * r;
+    z = fma(fma(-den, z, t), r, z);
+    const double w = z * z;
+    double s = 1.0 / 33.0;
+    s = fma(s, w, 1.0 / 31.0); s = fma(s, w, 1.0 / 29.0); s = fma(s, w, 1.0 / 27.0); s = fma(s, w, 1.0 / 25.0);
+    s = fma(s, w, 1.0 / 23.0); s = fma(s, w, 1.0 / 21.0); s = fma(s, w, 1.0 / 19.0); s = fma(s, w, 1.0 / 17.0);
+    s = fma(s, w, 1.0 / 15.0); s = fma(s, w, 1.0 / 13.0); s = fma(s, w, 1.0 / 11.0); s = fma(s, w, 1.0 / 9.0);
+    s = fma(s, w, 1.0 / 7.0); s = fma(s, w, 1.0 / 5.0); s = fma(s, w, 1.0 / 3.0); s = fma(s, w, 1.0);
+    return fmax(x, 0.0) + 2.0 * z * s;
+}
 
 enum Prior : int {
     PR_FLAT = 0, PR_NORMAL = 1, PR_HALFCAUCHY = 2, PR_UNIFORM = 3, PR_BETA = 4, PR_NORMAL_REF = 5, PR_GAMMA = 6,

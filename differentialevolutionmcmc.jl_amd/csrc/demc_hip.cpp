@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "demc_kernels.hpp"
+#include "demc_longrow.hpp"
 
 using namespace demc;
 
@@ -50,6 +51,8 @@ struct demc_handle {
     double *tr_w = nullptr, *partial = nullptr, *aux = nullptr;
     DimTab* dimtab = nullptr;
     std::vector<DimTab> h_tab;  // host copy: bounds and priors arrive in separate calls
+    DimSeg* dimseg = nullptr;   // run-length form of the table (kMaxDimSeg entries)
+    int n_seg = 0;              // 0: more segments than kMaxDimSeg, the kernels read dimtab
     double *hist = nullptr, *lp_hist = nullptr, *mig_rows = nullptr, *scratch_theta = nullptr, *scratch_w = nullptr;
     long long* id = nullptr;
     unsigned char *prop_oob = nullptr, *tr_acc = nullptr, *masks = nullptr, *acc_hist = nullptr;
@@ -218,7 +221,7 @@ KParams base_params(demc_handle* h) {
     k.fitness_kind = c.fitness_kind;
     k.theta = h->theta; k.weight = h->weight; k.id = h->id; k.prop = h->prop; k.prop_prior = h->prop_prior;
     k.prop_adj = h->prop_adj; k.prop_oob = h->prop_oob; k.tr_idx = h->tr_idx; k.tr_w = h->tr_w; k.tr_acc = h->tr_acc;
-    k.dimtab = h->dimtab; k.mask = nullptr;
+    k.dimtab = h->dimtab; k.dimseg = h->dimseg; k.n_seg = h->n_seg; k.mask = nullptr;
     k.hist = h->hist; k.acc_hist = h->acc_hist; k.lp_hist = h->lp_hist; k.id_hist = h->id_hist;
     k.P = h->P; k.store_row = -1; k.tile_in_lds = h->tile_in_lds;
     k.family = h->family; k.N = h->N; k.d = h->d; k.n_acc = h->n_acc; k.n_partials = 1;
@@ -433,6 +436,16 @@ int launch_phase(demc_handle* h, KParams& k) {
     const size_t lds_tile = h->k1_lds - h->k1_tile_bytes + (size_t)k.tile_rows * c.D * sizeof(double);  // <= k1_lds
     k.plan = (tile && k.mode == MODE_STEP && k.lpp >= 4 && k.lpp <= 64 && lds_tile + plan_bytes <= kMaxDynLds && !h->rp_active) ? 1 : 0;
     if (const char* e = experiment("DEMC_K1_PLAN")) k.plan = k.plan && e[0] == '1';  // A/B experiments
+    // long rows of a hierarchical family, whole update fused: the dedicated one-pass kernel (demc_longrow.hpp)
+    if (k.lpp > 64 && h->hier_scr && k.fuse_obs && k.fuse_accept && k.mode == MODE_STEP && !h->rp_active && c.fuse != 2 && h->n_seg > 0) {
+        const size_t lr_lds = ((((size_t)c.D + 1) & ~(size_t)1) + (size_t)k.pool_n + ((size_t)k.pool_n + 15) / 16) * sizeof(double);
+        if (lr_lds <= kMaxDynLds) {
+            tick(h, 0, true);
+            hipLaunchKernelGGL(k_longrow<512>, dim3((unsigned)n_prop), dim3(512), lr_lds, h->stream, k);
+            tick(h, 0, false);
+            return DEMC_OK;
+        }
+    }
     tick(h, 0, true);
     const int tail = tail_of(k);
     const size_t lds = tile ? lds_tile + (k.plan ? plan_bytes : 0) : h->k1_lds - h->k1_tile_bytes;
@@ -692,6 +705,7 @@ int size_k1_lds(demc_handle* h) {
             for (int plain = 0; plain < 2; ++plain)
                 HIPCHK(hipFuncSetAttribute((const void*)k1_stream_instance(wgs, tail, plain != 0),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
+    HIPCHK(hipFuncSetAttribute((const void*)k_longrow<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
     plan_resident(h);
     plan_stream(h);
     HIPCHK(hipFuncSetAttribute((const void*)k_mig_pack, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
@@ -743,6 +757,8 @@ bool chol_inv(const double* S, int d, std::vector<double>& Ainv, double& logdet)
 
 extern "C" {
 
+static int upload_dimtab(demc_handle* h);  // (defined next to demc_set_priors)
+
 int32_t demc_version(void) { return DEMC_VERSION; }
 
 const char* demc_last_error(demc_handle* h) { return h ? h->err.c_str() : "null handle"; }
@@ -787,6 +803,7 @@ int32_t demc_create(const demc_config* cfg, demc_handle** out) {
     ALLOC(h->tr_idx, P * 4); ALLOC(h->tr_w, P); ALLOC(h->tr_acc, P);
     ALLOC(h->partial, (size_t)h->partial_cap * P); ALLOC(h->aux, P);
     ALLOC(h->dimtab, D);
+    ALLOC(h->dimseg, (size_t)kMaxDimSeg);
     ALLOC(h->mig_rows, (size_t)c.n_groups_total * (D + 3));
     ALLOC(h->scratch_theta, P * D); ALLOC(h->scratch_w, P);
     if (c.store_history && c.n_rows > 0) {
@@ -799,7 +816,8 @@ int32_t demc_create(const demc_config* cfg, demc_handle** out) {
         DimTab t0;
         t0.lo = -INFINITY; t0.hi = INFINITY; t0.a = 0.0; t0.b = 1.0; t0.c = 0.0; t0.kind = PR_FLAT; t0.ref = 0;
         h->h_tab.assign(D, t0);
-        HIPCHK(hipMemcpy(h->dimtab, h->h_tab.data(), D * sizeof(DimTab), hipMemcpyHostToDevice));
+        int rc_tab = upload_dimtab(h);
+        if (rc_tab != DEMC_OK) return rc_tab;
         std::vector<long long> id(P);
         for (size_t s = 0; s < P; ++s) id[s] = (long long)c.group_offset * c.Np + (long long)s;
         HIPCHK(hipMemcpy(h->id, id.data(), P * sizeof(long long), hipMemcpyHostToDevice));
@@ -847,7 +865,7 @@ int32_t demc_destroy(demc_handle* h) {
     for (hipEvent_t e : h->event_pool) hipEventDestroy(e);
     h->event_pool.clear();
     void* ptrs[] = {h->theta, h->weight, h->prop, h->prop_prior, h->prop_adj, h->tr_w, h->partial, h->aux,
-                    h->dimtab, h->hist, h->lp_hist, h->mig_rows, h->scratch_theta, h->scratch_w, h->id, h->prop_oob,
+                    h->dimtab, h->dimseg, h->hist, h->lp_hist, h->mig_rows, h->scratch_theta, h->scratch_w, h->id, h->prop_oob,
                     h->tr_acc, h->masks, h->acc_hist, h->tr_idx, h->id_hist, h->data, h->Ainv, h->Ypad,
                     h->Xf, h->sx, h->xbar};
     for (void* p : ptrs)
@@ -918,10 +936,13 @@ int32_t demc_set_model(demc_handle* h, int32_t family, const double* data, const
             h->c0 = hyper[0];
             dev.assign(data, data + S);
             dev.resize(2 * S);
+            double lgc_sum = 0.0;
             for (long long s = 0; s < S; ++s) {
                 const double n = hyper[0], k = data[s];
                 dev[S + s] = std::lgamma(n + 1.0) - std::lgamma(k + 1.0) - std::lgamma(n - k + 1.0);
+                lgc_sum += dev[S + s];
             }
+            h->c2 = lgc_sum;  // the long-row kernel adds the coefficients as one data-only constant
         } break;
         case DEMC_FAM_HIER_GAUSSIAN:
             if (D != dm[0] + 3 || dm[1] < 1) return fail(h, DEMC_EINVAL, "HIER_GAUSSIAN: D=S+3, dims=[S,n]");
@@ -1075,9 +1096,23 @@ int32_t demc_set_model_source(demc_handle* h, const char* hip_source, const doub
     });
 }
 
-int upload_dimtab(demc_handle* h) {
+static int upload_dimtab(demc_handle* h) {
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(h->dimtab, h->h_tab.data(), (size_t)h->c.D * sizeof(DimTab), hipMemcpyHostToDevice));
+    // run-length form: consecutive scalars with byte-identical entries share a segment
+    DimSeg segs[kMaxDimSeg];
+    std::memset(segs, 0, sizeof segs);
+    int n = 0;
+    for (int j = 0; j < h->c.D; ++j) {
+        if (j == 0 || std::memcmp(&h->h_tab[(size_t)j], &h->h_tab[(size_t)j - 1], sizeof(DimTab)) != 0) {
+            if (n == kMaxDimSeg) { n = -1; break; }
+            segs[n].start = j;
+            segs[n].t = h->h_tab[(size_t)j];
+            ++n;
+        }
+    }
+    h->n_seg = n > 0 ? n : 0;
+    HIPCHK(hipMemcpy(h->dimseg, segs, sizeof segs, hipMemcpyHostToDevice));
     return DEMC_OK;
 }
 

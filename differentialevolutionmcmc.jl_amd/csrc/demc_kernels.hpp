@@ -38,6 +38,17 @@ struct DimTab {
     int kind, ref;
 };
 
+// Run-length form of the DimTab array: models give whole blocks of scalars the same bounds and prior (cfg4: 10 000 subject
+// effects ~ Normal(0, sd); cfg3: 32 means ~ Normal(0,1)), so the table is a handful of segments.  The kernels keep them in LDS
+// and look a scalar's entry up by its segment instead of streaming 48 bytes per scalar from L2/HBM -- at D = 10 002 that
+// stream was larger than the particle rows themselves.
+struct DimSeg {
+    int start, pad;  // first scalar of the segment
+    DimTab t;
+    double pad2;
+};
+constexpr int kMaxDimSeg = 16;
+
 // Everything a sweep needs, passed by value as the kernarg.
 struct KParams {
     // geometry
@@ -65,6 +76,8 @@ struct KParams {
     double* tr_w;         // [P]
     unsigned char* tr_acc;  // [P]
     const DimTab* dimtab;       // [D] bounds + prior of every scalar, packed
+    const DimSeg* dimseg;       // [n_seg] the same table run-length encoded (n_seg = 0: too many segments, use dimtab)
+    int n_seg;
     const unsigned char* mask;  // [D] or null
     // history (slot keyed)
     double* hist;             // [rows][P][D]
@@ -304,7 +317,7 @@ __device__ inline double obs_range_sum(const KParams& p, const double* th, long 
             for (long long s = i0; s < i1; s += stride) {
                 const double eta = mu0 + th[2 + s], k = p.data[s];
                 // k log p + (n-k) log(1-p), p = logistic(eta): softplus(eta) = eta + softplus(-eta), so ONE softplus per subject
-                acc += lgc[s] - n * softplus(-eta) - (n - k) * eta;
+                acc += lgc[s] - n * softplus_fast(-eta) - (n - k) * eta;
             }
         } break;
         case FAM_HIER_GAUSSIAN: {  // Hierarchical_Example.jl:36-44
@@ -623,6 +636,9 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
     __shared__ double s_total;
     __shared__ double s_gsum[8];
     __shared__ int s_gsumi[8];
+    __shared__ DimSeg s_seg[kMaxDimSeg];
+    for (int i = threadIdx.x; i < p0.n_seg * (int)(sizeof(DimSeg) / sizeof(double)); i += WG)
+        reinterpret_cast<double*>(s_seg)[i] = reinterpret_cast<const double*>(p0.dimseg)[i];  // visible after the barriers below
     KParams p = p0;  // RES: the per-phase fields (iter, sweep, mask, store_row, active range, pool) are rewritten every step
     const int tid = threadIdx.x;
     // Workgroups are dealt to the 8 XCDs round-robin by blockIdx, and each XCD has its own L2.  The n_split workgroups of
@@ -1224,6 +1240,10 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
                 keep0 = !p.mask[j0];
                 keep1 = has1 && !p.mask[j1];
             }
+            // block sweeps (block_update!, main.jl:174-179): a scalar outside the block keeps its value whatever the crossover
+            // proposes (reset!), so neither its noise draw nor the partner rows are needed -- in the hyper-parameter sweep of
+            // a hierarchical model that is all but a few scalars of the row.  (Mutation ignores the mask, main.jl:205.)
+            if (!PLAIN && kind != 2 && keep0 && (keep1 || !has1)) return;
             const U4 nz = draw_block(p.seed, S_NOISE, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)k);
             double u0 = u53(nz.x, nz.y), u1 = u53(nz.z, nz.w);
             if (kind == 2) {  // pt + Normal(0, sigma): mutation.jl:15-18 (block mask ignored, main.jl:205)
@@ -1269,7 +1289,21 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
             const bool has1 = j0 + 1 < D;
             // the per-scalar constants go out with the row loads of value_pair (one wait for all of them) instead of
             // starting a second round trip once the proposal values exist
-            const DimTab tab0 = p.dimtab[j0], tab1 = p.dimtab[has1 ? j0 + 1 : j0];
+            DimTab tab0, tab1;
+            if (p.n_seg > 0) {  // segment of each scalar = number of segment starts at or below it
+                int g0 = 0, g1 = 0;
+                const int j1 = has1 ? j0 + 1 : j0;
+                for (int i = 1; i < p.n_seg; ++i) {
+                    const int st = s_seg[i].start;
+                    g0 += (j0 >= st) ? 1 : 0;
+                    g1 += (j1 >= st) ? 1 : 0;
+                }
+                tab0 = s_seg[g0].t;
+                tab1 = s_seg[g1].t;
+            } else {
+                tab0 = p.dimtab[j0];
+                tab1 = p.dimtab[has1 ? j0 + 1 : j0];
+            }
             double v0, v1;
             value_pair(k, v0, v1);
             if (!PLAIN && kind == 1) {  // adjust_loglike norms (crossover.jl:268-273)
@@ -1678,7 +1712,7 @@ __global__ __launch_bounds__(256) void k_hier_loglike(KParams p) {
         const double* lgc = p.data + S;
         for (long long s = tid; s < S; s += 256) {
             const double eta = mu0 + th[2 + s], k = p.data[s];
-            acc += lgc[s] - n * softplus(-eta) - (n - k) * eta;  // softplus(eta) = eta + softplus(-eta)
+            acc += lgc[s] - n * softplus_fast(-eta) - (n - k) * eta;  // softplus(eta) = eta + softplus(-eta)
         }
     } else {  // FAM_HIER_GAUSSIAN  Hierarchical_Example.jl:36-44
         const double mu0 = th[0], sg = th[2 + S];

@@ -285,6 +285,48 @@ def test_streaming_resident_form_equals_the_launch_chain(demc, family, G, Np, d,
             assert np.array_equal(x, y), f"array {i}"
 
 
+@pytest.mark.parametrize("family,S,kw", [
+    ("hier_binomial", 2500, dict()),                                      # D = 2502, default sampler inside burn-in (base term)
+    ("hier_binomial", 5001, dict(theta_snooker=0.3, kappa=0.8)),          # odd D (no 16-byte row accesses), snooker, recombination
+    ("hier_gaussian", 2100, dict(beta=0.5)),                              # several observations per subject, mutation
+    ("hier_binomial", 4100, dict(blocks=True, theta_snooker=0.2)),        # two block sweeps [hyper ; subject], snooker
+])
+def test_longrow_kernel_equals_generic_fused_kernel(demc, family, S, kw):
+    """rows of thousands of scalars run in the one-pass long-row kernel (fuse = 0); fuse = 2 keeps k_propose's fused form
+    with a workgroup per particle.  Same proposals, priors and decisions; the likelihood sums run in a different order."""
+    kw = dict(kw)
+    prob = make_problem(family, np.random.default_rng(91), S=S, n=4)
+    D = prob["D"]
+    blocks = None
+    if kw.pop("blocks", False):
+        m0 = np.zeros(D, np.uint8)
+        m0[:2] = 1
+        blocks = np.stack([m0, 1 - m0])
+    G, Np = 3, 10
+    th0 = prob["init"](G * Np)
+    a, b = (_run_fuse_mode(demc, prob, th0, fuse, G, Np, D, 12, blocks=blocks, alpha=0.3, burnin=6, **kw) for fuse in (0, 2))
+    for i, (x, y) in enumerate(zip(a, b)):
+        if i in (2, 5):
+            np.testing.assert_allclose(x, y, rtol=1e-10)
+        elif i in (0, 4) and kw.get("theta_snooker", 0.0) > 0.0:
+            np.testing.assert_allclose(x, y, rtol=0, atol=1e-11)
+        else:
+            assert np.array_equal(x, y), f"array {i}"
+
+
+def test_longrow_kernel_against_the_oracle(demc, orc):
+    """teacher-forced against the oracle: sequential (reference) and two_colour schedules, history partners, blocks"""
+    prob = make_problem("hier_binomial", np.random.default_rng(92), S=2200)
+    D = prob["D"]
+    m0 = np.zeros(D, np.uint8)
+    m0[:2] = 1
+    teacher_forced(demc, orc, prob, n_iter=5, n_groups=2, Np=8, schedule=2, burnin=3, theta_snooker=0.25, kappa=0.9,
+                   masks=np.stack([m0, 1 - m0]), exact_de=False)
+    teacher_forced(demc, orc, prob, n_iter=4, n_groups=2, Np=6, schedule=0, burnin=2, theta_snooker=0.25, exact_de=False)
+    teacher_forced(demc, orc, prob, n_iter=4, n_initial=3, n_groups=2, Np=6, schedule=2, burnin=2, partner_kind=1, alpha=0.0,
+                   exact_de=False)
+
+
 def test_streaming_resident_form_with_blocks_and_trace(demc, orc):
     """the streaming-resident kernel under block updates, and teacher-forced against the oracle with the trace on"""
     prob = make_problem("mvn_full", np.random.default_rng(82), N=500, d=6)
