@@ -569,3 +569,127 @@ def test_geometry_groups_makes_shards_reproduce_the_unsharded_run():
     # without the pin the accept decisions still agree, the log-densities only to rounding
     loose = [run(G // 2, 0, 0), run(G // 2, G // 2, 0)]
     np.testing.assert_allclose(np.concatenate([h[4] for h in loose]), whole[4], rtol=1e-11)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Statistical gates of the race models (the reference's only multi-group, threaded, non-Gaussian test) and the BASELINE
+# cfg4 / cfg5 shapes at one GPU's full share
+# ---------------------------------------------------------------------------------------------------------------------
+def _oracle_sequential(orc):
+    def make(**cfg):
+        cfg = dict(cfg)
+        cfg["schedule"] = 0  # the reference's own sequential in-place sweep
+        cfg["n_threads"] = 8
+        return orc.Oracle(**{k: v for k, v in cfg.items() if k in orc.CFG_KEYS})
+    return make
+
+
+def test_lognormal_race_tests_jl(orc):
+    """test/lognormal_race_tests.jl:1-66: LNR(nu = [-2,-2,-3,-3], sigma = 1, tau = .5), 100 trials, nu ~ N(0,3), tau ~ U(0, min rt),
+    DE(burnin = 2000, Np = 24, n_groups = 4), 5000 iterations under MCMCThreads.  The reference compares mean and sd with NUTS at
+    rtol 0.05 (needs Turing); here the comparison chain is the CPU oracle running the reference's own schedule (sequential
+    sweep) on the same model -- a different engine, schedule and random stream -- at the same tolerance, plus rhat."""
+    rng = np.random.default_rng(9918)
+    nu, tau, N = np.array([-2.0, -2.0, -3.0, -3.0]), 0.5, 100
+    t = np.exp(rng.normal(nu, 1.0, (N, 4)))
+    choice, rt = t.argmin(1) + 1.0, t.min(1) + tau
+    min_rt = float(rt.min())
+
+    def run(factory, seed):
+        r2 = np.random.default_rng(seed)
+        sp = lambda: [r2.normal(0, 3, 4), r2.uniform(0, min_rt)]
+        model = D.DEModel(sample_prior=sp, prior_loglike=D.Priors(ν=D.Normal(0, 3), τ=D.Uniform(0.0, min_rt)),
+                          loglike=D.LNRLikelihood(sigma=1.0), data=(choice, rt), names=("ν", "τ"))
+        de = D.DE(sample_prior=sp, bounds=((-np.inf, np.inf), (0.0, min_rt)), burnin=2000, Np=24, n_groups=4)
+        return D.sample(model, de, D.MCMCThreads(), 5000, engine_factory=factory).describe()
+
+    gpu = run(None, 68541)
+    ref = run(_oracle_sequential(orc), 1234)
+    assert len(gpu) == 5 and set(gpu) == set(ref)
+    for nm in gpu:
+        assert abs(gpu[nm]["rhat"] - 1.0) < 0.05, (nm, gpu[nm])
+        assert abs(gpu[nm]["mean"] - ref[nm]["mean"]) <= 0.05 * abs(ref[nm]["mean"]) + 0.01, (nm, gpu[nm], ref[nm])
+        assert abs(gpu[nm]["std"] - ref[nm]["std"]) <= 0.08 * ref[nm]["std"], (nm, gpu[nm], ref[nm])
+    # and the posterior sits where the data were generated (wide tolerances: 100 trials)
+    for j in range(4):
+        assert abs(gpu[f"ν[{j + 1}]"]["mean"] - nu[j]) < 4 * gpu[f"ν[{j + 1}]"]["std"]
+
+
+def test_run_lba_jl_parameter_recovery(orc):
+    """Examples/Run_LBA.jl:6-47: LBA(nu = [3,2], A = .8, k = .2, tau = .3), 100 trials, the example's priors and bounds,
+    DE(burnin = 1500, n_groups = 3, Np = 15), 3000 iterations under MCMCThreads: the chain recovers the generating parameters
+    (each inside the chain's central mass) and agrees with the oracle's sequential-schedule chain on the same model"""
+    from demc_amd.workloads import simulate_lba
+    rng = np.random.default_rng(88484)
+    truth = dict(nu=(3.0, 2.0), A=0.8, k=0.2, tau=0.3)
+    choice, rt = simulate_lba(rng, 100, truth["nu"], truth["A"], truth["k"], truth["tau"])
+    min_rt = float(rt.min())
+
+    def run(factory, seed):
+        r2 = np.random.default_rng(seed)
+        sp = lambda: [np.abs(r2.normal(1, 5, 2)), abs(r2.normal(0.8, 0.2)), abs(r2.normal(0.2, 0.1)), r2.uniform(0, min_rt)]
+        model = D.DEModel(sample_prior=sp, loglike=D.LBALikelihood(), data=(choice, rt), names=("ν", "A", "k", "τ"),
+                          prior_loglike=D.Priors(ν=D.Normal(1, 5), A=D.Normal(0.8, 0.2), k=D.Normal(0.2, 0.1), τ=D.Uniform(0, min_rt)))
+        de = D.DE(sample_prior=sp, bounds=((0.0, np.inf), (0.0, np.inf), (0.0, np.inf), (0.0, min_rt)), burnin=1500, n_groups=3, Np=15)
+        return D.sample(model, de, D.MCMCThreads(), 3000, engine_factory=factory)
+
+    ch = run(None, 5)
+    d = ch.describe()
+    flat = dict(zip(["ν[1]", "ν[2]", "A", "k", "τ"], [3.0, 2.0, 0.8, 0.2, 0.3]))
+    for nm, tv in flat.items():
+        x = ch[nm].ravel()
+        lo, hi = np.quantile(x, [0.005, 0.995])
+        assert lo < tv < hi, (nm, tv, lo, hi)
+        assert abs(d[nm]["rhat"] - 1.0) < 0.1, (nm, d[nm])
+    assert d["ν[1]"]["mean"] > d["ν[2]"]["mean"]          # the faster accumulator is recovered as the faster one
+    ref = run(_oracle_sequential(orc), 77).describe()
+    for nm in flat:
+        assert abs(d[nm]["mean"] - ref[nm]["mean"]) <= 0.1 * abs(ref[nm]["mean"]) + 0.02, (nm, d[nm], ref[nm])
+        assert abs(d[nm]["std"] - ref[nm]["std"]) <= 0.2 * ref[nm]["std"] + 0.005, (nm, d[nm], ref[nm])
+
+
+def _full_share(name, orc, n_iter, spot_rows, rtol):
+    """one GPU's share of a BASELINE config at FULL size: size-independent properties + an oracle spot check"""
+    from demc_amd import workloads as W
+    w = W.BUILDERS[name]()
+    G, Np, Dd = w["G"], w["Np"], w["D"]
+    P = G * Np
+    eng = D.HipEngine(n_groups=G, Np=Np, D=Dd, n_rows=n_iter, schedule=2, seed=20260001, burnin=1000, trace=0, **w["engine"])
+    W.configure(eng, w)
+    th0 = w["init"](P, np.random.default_rng(3))
+    eng.set_state(th0)
+    _, w0, _ = eng.get_state()
+    assert np.isfinite(w0).all()
+    o = orc.Oracle(n_groups=1, Np=4, D=Dd, n_rows=0, store_history=0, n_threads=8, **w["engine"])
+    W.configure(o, w)
+    sub = np.linspace(0, P - 1, spot_rows).astype(int)
+    np.testing.assert_allclose(w0[sub], o.logpost(th0[sub]), rtol=rtol)       # initial evaluation vs the oracle
+    eng.step(1, n_iter)
+    th, wts, ids = eng.get_state()
+    assert np.array_equal(np.sort(ids), np.arange(P))                          # ids stay a permutation
+    fin = np.isfinite(wts)
+    assert fin.all()
+    np.testing.assert_allclose(eng.logpost(th[sub]), wts[sub], rtol=1e-10)     # stored weights re-evaluate to themselves
+    np.testing.assert_allclose(wts[sub], o.logpost(th[sub]), rtol=rtol)        # ... and to the oracle's value
+    hth, hacc, hlp, hid = eng.get_history(n_iter - 1, n_iter)
+    assert np.array_equal(hth[0], th) and np.array_equal(hid[0], ids) and np.array_equal(hlp[0], wts)
+    assert 0.02 < hacc.mean() < 0.98
+    lo, hi = np.asarray(w["lo"]), np.asarray(w["hi"])
+    assert ((th >= lo) & (th <= hi)).all()                                     # accepted rows are in bounds
+    eng.close()
+    o.close()
+    return wts.mean() - w0.mean()
+
+
+def test_cfg4_full_share_properties(orc):
+    """BASELINE cfg4 at one GPU's share: 16 groups x 32 particles, hierarchical Binomial with 1e4 subjects (D = 10 002),
+    two block sweeps [hyper ; subject] per iteration -- the long-row kernel at the size bench.py --config cfg4 runs"""
+    gain = _full_share("cfg4", orc, n_iter=6, spot_rows=6, rtol=1e-9)
+    assert gain > 0  # prior draws climb towards the posterior
+
+
+def test_cfg5_full_share_properties(orc):
+    """BASELINE cfg5 at one GPU's share: 64 groups x 128 particles, LBA with 3 accumulators, 5e4 trials simulated from
+    nu = (3,2,1), A = .8, k = .2, tau = .3, snooker 0.1 (the data bench.py --config cfg5 runs)"""
+    gain = _full_share("cfg5", orc, n_iter=4, spot_rows=8, rtol=1e-5)
+    assert gain > 0
