@@ -22,6 +22,14 @@ struct DemcConfig
     proposal_kind::Int32; partner_kind::Int32; update_kind::Int32; fitness_kind::Int32
     schedule::Int32; store_history::Int32; group_offset::Int32; n_groups_total::Int32
     seed::UInt64; device_id::Int32; loglike_mode::Int32; trace::Int32; fuse::Int32
+    geometry_groups::Int32; reserved0::Int32
+end
+
+# POD mirror of demc_replay (include/demc.h): caller-supplied draws (test mode).  C_NULL members = draw as usual.
+struct DemcReplay
+    u_step::Ptr{Float64}; u_group::Ptr{Float64}; u_part::Ptr{Float64}; partner::Ptr{Int64}
+    u_noise::Ptr{Float64}; z_noise::Ptr{Float64}; u_recomb::Ptr{Float64}
+    mig_groups::Ptr{Int32}; n_mig_groups::Int32; reserved::Int32; mig_particle::Ptr{Int64}
 end
 
 """
@@ -41,7 +49,7 @@ struct ModelSpec
 end
 
 struct HIPBackend
-    schedule::Symbol      # :two_colour (default) or :synchronous
+    schedule::Symbol      # :two_colour (default), :synchronous, or :sequential (the reference's own sweep; slow, for replay runs)
     loglike_mode::Symbol  # :streaming or :suffstat
     device_id::Int
     seed::UInt64
@@ -65,6 +73,37 @@ const FITNESS = IdDict(compute_posterior! => 0, evaluate_fun! => 1)
 
 flatten(Θ) = collect(Float64, Iterators.flatten(Θ))
 
+"top-level layout of a (possibly nested) Θ: for every parameter its shape (() for a scalar) and its offset in the flat row"
+function layout(Θ)
+    shapes = [θ isa AbstractArray ? size(θ) : () for θ in Θ]
+    lens = [θ isa AbstractArray ? length(θ) : 1 for θ in Θ]
+    offs = cumsum(vcat(0, lens))
+    return shapes, lens, offs
+end
+
+"one top-level element of Θ back from its slice of a flat row (utilities.jl:161-180 stores top-level elements)"
+unflatten(x::AbstractVector{Float64}, shape) = shape == () ? x[1] : reshape(collect(x), shape)
+
+"de.blocking_on(de) is asked on EVERY iteration with de.iter set (src/main.jl:34,137,162): (first iteration, count, on?) runs"
+function blocking_runs(de, n_iter)
+    saved = de.iter
+    flags = Bool[]
+    for it = 1:n_iter
+        de.iter = it + de.n_initial
+        push!(flags, de.blocking_on(de))
+    end
+    de.iter = saved
+    runs = Tuple{Int,Int,Bool}[]
+    for (i, f) in enumerate(flags)
+        if !isempty(runs) && runs[end][3] == f
+            runs[end] = (runs[end][1], runs[end][2] + 1, f)
+        else
+            push!(runs, (i, 1, f))
+        end
+    end
+    return runs
+end
+
 "flatten de.bounds (one tuple per top-level parameter, zip-truncated: utilities.jl:73-78) to per-scalar lo/hi"
 function flat_bounds(de, Θ)
     lo = Float64[]; hi = Float64[]
@@ -85,12 +124,13 @@ function sample(model::DEModel, de::DE, b::HIPBackend, n_iter::Int; model_spec::
     groups = sample_init(model, de, n_iter)                      # src/main.jl:263-271 (allocates de.samples)
     particles = vcat(groups...)
     P = length(particles); D = length(flatten(particles[1].Θ))
-    blocking = de.blocking_on(de)
+    shapes, lens, offs = layout(particles[1].Θ)
+    sched = b.schedule == :two_colour ? 2 : b.schedule == :synchronous ? 1 : 0
     cfg = DemcConfig(de.n_groups, de.Np, D, 0, de.burnin, de.n_initial, n_iter + de.n_initial,
         de.α, de.β, de.ϵ, de.σ, de.κ, de.θsnooker,
         hook_code(de.generate_proposal, PROPOSALS, "generate_proposal"), hook_code(de.sample, PARTNERS, "sample"),
         hook_code(de.update_particle!, UPDATES, "update_particle!"), hook_code(de.evaluate_fitness!, FITNESS, "evaluate_fitness!"),
-        b.schedule == :two_colour ? 2 : 1, 1, 0, de.n_groups, b.seed, b.device_id, b.loglike_mode == :streaming ? 0 : 1, 0, 0)
+        sched, 1, 0, de.n_groups, b.seed, b.device_id, b.loglike_mode == :streaming ? 0 : 1, 0, 0, 0, 0)
     href = Ref{Ptr{Cvoid}}(C_NULL)
     rc = @ccall LIB.demc_create(Ref(cfg)::Ptr{DemcConfig}, href::Ptr{Ptr{Cvoid}})::Int32
     h = href[]
@@ -105,10 +145,9 @@ function sample(model::DEModel, de::DE, b::HIPBackend, n_iter::Int; model_spec::
         end
         lo, hi = flat_bounds(de, particles[1].Θ)
         check(h, @ccall LIB.demc_set_bounds(h::Ptr{Cvoid}, lo::Ptr{Float64}, hi::Ptr{Float64})::Int32)
-        if blocking
-            masks = UInt8[x for blk in de.blocks for x in Iterators.flatten(blk)]   # nblocks x D, row-major
-            check(h, @ccall LIB.demc_set_blocks(h::Ptr{Cvoid}, masks::Ptr{UInt8}, Int32(length(de.blocks))::Int32)::Int32)
-        end
+        # de.blocks: one nested Bool array per block (src/structs.jl:45), flattened like Θ -> nblocks x D bytes, row-major
+        has_blocks = !isempty(de.blocks) && !(de.blocks[1] isa Bool)               # default is the placeholder [false]
+        masks = has_blocks ? UInt8[x for blk in de.blocks for x in Iterators.flatten(blk)] : UInt8[]
         if de.n_initial > 0   # initialize_samples (utilities.jl:35-39): rows 1:n_initial, [row][particle][D]
             rows = Float64[x for i = 1:de.n_initial for p = 1:P for x in Iterators.flatten(de.samples[i, :, p])]
             check(h, @ccall LIB.demc_set_history_rows(h::Ptr{Cvoid}, 0::Int64, Int64(de.n_initial)::Int64, rows::Ptr{Float64})::Int32)
@@ -117,18 +156,37 @@ function sample(model::DEModel, de::DE, b::HIPBackend, n_iter::Int; model_spec::
         weight = Float64[p.weight for p in particles]                      # evaluated by sample_init on the host
         ids = Int64[p.id - 1 for p in particles]                           # ids are 0-based across the ABI
         check(h, @ccall LIB.demc_set_state(h::Ptr{Cvoid}, theta::Ptr{Float64}, weight::Ptr{Float64}, ids::Ptr{Int64})::Int32)
-        # for iter in 1:n_iter: de.iter = iter + n_initial; groups = stepfun(model, de, groups)   (src/main.jl:33-38)
-        check(h, @ccall LIB.demc_step(h::Ptr{Cvoid}, Int64(1 + de.n_initial)::Int64, Int32(n_iter)::Int32)::Int32)
+        # for iter in 1:n_iter: de.iter = iter + n_initial; groups = stepfun(model, de, groups)   (src/main.jl:33-38).
+        # Whether a step is a block update is asked per iteration (main.jl:137,162): consecutive iterations with the same
+        # answer go to the device as one demc_step call, with the block masks switched on or off in between.
+        for (first, count, on) in blocking_runs(de, n_iter)
+            on && !has_blocks && error("blocking_on(de) is true but de.blocks holds no blocks")
+            nb = on ? length(de.blocks) : 0
+            check(h, @ccall LIB.demc_set_blocks(h::Ptr{Cvoid}, masks::Ptr{UInt8}, Int32(nb)::Int32)::Int32)
+            check(h, @ccall LIB.demc_step(h::Ptr{Cvoid}, Int64(first + de.n_initial)::Int64, Int32(count)::Int32)::Int32)
+        end
         de.iter = n_iter + de.n_initial
         n_rows = n_iter + de.n_initial
         # bundle_samples' gather (src/main.jl:232-241) on the device: layout 0 IS Array{Float64,3}(n_rows, D+2, P) in
         # Julia's column-major order, already keyed by particle id (parameters, then "acceptance", then "lp")
         v = Array{Float64,3}(undef, n_rows, D + 2, P)
         check(h, @ccall LIB.demc_export_chains(h::Ptr{Cvoid}, 0::Int64, Int64(n_rows)::Int64, 0::Int32, v::Ptr{Float64})::Int32)
+        # de.samples[row, k, id] holds the k-th TOP-LEVEL element of Θ (utilities.jl:161-180): a scalar, or the array rebuilt
+        # from its slice of the flat row (test/multivariate_normal_tests.jl:19 uses Θ = [μ::Vector, σ])
         for id = 1:P
-            de.samples[:, :, id] = v[:, 1:D, id]          # flat parameters; un-flatten here for nested Θ
+            for k in eachindex(shapes), row = 1:n_rows
+                de.samples[row, k, id] = unflatten(view(v, row, offs[k]+1:offs[k]+lens[k], id), shapes[k])
+            end
             particles[id].accept .= v[:, D + 1, id] .!= 0
             particles[id].lp .= v[:, D + 2, id]
+        end
+        # final state of the particle objects (bundle_samples reads accept/lp from them; Θ for completeness)
+        th = Vector{Float64}(undef, P * D); wt = Vector{Float64}(undef, P); idv = Vector{Int64}(undef, P)
+        check(h, @ccall LIB.demc_get_state(h::Ptr{Cvoid}, th::Ptr{Float64}, wt::Ptr{Float64}, idv::Ptr{Int64})::Int32)
+        for s = 1:P
+            p = particles[idv[s] + 1]
+            p.Θ = [unflatten(view(th, (s - 1) * D + offs[k] + 1:(s - 1) * D + offs[k] + lens[k]), shapes[k]) for k in eachindex(shapes)]
+            p.weight = wt[s]
         end
     finally
         h != C_NULL && @ccall LIB.demc_destroy(h::Ptr{Cvoid})::Int32
@@ -160,5 +218,31 @@ function host_migration!(h, de::DE, P::Int)  # P = de.n_groups * de.Np
     return nothing
 end
 # driver loop for that mode: `rand() <= de.α && host_migration!(h, de, P); demc_update(h, iter, 1)` per iteration
+
+"""
+    set_replay!(h; u_step, u_group, u_part, partner, u_noise, z_noise, u_recomb, mig_groups, mig_particle)
+
+Test mode (`demc_set_replay`, include/demc.h): feed draws taken from Julia's own RNG -- in the order of SURVEY.md Appendix A --
+in place of the library's addressed Philox draws, for one step at a time, e.g. with `HIPBackend(schedule = :sequential)` to
+follow `crossover!`'s in-place sweep exactly.  Arrays use the C layouts of demc.h (`u_part`: 5 x P column-major = [P][5]
+row-major, `partner`: 3 x P, the per-scalar tables D x P); partner rows are 0-based positions inside the group.  Any argument
+left `nothing` is drawn as usual; `set_replay!(h)` with no arguments switches the mode off.
+"""
+function set_replay!(h; u_step = nothing, u_group = nothing, u_part = nothing, partner = nothing, u_noise = nothing,
+                     z_noise = nothing, u_recomb = nothing, mig_groups = nothing, mig_particle = nothing)
+    args = (u_step, u_group, u_part, partner, u_noise, z_noise, u_recomb, mig_groups, mig_particle)
+    if all(isnothing, args)
+        check(h, @ccall LIB.demc_set_replay(h::Ptr{Cvoid}, C_NULL::Ptr{DemcReplay})::Int32)
+        return nothing
+    end
+    ptr(x, T) = x === nothing ? Ptr{T}(C_NULL) : pointer(x)
+    GC.@preserve u_step u_group u_part partner u_noise z_noise u_recomb mig_groups mig_particle begin
+        r = DemcReplay(ptr(u_step, Float64), ptr(u_group, Float64), ptr(u_part, Float64), ptr(partner, Int64),
+                       ptr(u_noise, Float64), ptr(z_noise, Float64), ptr(u_recomb, Float64), ptr(mig_groups, Int32),
+                       mig_groups === nothing ? Int32(0) : Int32(length(mig_groups)), Int32(0), ptr(mig_particle, Int64))
+        check(h, @ccall LIB.demc_set_replay(h::Ptr{Cvoid}, Ref(r)::Ptr{DemcReplay})::Int32)
+    end
+    return nothing
+end
 
 end # module

@@ -357,6 +357,9 @@ def test_plain_c_caller_of_the_abi(tmp_path):
     out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "C-ABI driver OK" in out.stdout
+    # second scenario: the call sequence of julia/DEMCHIP.jl's sample() for nested Theta with per-iteration blocking_on
+    # (set_blocks / demc_step per run, layout-0 export checked element by element against the raw history)
+    assert "nested/blocked sequence: 600 step calls, export mismatches 0" in out.stdout
 
 
 def test_handles_of_different_sizes_coexist():
