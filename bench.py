@@ -108,24 +108,24 @@ def describe(a, w, world):
             f"n_groups={G}x{world} (BASELINE: 512 groups over 8 GPUs), Np={Np}, snooker 0.1, schedule={a.schedule}")
 
 
-def measured_traffic(a, w, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/<round>/bench_<config>_<mode>_pmc.json: FETCH_SIZE and WRITE_SIZE in KB, separate --pmc passes).  On gfx950
-    FETCH_SIZE counts half the bytes of wide streaming reads (MI355X_MICROARCH.md, HBM section), hence the factor 2.
-    Only for the config's default shape; otherwise None.  NOT measured in the run that prints it."""
-    from demc_amd import workloads as W
-    ref = W.BUILDERS[a.config].__defaults__
-    if a.n_groups is not None or a.Np is not None or a.nobs is not None or a.dim is not None or a.schedule != "two_colour":
+def measured_traffic(a, launches, k_iters):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/<round>/bench_<config>_<mode>_pmc.json, written by tools/collect_profiles.py: FETCH_SIZE and WRITE_SIZE in
+    separate --pmc passes; FETCH_SIZE doubled -- on gfx950 it counts half the bytes of wide streaming reads,
+    MI355X_MICROARCH.md, HBM section).  Resident kernels are recorded per iteration and scaled to this run's launches.
+    Only for the config's default shape; otherwise None.  NOT measured in the run that prints it (see traffic_source)."""
+    if a.n_groups is not None or a.Np is not None or a.nobs is not None or a.dim is not None or a.schedule != "two_colour" or a.fuse:
         return None, None
-    for rnd in (PROFILE_ROUND, "r01"):
+    for rnd in (PROFILE_ROUND,):
         path = os.path.join(ROOT, "profiles", rnd, f"bench_{a.config}_{a.mode}_pmc.json")
         try:
-            rec = json.load(open(path))[kernel]
+            rec = json.load(open(path))["dominant"]
         except (OSError, KeyError, ValueError):
             continue
-        if "bytes" in rec:  # already reduced by tools/collect_profiles.py (e.g. per iteration for a resident kernel)
-            return float(rec["bytes"]), f"profiles/{rnd}/" + os.path.basename(path)
-        return (2.0 * rec["FETCH_SIZE_KB_mean"] + rec["WRITE_SIZE_KB_mean"]) * 1024.0, f"profiles/{rnd}/" + os.path.basename(path)
+        src = f"profiles/{rnd}/{os.path.basename(path)} (rocprofv3 --pmc passes of this command, not this run)"
+        if "bytes_per_launch" in rec:
+            return float(rec["bytes_per_launch"]), src
+        return float(rec["bytes_per_iteration"]) * k_iters / max(1, launches), src
     return None, None
 
 
@@ -149,8 +149,9 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
             ach = executed / t_s / 1e12
             kern = ("k_propose<...,RES> with the observation stream inside (v_mfma_f64_16x16x4_f64)" if streamed_in_k1
                     else f"k_cross_mfma<{max(1, 1 << max(0, (max(1, (d + 3) // 4) - 1).bit_length())) if d <= 64 else 16},4> (v_mfma_f64_16x16x4_f64)")
-            traffic, src = measured_traffic(a, w, "streaming_kernel")
-            alg_bytes = 8.0 * N * d + P / phases * 8.0 * d  # operands of one launch: X once + the proposals' y rows
+            traffic, src = measured_traffic(a, n_launch, k_iters)
+            # operands of one launch: X once per colour phase + the proposals' y rows
+            alg_bytes = (8.0 * N * d * phases + P * 8.0 * d) * k_iters / n_launch
             rf = dict(bound="mfma", kernel=kern, achieved=ach, peak=PEAK_FP64_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP64_TFLOPS,
                       flop_counted="executed 2*N*D per particle-update (every proposal x observation pair on the matrix cores)",
                       survey_equivalent_tflops=survey / t_s / 1e12,
@@ -163,27 +164,27 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
             n_launch = max(1, tm["propose"]["launches"])
             byts = (24.0 * D + 17.0) * P * k_iters
             ach = byts / t_s / 1e9
-            traffic, src = measured_traffic(a, w, "k_propose_fused_per_iteration")
+            traffic, src = measured_traffic(a, n_launch, k_iters)
             rf = dict(bound="hbm", kernel="k_propose with the fused prep/accept/store tail" +
                       (", resident form (one launch per run of iterations between migrations)" if n_launch < phases * k_iters else ""),
                       achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
                       bytes_counted="24*D+17 per particle-update (SURVEY 8d)", launch_ms=t_s / n_launch * 1e3, launches=n_launch,
                       updates_per_launch=P * k_iters / n_launch,
-                      traffic=None if traffic is None else traffic * k_iters / n_launch, traffic_source=src,
-                      wasted_traffic_ratio=None if traffic is None else traffic / ((24.0 * D + 17.0) * P))
+                      traffic=traffic, traffic_source=src,
+                      wasted_traffic_ratio=None if traffic is None else traffic / (byts / n_launch))
     elif a.config == "cfg4":
         S = w["dims"][0]
         t_s = (fused_ms + tm["loglike"]["ms"]) * 1e-3
         n_launch = max(1, tm["propose"]["launches"])
         byts = sweeps * (24.0 * D + 17.0 + 16.0 * S) * P * k_iters
         ach = byts / t_s / 1e9
-        traffic, src = measured_traffic(a, w, "k_propose_per_iteration")
-        rf = dict(bound="hbm", kernel="k_propose<512,...,TAIL_OBS> (a workgroup per particle; subject terms, accept and store fused)",
+        traffic, src = measured_traffic(a, n_launch, k_iters)
+        rf = dict(bound="hbm", kernel="k_longrow<512> (a workgroup per particle, one pass: proposal, prior, subject terms, accept, store)",
                   achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
                   bytes_counted=f"{sweeps} block sweeps x (24*D+17 + 16*S) per particle-update and iteration (SURVEY 8d)",
                   launch_ms=t_s / n_launch * 1e3, launches=n_launch, updates_per_launch=sweeps * P * k_iters / n_launch,
-                  traffic=None if traffic is None else traffic * k_iters / n_launch, traffic_source=src,
-                  wasted_traffic_ratio=None if traffic is None else traffic / (byts / k_iters))
+                  traffic=traffic, traffic_source=src,
+                  wasted_traffic_ratio=None if traffic is None else traffic / (byts / n_launch))
     else:  # cfg5
         N, na = w["dims"]
         t_s = tm["loglike"]["ms"] * 1e-3

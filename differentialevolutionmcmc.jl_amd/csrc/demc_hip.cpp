@@ -86,6 +86,7 @@ struct demc_handle {
     unsigned long long* st_gran = nullptr;  // hand-over granules (device)
     unsigned* st_err = nullptr;             // time-out flag (host-mapped, zero-copy)
     int n_cus = 0;
+    int ainv_lds = 1;
     std::string err;
     // replay (demc_set_replay): device copies of the caller's draws
     double *rp_group = nullptr, *rp_part = nullptr, *rp_noise = nullptr, *rp_znoise = nullptr, *rp_recomb = nullptr;
@@ -221,7 +222,7 @@ KParams base_params(demc_handle* h) {
     k.fitness_kind = c.fitness_kind;
     k.theta = h->theta; k.weight = h->weight; k.id = h->id; k.prop = h->prop; k.prop_prior = h->prop_prior;
     k.prop_adj = h->prop_adj; k.prop_oob = h->prop_oob; k.tr_idx = h->tr_idx; k.tr_w = h->tr_w; k.tr_acc = h->tr_acc;
-    k.dimtab = h->dimtab; k.dimseg = h->dimseg; k.n_seg = h->n_seg; k.mask = nullptr;
+    k.dimtab = h->dimtab; k.dimseg = h->dimseg; k.n_seg = h->n_seg; k.ainv_lds = h->ainv_lds; k.mask = nullptr;
     k.hist = h->hist; k.acc_hist = h->acc_hist; k.lp_hist = h->lp_hist; k.id_hist = h->id_hist;
     k.P = h->P; k.store_row = -1; k.tile_in_lds = h->tile_in_lds;
     k.family = h->family; k.N = h->N; k.d = h->d; k.n_acc = h->n_acc; k.n_partials = 1;
@@ -500,7 +501,7 @@ void plan_resident(demc_handle* h) {
         if (!k.fuse_accept) return false;
         scr_doubles = (k.fuse_prep || k.fuse_obs) ? (size_t)(wg / lpp) * (D + 2) : 0;
         const size_t doubles =
-            Np * D + Np + (Np + (Np + 15) / 16) + (h->family == FAM_MVN_FULL ? d * d : 0) + (mvn ? d : 0) + scr_doubles;
+            Np * D + Np + (Np + (Np + 15) / 16) + ((h->family == FAM_MVN_FULL && h->ainv_lds) ? d * d : 0) + (mvn ? d : 0) + scr_doubles;
         bytes = doubles * sizeof(double) + (size_t)n_act * (4 * sizeof(double) + 4 * sizeof(int));
         return bytes <= kMaxDynLds;
     };
@@ -571,7 +572,7 @@ void plan_stream(demc_handle* h) {
     const int chunk = (h->n_tiles + C - 1) / C;
     const size_t D = (size_t)c.D, Np = (size_t)c.Np, d = (size_t)h->d;
     const size_t scr_doubles = (size_t)rows * (D + 6);
-    const size_t doubles = Np * D + Np + (Np + (Np + 15) / 16) + (h->family == FAM_MVN_FULL ? d * d : 0) + d + scr_doubles +
+    const size_t doubles = Np * D + Np + (Np + (Np + 15) / 16) + ((h->family == FAM_MVN_FULL && h->ainv_lds) ? d * d : 0) + d + scr_doubles +
                            (size_t)rows * h->dpad + (size_t)(wg / 64) * nact_max;
     size_t bytes = doubles * sizeof(double) + (size_t)nact_max * (4 * sizeof(double) + 4 * sizeof(int)) +
                    2 * sizeof(unsigned) * (size_t)C * nact_max + 16;
@@ -673,7 +674,9 @@ int size_k1_lds(demc_handle* h) {
     const demc_config& c = h->c;
     const size_t D = (size_t)c.D;
     const size_t cdf = ((size_t)c.Np + ((size_t)c.Np + 15) / 16) * sizeof(double);
-    const size_t ainv = (h->family == FAM_MVN_FULL) ? (size_t)h->d * h->d * sizeof(double) : 0;
+    size_t ainv = (h->family == FAM_MVN_FULL) ? (size_t)h->d * h->d * sizeof(double) : 0;
+    h->ainv_lds = ainv <= 40 * 1024 ? 1 : 0;  // d <= 71: beside the tile; wider data read A^-1 from L2
+    if (!h->ainv_lds) ainv = 0;
     const size_t xb = is_mvn(h->family) ? (size_t)h->d * sizeof(double) : 0;
     const size_t scr_rows = (size_t)(h->lpp >= 256 ? 1 : 256 / h->lpp) * (D + 2) * sizeof(double);
     const bool hier = h->family == FAM_HIER_BINOMIAL || h->family == FAM_HIER_GAUSSIAN;
@@ -968,7 +971,7 @@ int32_t demc_set_model(demc_handle* h, int32_t family, const double* data, const
             const long long N = dm[0];
             const int d = (int)dm[1];
             if (N < 1 || d < 1) return fail(h, DEMC_EINVAL, "MVN: dims=[N,d]");
-            if (d > 64) return fail(h, DEMC_EUNSUPPORTED, "MVN families: data dimension d <= 64");
+            if (d > 1024) return fail(h, DEMC_EUNSUPPORTED, "MVN families: data dimension d <= 1024");
             if (family == DEMC_FAM_MVN_ISO && D != d + 1) return fail(h, DEMC_EINVAL, "MVN_ISO: D=d+1");
             if (family == DEMC_FAM_MVN_FULL && (D != d || nhyper != d * d)) return fail(h, DEMC_EINVAL, "MVN_FULL: D=d, hyper=Sigma[d][d]");
             h->N = N;

@@ -78,6 +78,7 @@ struct KParams {
     const DimTab* dimtab;       // [D] bounds + prior of every scalar, packed
     const DimSeg* dimseg;       // [n_seg] the same table run-length encoded (n_seg = 0: too many segments, use dimtab)
     int n_seg;
+    int ainv_lds;               // K1: A^-1 [d][d] is staged in LDS (else read from L2: wide data)
     const unsigned char* mask;  // [D] or null
     // history (slot keyed)
     double* hist;             // [rows][P][D]
@@ -673,7 +674,9 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
     const int ppp = WG / lpp;  // particles per pass
     const int wave = tid >> 6, lane = tid & 63;
     const int dd = d * d;
-    const bool ld_ainv = FUSE_PREP && p.Ainv;
+    // A^-1 is staged in LDS when it fits next to everything else (host: p.ainv_lds); for wide data (d in the hundreds) the
+    // preparation reads it from L2 instead
+    const bool ld_ainv = FUSE_PREP && p.Ainv && p.ainv_lds;
     // LDS carve-up (host computes the same sizes): tile | weights (RES) | cdf + chunk totals | A^-1 | theta' scratch | plan
     const int plan_cap = RES ? Np - Np / 2 : (p.n_act + p.n_split - 1) / p.n_split;  // particles a workgroup moves per phase
     double* tile = lds;
@@ -1424,16 +1427,17 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
             for (int k = sl; 2 * k < d; k += lpp) {
                 const int c0 = 2 * k, c1 = 2 * k + 1;
                 double y0 = 0.0, y1 = 0.0;
+                const double* ainv_g = ld_ainv ? (const double*)ainv_s : p.Ainv;
                 if (p.Ainv) {
                     if (c1 < d) {
 #pragma unroll 4
                         for (int j = 0; j < d; ++j) {
                             const double t = th[j] - xb_s[j];
-                            y0 = fma(ainv_s[j * d + c0], t, y0);  // A^-1 is symmetric: column c == row c
-                            y1 = fma(ainv_s[j * d + c1], t, y1);
+                            y0 = fma(ainv_g[j * d + c0], t, y0);  // A^-1 is symmetric: column c == row c
+                            y1 = fma(ainv_g[j * d + c1], t, y1);
                         }
                     } else
-                        for (int j = 0; j < d; ++j) y0 = fma(ainv_s[j * d + c0], th[j] - xb_s[j], y0);
+                        for (int j = 0; j < d; ++j) y0 = fma(ainv_g[j * d + c0], th[j] - xb_s[j], y0);
                 } else {
                     y0 = th[c0] - xb_s[c0];
                     if (c1 < d) y1 = th[c1] - xb_s[c1];

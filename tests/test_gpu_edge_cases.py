@@ -11,7 +11,7 @@ from test_gpu_parity import teacher_forced
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("N,d", [(5, 1), (17, 3), (100, 4), (333, 7), (64, 33), (50, 64)])
+@pytest.mark.parametrize("N,d", [(5, 1), (17, 3), (100, 4), (333, 7), (64, 33), (50, 64), (40, 65), (90, 100), (70, 130), (33, 200)])
 def test_mvn_full_ragged_shapes(demc, orc, N, d):
     prob = make_problem("mvn_full", np.random.default_rng(100 + d), N=N, d=d)
     teacher_forced(demc, orc, prob, n_iter=4, n_groups=3, Np=9, schedule=2, burnin=2, check_hist=False)

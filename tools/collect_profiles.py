@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
-"""Collects the rocprofv3 evidence behind bench.py's `roofline` object and DESIGN.md section 6, on the GPU box:
+"""Collects the rocprofv3 evidence behind bench.py's `roofline` objects and DESIGN.md section 6, on the GPU box:
 
-    python3 tools/collect_profiles.py gpurun_out/profiles_rNN          # then copy the summaries into profiles/rNN/
+    python3 tools/collect_profiles.py gpurun_out/profiles_rNN [combo ...]     # then copy the summaries into profiles/rNN/
 
-For each mode (streaming = default bench, suffstat) it runs `python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline`
-under `rocprofv3 --kernel-trace --stats` (kernel_stats csv), then twice more under `--kernel-trace --pmc FETCH_SIZE` and
-`--pmc WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md prescribes; FETCH_SIZE is doubled by the readers of the
-json, see bench.py), and for streaming once more with the matrix-pipe counters.  Each program is started directly
-after `--` (no shell / env hop).  The fused K1 in its resident form covers a varying number of iterations per launch,
-so its traffic is also reduced to bytes per ITERATION: all of its launches together span warmup + steps + the bench's
-20 roofline iterations."""
+A combo is config:mode (default: every bench row -- cfg3:streaming cfg3:suffstat cfg2:streaming cfg4:streaming cfg5:streaming).
+For each it runs `python3 bench.py --config C --mode M --steps 20 --warmup 5 --no-cpu-baseline --accuracy-iters 0`
+  * under `rocprofv3 --kernel-trace --stats`                       -> bench_<C>_<M>_kernel_stats.csv and the bench line of that run,
+  * under `--kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`  (separate passes, as MI355X_MICROARCH.md prescribes; FETCH_SIZE
+    is doubled by the readers of the json: gfx950 counts half the bytes of wide streaming reads)   -> bench_<C>_<M>_pmc.json,
+  * and once more with the pipe counters of the dominant kernel (matrix pipe for the MvNormal stream, VALU otherwise)
+                                                                    -> bench_<C>_<M>_pipe_pmc.json.
+Each program is started directly after `--` (no shell / env hop).  `dominant` in the pmc json names the kernel bench.py's
+roofline is about and its HBM bytes per launch, or per ITERATION for the resident kernels (one launch covers a varying number
+of iterations: all launches of the run together span warmup + steps iterations)."""
 import csv
 import glob
 import json
@@ -20,7 +23,13 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STEPS, WARMUP, ROOFLINE_ITERS = 20, 5, 20
+STEPS, WARMUP = 20, 5
+DOMINANT = {("cfg3", "streaming"): "k_cross_mfma", ("cfg3", "suffstat"): "k_propose<", ("cfg2", "streaming"): "k_propose<",
+            ("cfg4", "streaming"): "k_longrow", ("cfg5", "streaming"): "k_obs_loglike"}
+MFMA_CTRS = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_F64", "SQ_INSTS_VALU_MFMA_MOPS_F64", "GRBM_GUI_ACTIVE",
+             "SQ_WAVE_CYCLES", "SQ_INSTS_VALU"]
+VALU_CTRS = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS",
+             "GRBM_GUI_ACTIVE"]
 
 
 def run(out_dir, tag, prof_args, bench_args):
@@ -31,10 +40,11 @@ def run(out_dir, tag, prof_args, bench_args):
     env = dict(os.environ, TMPDIR="/tmp")
     with open(os.path.join(out_dir, tag + ".log"), "w") as log:
         subprocess.run(cmd, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, check=True, timeout=600)
+    print("  pass", tag, "done", flush=True)
     return d
 
 
-def counters(d, skip=2):
+def counters(d):
     """kernel -> counter -> list of per-dispatch values (instances summed), in dispatch order"""
     vals = defaultdict(lambda: defaultdict(list))
     grid = {}
@@ -56,18 +66,35 @@ def short(name):
     return name.replace("void ", "").split("(")[0]
 
 
+def dominant_kernel(names, pat, resident):
+    """the kernel of the run that matches the pattern: for k_propose, the resident / streaming-resident instance (its 4th
+    template argument `true`) -- the initial evaluation runs in a non-resident instance and is not the roofline's subject"""
+    cand = [n for n in names if pat in n]
+    if pat == "k_propose<" and resident:
+        res = [n for n in cand if len(n.split(",")) >= 4 and n.split(",")[3].strip().startswith("true")]
+        cand = res or cand
+    return max(cand, key=lambda n: names[n]) if cand else None
+
+
 def main():
     out_dir = os.path.abspath(sys.argv[1])
     os.makedirs(out_dir, exist_ok=True)
-    base = ["--steps", str(STEPS), "--warmup", str(WARMUP), "--no-cpu-baseline"]
-    for mode in ("streaming", "suffstat"):
-        args = base + (["--mode", "suffstat"] if mode == "suffstat" else [])
-        d = run(out_dir, f"{mode}_stats", ["--stats"], args)
+    combos = [tuple(c.split(":")) for c in sys.argv[2:]] or list(DOMINANT)
+    for cfg, mode in combos:
+        print(f"{cfg} {mode}", flush=True)
+        tag = f"{cfg}_{mode}"
+        args = ["--config", cfg, "--mode", mode, "--steps", str(STEPS), "--warmup", str(WARMUP), "--no-cpu-baseline",
+                "--accuracy-iters", "0"]
+        d = run(out_dir, f"{tag}_stats", ["--stats"], args)
         for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
-            shutil.copy(f, os.path.join(out_dir, f"bench_cfg3_{mode}_kernel_stats.csv"))
-        res = {}
+            shutil.copy(f, os.path.join(out_dir, f"bench_{tag}_kernel_stats.csv"))
+        with open(os.path.join(out_dir, f"{tag}_stats.log")) as fh:
+            lines = [ln for ln in fh if ln.startswith("{\"metric\"")]
+        if lines:
+            open(os.path.join(out_dir, f"bench_{tag}_line.json"), "w").write(lines[-1])
+        res, totals = {}, defaultdict(float)
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            vals, grid = counters(run(out_dir, f"{mode}_{ctr}", ["--pmc", ctr], args))
+            vals, grid = counters(run(out_dir, f"{tag}_{ctr}", ["--pmc", ctr], args))
             for kname, cs in vals.items():
                 v = cs[ctr]
                 e = res.setdefault(short(kname), {"grid_size": grid[kname]})
@@ -75,36 +102,43 @@ def main():
                 e[ctr + "_KB_mean"] = sum(use) / len(use)
                 e["launches_" + ctr] = len(use)
                 e[ctr + "_KB_total"] = sum(v)
-        # fused K1 (resident or per-phase): HBM bytes per iteration over the whole run
-        fused = [k for k in res if "k_propose" in k and res[k].get("launches_FETCH_SIZE", 0) >= 1 and "false" not in k.split(",")[1]]
-        if mode == "suffstat" and fused:
-            n_it = STEPS + WARMUP + ROOFLINE_ITERS
-            tot = sum(2.0 * res[k]["FETCH_SIZE_KB_total"] + res[k]["WRITE_SIZE_KB_total"] for k in fused) * 1024.0
-            res["k_propose_fused_per_iteration"] = {"bytes": tot / n_it, "iterations": n_it, "kernels": fused,
-                                                    "note": "2 x FETCH_SIZE + WRITE_SIZE summed over every launch / iterations"}
-        json.dump(res, open(os.path.join(out_dir, f"bench_cfg3_{mode}_pmc.json"), "w"), indent=1)
-        if mode == "streaming":
-            ctrs = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_F64", "SQ_INSTS_VALU_MFMA_MOPS_F64",
-                    "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU"]
-            vals, grid = counters(run(out_dir, "streaming_mfma", ["--pmc"] + ctrs, args))
-            m = {}
-            for kname, cs in vals.items():
-                if "k_cross_mfma" not in kname:
-                    continue
-                e = m.setdefault(short(kname), {"grid_size": grid[kname]})
-                for c, v in cs.items():
-                    use = v[2:] if len(v) > 2 else v
-                    e[c + "_mean"] = sum(use) / len(use)
-                    e["launches"] = len(use)
-                if "SQ_VALU_MFMA_BUSY_CYCLES_mean" in e and "GRBM_GUI_ACTIVE_mean" in e:
-                    # GRBM_GUI_ACTIVE sums 8 XCD instances; 1024 SIMDs (256 CUs x 4)
-                    e["mfma_busy_frac"] = e["SQ_VALU_MFMA_BUSY_CYCLES_mean"] / (e["GRBM_GUI_ACTIVE_mean"] / 8.0 * 1024.0)
-            json.dump(m, open(os.path.join(out_dir, "bench_cfg3_streaming_mfma_pmc.json"), "w"), indent=1)
-        # the bench line of the --stats run, for cross-checking launch_ms against the csv
-        with open(os.path.join(out_dir, f"{mode}_stats.log")) as fh:
-            lines = [ln for ln in fh if ln.startswith("{\"metric\"")]
-        if lines:
-            open(os.path.join(out_dir, f"bench_cfg3_{mode}_line.json"), "w").write(lines[-1])
+                e["launches_total"] = len(v)
+                totals[short(kname)] += (2.0 if ctr == "FETCH_SIZE" else 1.0) * sum(v) * 1024.0
+        dom = dominant_kernel(totals, DOMINANT[(cfg, mode)], resident=True)
+        if dom:
+            e = res[dom]
+            resident = DOMINANT[(cfg, mode)] == "k_propose<"
+            rec = {"kernel": dom, "note": "HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 half-count of wide streaming reads)"}
+            if resident:  # a launch covers several iterations: reduce to bytes per iteration over the whole run
+                rec["bytes_per_iteration"] = totals[dom] / (STEPS + WARMUP)
+                rec["iterations"] = STEPS + WARMUP
+            else:
+                rec["bytes_per_launch"] = (2.0 * e["FETCH_SIZE_KB_mean"] + e["WRITE_SIZE_KB_mean"]) * 1024.0
+            rec["launches"] = e["launches_total"]
+            res["dominant"] = rec
+        json.dump(res, open(os.path.join(out_dir, f"bench_{tag}_pmc.json"), "w"), indent=1)
+        # pipe counters of the dominant kernel
+        mfma = (cfg in ("cfg2", "cfg3")) and mode == "streaming"
+        ctrs = MFMA_CTRS if mfma else VALU_CTRS
+        vals, grid = counters(run(out_dir, f"{tag}_pipe", ["--pmc"] + ctrs, args))
+        m = {}
+        for kname, cs in vals.items():
+            if "demc" not in kname:
+                continue
+            e = m.setdefault(short(kname), {"grid_size": grid[kname]})
+            for c, v in cs.items():
+                use = v[2:] if len(v) > 2 else v
+                e[c + "_mean"] = sum(use) / len(use)
+                e["launches"] = len(use)
+            if "SQ_VALU_MFMA_BUSY_CYCLES_mean" in e and e.get("GRBM_GUI_ACTIVE_mean", 0) > 0:
+                # GRBM_GUI_ACTIVE sums 8 XCD instances; 1024 SIMDs (256 CUs x 4)
+                e["mfma_busy_frac"] = e["SQ_VALU_MFMA_BUSY_CYCLES_mean"] / (e["GRBM_GUI_ACTIVE_mean"] / 8.0 * 1024.0)
+            if "SQ_ACTIVE_INST_VALU_mean" in e and e.get("GRBM_GUI_ACTIVE_mean", 0) > 0:
+                # SQ_ACTIVE_INST_VALU: cycles (x4) a SIMD spent issuing VALU work, summed over the chip
+                e["valu_busy_frac"] = 4.0 * e["SQ_ACTIVE_INST_VALU_mean"] / (e["GRBM_GUI_ACTIVE_mean"] / 8.0 * 1024.0)
+            if "SQ_INSTS_VALU_mean" in e and e.get("SQ_WAVES_mean", 0) > 0:
+                e["valu_insts_per_wave"] = e["SQ_INSTS_VALU_mean"] / e["SQ_WAVES_mean"]
+        json.dump(m, open(os.path.join(out_dir, f"bench_{tag}_pipe_pmc.json"), "w"), indent=1)
     print("summaries in", out_dir)
 
 
