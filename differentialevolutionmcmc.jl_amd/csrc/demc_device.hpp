@@ -62,6 +62,10 @@ __host__ __device__ inline double u53(uint32_t lo, uint32_t hi) {
     const uint64_t x = ((uint64_t)hi << 32) | lo;
     return (double)(x >> 11) * (1.0 / 9007199254740992.0);
 }
+// 32-bit uniform in (0,1) from ONE word: the per-scalar draws (crossover noise b ~ U(-eps, eps), recombination coins, the
+// Box-Muller inputs of the mutation noise) -- four scalars per Philox block: block m of the NOISE / RECOMB streams covers
+// scalars 4m..4m+3 (word 2(k&1)+e for scalar e of dim pair k).  2^-32 resolution is ample for a jitter of scale eps.
+__host__ __device__ inline double u32unit(uint32_t w) { return ((double)w + 0.5) * (1.0 / 4294967296.0); }
 __host__ __device__ inline uint32_t mulhi32(uint32_t x, uint32_t m) { return (uint32_t)(((uint64_t)x * m) >> 32); }
 __device__ inline uint64_t mulhi64(uint64_t x, uint64_t m) { return __umul64hi(x, m); }
 

@@ -490,6 +490,43 @@ __device__ inline double wave_max(double v) {
     return fmax(fmax(r[0], r[1]), fmax(r[2], r[3]));
 }
 
+// Cumulative weights of up to 64 R values held one per lane and register (index = lane + 64 r; entries beyond n must be
+// 0.0), in place, in the FIXED two-level order the oracle uses (select_base_stable / select_particle_stable): a
+// sequential left-to-right prefix inside chunks of 16, a sequential prefix over the chunk totals, cdf[i] = offset[chunk] +
+// prefix[i].  A chunk is one DPP row: fifteen rounds of p = row_shr:1(p) + e leave ((e0 + e1) + e2) + ... in every lane
+// (lane k is final after round k and is recomputed to the same value afterwards); the chunk totals travel through
+// v_readlane.  No LDS round trips -- the LDS form of the same sums cost five dependent LDS passes.
+template <int R>
+__device__ inline void wave_cdf(double (&e)[R], int n) {
+    const int lane = threadIdx.x & 63;
+    double pre[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) pre[r] = e[r];
+    for (int s = 0; s < 15; ++s)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double sh = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(pre[r]), 0x111, 0xf, 0xf, true),
+                                               __builtin_amdgcn_update_dpp(0, __double2loint(pre[r]), 0x111, 0xf, 0xf, true));
+            pre[r] = sh + e[r];  // row_shr:1 feeds +0.0 into lane 0 of the row
+        }
+    double off = 0.0, offv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        offv[r] = 0.0;
+#pragma unroll
+        for (int row = 0; row < 4; ++row) {
+            if (16 * (4 * r + row) < n) {  // (uniform)
+                const double t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pre[r]), 16 * row + 15),
+                                                  __builtin_amdgcn_readlane(__double2loint(pre[r]), 16 * row + 15));
+                if ((lane >> 4) == row) offv[r] = off;
+                off = off + t;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) e[r] = offv[r] + pre[r];
+}
+
 // Orders the LDS operations of ONE wave (which the hardware executes in issue order) against compiler reordering: enough
 // for data handed between lanes of the same wave.
 __device__ inline void wave_lds_sync() {
@@ -825,6 +862,26 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
         double m = fmax(fmax(wv[0], wv[1]), fmax(wv[2], wv[3]));
         for (int i = lane + 256; i < n_cdf; i += 64) m = fmax(m, pw[i]);  // pools beyond 256 (these reads queue behind the tile)
         m = wave_max(m);
+        if (n_cdf <= 256) {  // the whole pool sits in this wave's registers: prefix sums on the DPP network, one LDS write
+            double e[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e[k] = (lane + 64 * k < n_cdf) ? exp(wv[k] - m) : 0.0;
+            if (n_cdf <= 64) {
+                double e1[1] = {e[0]};
+                wave_cdf<1>(e1, n_cdf);
+                e[0] = e1[0];
+            } else if (n_cdf <= 128) {
+                double e2[2] = {e[0], e[1]};
+                wave_cdf<2>(e2, n_cdf);
+                e[0] = e2[0]; e[1] = e2[1];
+            } else
+                wave_cdf<4>(e, n_cdf);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (lane + 64 * k < n_cdf) cdf[lane + 64 * k] = e[k];
+            wave_lds_sync();
+            if (lane == 0) s_total = cdf[n_cdf - 1];
+        } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (lane + 64 * k < n_cdf) cdf[lane + 64 * k] = exp(wv[k] - m);
@@ -867,6 +924,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
         for (int i = lane; i < n_cdf; i += 64) cdf[i] = ctot[i >> 4] + cdf[i];
         wave_lds_sync();
         if (lane == 0) s_total = cdf[n_cdf - 1];
+        }
     }
     DEMC_STAMP(0);  // wave 0: softmax prefix sums done (tile still in flight)
 
@@ -1247,8 +1305,9 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
             // proposes (reset!), so neither its noise draw nor the partner rows are needed -- in the hyper-parameter sweep of
             // a hierarchical model that is all but a few scalars of the row.  (Mutation ignores the mask, main.jl:205.)
             if (!PLAIN && kind != 2 && keep0 && (keep1 || !has1)) return;
-            const U4 nz = draw_block(p.seed, S_NOISE, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)k);
-            double u0 = u53(nz.x, nz.y), u1 = u53(nz.z, nz.w);
+            // (noise block k >> 1 covers the dim pairs 2(k >> 1) and 2(k >> 1) + 1: four scalars per block)
+            const U4 nz = draw_block(p.seed, S_NOISE, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)(k >> 1));
+            double u0 = u32unit((k & 1) ? nz.z : nz.x), u1 = u32unit((k & 1) ? nz.w : nz.y);
             if (kind == 2) {  // pt + Normal(0, sigma): mutation.jl:15-18 (block mask ignored, main.jl:205)
                 const double rad = sqrt(-2.0 * log(1.0 - u0));
                 double sn, cs;
@@ -1269,8 +1328,8 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
             v0 = cross(j0, t0, u0);
             if (has1) v1 = cross(j1, t1, u1);
             if (!PLAIN && p.kappa != 1.0) {  // recombination! crossover.jl:301-312
-                const U4 rc = draw_block(p.seed, S_RECOMB, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)k);
-                double c0u = u53(rc.x, rc.y), c1u = u53(rc.z, rc.w);
+                const U4 rc = draw_block(p.seed, S_RECOMB, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)(k >> 1));
+                double c0u = u32unit((k & 1) ? rc.z : rc.x), c1u = u32unit((k & 1) ? rc.w : rc.y);
                 if (p.rp_recomb) {
                     c0u = replayed(p.rp_recomb, slot * D + j0, c0u);
                     if (has1) c1u = replayed(p.rp_recomb, slot * D + j1, c1u);

@@ -140,6 +140,32 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
         double m = -INFINITY;
         for (int i = lane; i < n_cdf; i += 64) m = fmax(m, pw[i]);
         m = wave_max(m);
+        int b;
+        if (n_cdf <= 256) {  // the usual case: the pool sits in this wave's registers, no LDS round trips (wave_cdf)
+            double e[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e[r] = (lane + 64 * r < n_cdf) ? exp(pw[lane + 64 * r] - m) : 0.0;
+            if (n_cdf <= 64) {
+                double e1[1] = {e[0]};
+                wave_cdf<1>(e1, n_cdf);
+                e[0] = e1[0];
+            } else
+                wave_cdf<4>(e, n_cdf);
+            const int last = n_cdf - 1;
+            const double lastv = (last >> 6) == 0 ? e[0] : (last >> 6) == 1 ? e[1] : (last >> 6) == 2 ? e[2] : e[3];
+            const double total = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lastv), last & 63),
+                                                  __builtin_amdgcn_readlane(__double2loint(lastv), last & 63));
+            if (!(total > 0.0) || !(total < INFINITY)) {
+                b = (int)(u_base * n_cdf);
+                b = b < n_cdf ? b : n_cdf - 1;
+            } else {  // first i with cdf[i] >= t, else last = number of entries below t (cdf is monotone)
+                const double t = u_base * total;
+                int cnt = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cnt += __popcll(__ballot(lane + 64 * r < n_cdf && e[r] < t));
+                b = cnt < n_cdf ? cnt : n_cdf - 1;
+            }
+        } else {
         for (int i = lane; i < n_cdf; i += 64) cdf[i] = exp(pw[i] - m);
         wave_lds_sync();
         const int n_chunk = (n_cdf + 15) >> 4;
@@ -166,7 +192,6 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
         for (int i = lane; i < n_cdf; i += 64) cdf[i] = ctot[i >> 4] + cdf[i];
         wave_lds_sync();
         const double total = cdf[n_cdf - 1];
-        int b;
         if (!(total > 0.0) || !(total < INFINITY)) {
             b = (int)(u_base * n_cdf);
             b = b < n_cdf ? b : n_cdf - 1;
@@ -178,6 +203,7 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
                 if (cdf[mid] >= t) hi = mid; else lo = mid + 1;
             }
             b = lo;
+        }
         }
         if (lane == 0) s_base = b + p.pool_lo;
     }
@@ -228,6 +254,8 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
         }
         return r;
     };
+    U4 nz = {0, 0, 0, 0}, rc = nz;  // the noise / recombination block last drawn by this lane, and which one it is
+    int nz_block = -1, rc_block = -1;
     // proposal of both scalars of pair k from loaded rows (recombination! and reset! applied)
     auto propose_pair = [&](int k, const PairIn& in, bool base_on, double& v0, double& v1) {
         const int j0 = 2 * k, j1 = j0 + 1;
@@ -236,8 +264,13 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
         if (kind == 3) return;
         const bool keep0 = in.keep0, keep1 = in.keep1;
         if (kind != 2 && keep0 && (keep1 || !has1)) return;  // outside the block: nothing to draw (mutation ignores the mask)
-        const U4 nz = draw_block(p.seed, S_NOISE, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)k);
-        const double u0 = u53(nz.x, nz.y), u1 = u53(nz.z, nz.w);
+        // noise block k >> 1 covers the dim pairs 2(k >> 1), 2(k >> 1) + 1 (four scalars per block); a lane owns both pairs
+        // of a block and visits them back to back, so the block is drawn once and kept
+        if (nz_block != (k >> 1)) {
+            nz = draw_block(p.seed, S_NOISE, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)(k >> 1));
+            nz_block = k >> 1;
+        }
+        const double u0 = u32unit((k & 1) ? nz.z : nz.x), u1 = u32unit((k & 1) ? nz.w : nz.y);
         if (kind == 2) {  // pt + Normal(0, sigma): mutation.jl:15-18
             const double rad = sqrt(-2.0 * log(1.0 - u0));
             double sn, cs;
@@ -264,16 +297,21 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
         v0 = cross(in.t.x, in.a.x, in.b.x, in.c.x, u0);
         if (has1) v1 = cross(in.t.y, in.a.y, in.b.y, in.c.y, u1);
         if (p.kappa != 1.0) {  // recombination! crossover.jl:301-312
-            const U4 rc = draw_block(p.seed, S_RECOMB, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)k);
-            if (u53(rc.x, rc.y) <= 1.0 - p.kappa) v0 = in.t.x;
-            if (u53(rc.z, rc.w) <= 1.0 - p.kappa) v1 = in.t.y;
+            if (rc_block != (k >> 1)) {
+                rc = draw_block(p.seed, S_RECOMB, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)(k >> 1));
+                rc_block = k >> 1;
+            }
+            if (u32unit((k & 1) ? rc.z : rc.x) <= 1.0 - p.kappa) v0 = in.t.x;
+            if (u32unit((k & 1) ? rc.w : rc.y) <= 1.0 - p.kappa) v1 = in.t.y;
         }
         if (keep0) v0 = in.t.x;
         if (keep1) v1 = in.t.y;
     };
 
+    // This lane's dim pairs, in the order it visits them: both pairs of noise block tid, then of block tid + WG, ...
+    auto pair_at = [&](int i) -> int { return 2 * (tid + (i >> 1) * WG) + (i & 1); };
     // first batch of row loads before anything waits: this lane's first pair (the base row follows once the pick is known)
-    const int k_first = tid;
+    const int k_first = 2 * tid;
     const bool any = 2 * k_first < D;
     PairIn cur = {};
     if (any) cur = load_pair(k_first, false);
@@ -413,9 +451,11 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
     // the rows of this lane's NEXT pair go out before the current pair's noise is drawn and its terms are formed.  (Deeper
     // prefetch -- three pairs in flight -- was measured and gains nothing: the pass is bound by VALU issue, Philox rounds
     // and the softplus of the likelihood, not by memory latency)
-    for (int k = k_first; 2 * k < D; k += WG) {
+    // (a block's second pair is missing only in the very last block of an odd-ish row, which ends its lane's sequence)
+    for (int i = 0; 2 * pair_at(i) < D; ++i) {
+        const int k = pair_at(i), kn = pair_at(i + 1);
         PairIn nxt = cur;
-        if (2 * (k + WG) < D) nxt = load_pair(k + WG, base_on);
+        if (2 * kn < D) nxt = load_pair(kn, base_on);
         process(k, cur);
         cur = nxt;
     }
@@ -468,8 +508,8 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
     if (acc || hrow) {
         // in a block sweep an accepted crossover proposal differs from the row only inside the block: write only those
         const bool masked = acc && p.mask && kind != 2 && kind != 3;
-        int it = 0;
-        for (int k = tid; 2 * k < D; k += WG, ++it) {
+        for (int it = 0; 2 * pair_at(it) < D; ++it) {  // the lane's pairs in the order the pass visited them (wbits)
+            const int k = pair_at(it);
             const int j0 = 2 * k;
             const bool has1 = j0 + 1 < D;
             double v0, v1;

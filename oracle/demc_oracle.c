@@ -51,6 +51,9 @@ double orc_u53(uint32_t lo, uint32_t hi) {
     const uint64_t x = ((uint64_t)hi << 32) | lo;
     return (double)(x >> 11) * (1.0 / 9007199254740992.0);
 }
+/* 32-bit uniform in (0,1): the per-scalar draws (crossover noise b, recombination, the mutation's Box-Muller inputs)
+ * take ONE word each -- four scalars per Philox block: block m of the NOISE / RECOMB streams covers scalars 4m..4m+3 */
+double orc_u32(uint32_t w) { return ((double)w + 0.5) * (1.0 / 4294967296.0); }
 static inline uint32_t mulhi32(uint32_t x, uint32_t m) { return (uint32_t)(((uint64_t)x * m) >> 32); }
 static inline uint64_t mulhi64(uint64_t x, uint64_t m) { return (uint64_t)(((unsigned __int128)x * m) >> 64); }
 
@@ -879,8 +882,8 @@ static void propose(orc_handle* h, int64_t iter, uint32_t sweep, int32_t g_glob,
         /* mutation! mutation.jl:13-25: theta + Normal(0, sigma) per scalar; block mask ignored (main.jl:205) */
         idx[0] = 2;
         for (int k = 0; 2 * k < D; ++k) {
-            draw_block(seed, S_NOISE, sweep, (uint64_t)iter, slot, (uint32_t)k, r);
-            const double u1 = orc_u53(r[0], r[1]), u2 = orc_u53(r[2], r[3]);
+            draw_block(seed, S_NOISE, sweep, (uint64_t)iter, slot, (uint32_t)(k >> 1), r); /* scalars 2k, 2k+1 = words 2(k&1), 2(k&1)+1 */
+            const double u1 = orc_u32(r[2 * (k & 1)]), u2 = orc_u32(r[2 * (k & 1) + 1]);
             const double rad = sqrt(-2.0 * log(1.0 - u1));
             double z0 = rad * cos(2.0 * PI_D * u2), z1 = rad * sin(2.0 * PI_D * u2);
             z0 = replayed(h->rp_znoise, (size_t)lslot * D + 2 * k, z0);
@@ -949,8 +952,8 @@ static void propose(orc_handle* h, int64_t iter, uint32_t sweep, int32_t g_glob,
         orc_axpby(pt, dif, 1.0, gam, D, prop);
         free(tmp);
         for (int k = 0; 2 * k < D; ++k) {
-            draw_block(seed, S_NOISE, sweep, (uint64_t)iter, slot, (uint32_t)k, r);
-            const double uu[2] = {orc_u53(r[0], r[1]), orc_u53(r[2], r[3])};
+            draw_block(seed, S_NOISE, sweep, (uint64_t)iter, slot, (uint32_t)(k >> 1), r); /* scalars 2k, 2k+1 = words 2(k&1), 2(k&1)+1 */
+            const double uu[2] = {orc_u32(r[2 * (k & 1)]), orc_u32(r[2 * (k & 1) + 1])};
             for (int q = 0; q < 2 && 2 * k + q < D; ++q) {
                 const int j = 2 * k + q;
                 const double u = replayed(h->rp_noise, (size_t)lslot * D + j, uu[q]);
@@ -961,8 +964,8 @@ static void propose(orc_handle* h, int64_t iter, uint32_t sweep, int32_t g_glob,
         /* recombination! then reset! then adjust_loglike (crossover.jl:255, :84-85) */
         if (h->c.kappa != 1.0)
             for (int k = 0; 2 * k < D; ++k) {
-                draw_block(seed, S_RECOMB, sweep, (uint64_t)iter, slot, (uint32_t)k, r);
-                const double uu[2] = {orc_u53(r[0], r[1]), orc_u53(r[2], r[3])};
+                draw_block(seed, S_RECOMB, sweep, (uint64_t)iter, slot, (uint32_t)(k >> 1), r);
+                const double uu[2] = {orc_u32(r[2 * (k & 1)]), orc_u32(r[2 * (k & 1) + 1])};
                 for (int q = 0; q < 2 && 2 * k + q < D; ++q)
                     if (replayed(h->rp_recomb, (size_t)lslot * D + 2 * k + q, uu[q]) <= 1.0 - h->c.kappa) prop[2 * k + q] = pt[2 * k + q];
             }
@@ -1023,8 +1026,8 @@ static void propose(orc_handle* h, int64_t iter, uint32_t sweep, int32_t g_glob,
         free(dif);
     }
     for (int k = 0; 2 * k < D; ++k) {
-        draw_block(seed, S_NOISE, sweep, (uint64_t)iter, slot, (uint32_t)k, r);
-        const double uu[2] = {orc_u53(r[0], r[1]), orc_u53(r[2], r[3])};
+        draw_block(seed, S_NOISE, sweep, (uint64_t)iter, slot, (uint32_t)(k >> 1), r); /* scalars 2k, 2k+1 = words 2(k&1), 2(k&1)+1 */
+        const double uu[2] = {orc_u32(r[2 * (k & 1)]), orc_u32(r[2 * (k & 1) + 1])};
         for (int q = 0; q < 2 && 2 * k + q < D; ++q) {
             const int j = 2 * k + q;
             const double u = replayed(h->rp_noise, (size_t)lslot * D + j, uu[q]);
@@ -1034,8 +1037,8 @@ static void propose(orc_handle* h, int64_t iter, uint32_t sweep, int32_t g_glob,
     }
     if (h->c.kappa != 1.0) /* recombination! crossover.jl:301-312 */
         for (int k = 0; 2 * k < D; ++k) {
-            draw_block(seed, S_RECOMB, sweep, (uint64_t)iter, slot, (uint32_t)k, r);
-            const double uu[2] = {orc_u53(r[0], r[1]), orc_u53(r[2], r[3])};
+            draw_block(seed, S_RECOMB, sweep, (uint64_t)iter, slot, (uint32_t)(k >> 1), r);
+            const double uu[2] = {orc_u32(r[2 * (k & 1)]), orc_u32(r[2 * (k & 1) + 1])};
             for (int q = 0; q < 2 && 2 * k + q < D; ++q)
                 if (replayed(h->rp_recomb, (size_t)lslot * D + 2 * k + q, uu[q]) <= 1.0 - h->c.kappa) prop[2 * k + q] = pt[2 * k + q];
         }
