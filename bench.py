@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--burnin", type=int, default=1000, help="DE burnin (reference default 1000)")
     ap.add_argument("--fuse", type=int, default=0, help="demc_config.fuse (0 auto, 1 never, 2 per phase)")
     ap.add_argument("--accuracy-iters", type=int, default=1500, help="length of the untimed accuracy leg (0: skip)")
+    ap.add_argument("--async-migration", action="store_true",
+                    help="groups an exchange does not select update while the all-gather is in flight (SURVEY 8f #3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -351,10 +353,9 @@ def main():
     eng = demc_amd.HipEngine(n_groups=G, Np=Np, D=D, n_rows=n_rows, schedule=2 if a.schedule == "two_colour" else 1,
                              group_offset=rank * G, n_groups_total=G * world, seed=20260001, device_id=local, burnin=a.burnin,
                              loglike_mode=0 if a.mode == "streaming" else 1, trace=0, fuse=a.fuse, **w["engine"])
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
     W.configure(eng, w)
     eng.set_state(w["init"](P, np.random.default_rng(20260003 + rank)))
-    drv = ShardedDriver(eng, dist, torch.device("cuda", local), stream_ordered=True)
+    drv = ShardedDriver(eng, dist, torch.device("cuda", local), stream_ordered=True, async_migration=a.async_migration)
 
     def sync():
         if dist:
@@ -413,7 +414,8 @@ def main():
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": describe(a, w, world), "particles_per_gpu": P, "block_sweeps_per_step": sweeps,
-                       "parallelism": f"groups sharded x{world}, one all-gather per migration"},
+                       "parallelism": f"groups sharded x{world}, one all-gather per migration" +
+                                      (" (asynchronous: unselected groups update during the gather)" if a.async_migration else "")},
             "particle_parameter_updates_per_s": value * D,
             "accuracy": accuracy, "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -18,7 +18,8 @@ EXPORTS = [
     "demc_version", "demc_create", "demc_destroy", "demc_last_error", "demc_set_stream", "demc_set_model",
     "demc_set_model_source", "demc_set_priors", "demc_set_bounds", "demc_set_blocks", "demc_set_state", "demc_get_state",
     "demc_set_history_rows", "demc_get_history", "demc_export_chains", "demc_step", "demc_update", "demc_migration_due",
-    "demc_migration_pack", "demc_migration_apply", "demc_migration_pack_async", "demc_migration_apply_async", "demc_apply_migration", "demc_get_weights", "demc_logpost",
+    "demc_migration_pack", "demc_migration_apply", "demc_migration_pack_async", "demc_migration_apply_async", "demc_migration_groups",
+    "demc_update_groups_async", "demc_apply_migration", "demc_get_weights", "demc_logpost",
     "demc_get_trace", "demc_set_replay", "demc_timing_enable", "demc_timing_read",
 ]
 
@@ -138,6 +139,8 @@ def load():
     L.demc_migration_apply.argtypes = [H, C.c_int64, C.c_void_p]
     L.demc_migration_pack_async.argtypes = [H, C.c_int64, C.c_void_p]
     L.demc_migration_apply_async.argtypes = [H, C.c_int64, C.c_void_p]
+    L.demc_migration_groups.argtypes = [C.POINTER(DemcConfig), C.c_int64, _ip, _ip]
+    L.demc_update_groups_async.argtypes = [H, C.c_int64, C.c_int32, _ip, C.c_int32]
     L.demc_logpost.argtypes = [H, _dp, C.c_int64, _dp]
     L.demc_get_trace.argtypes = [H, _dp, _dp, _dp, _ip, _bp]
     L.demc_set_replay.argtypes = [H, C.POINTER(DemcReplay)]
@@ -333,6 +336,20 @@ class HipEngine:
 
     def migration_apply_enqueue(self, it, dev_ptr):
         self._ck(self.L.demc_migration_apply_async(self.h, it, C.c_void_p(dev_ptr)))
+
+    def migration_groups(self, it):
+        """select_groups' ordered sub-group of iteration `it` (global group indices)"""
+        sel = np.empty(self.cfg.n_groups_total, np.int32)
+        n = C.c_int32()
+        rc = self.L.demc_migration_groups(C.byref(self.cfg), it, sel.ctypes.data_as(_ip), C.byref(n))
+        if rc != OK:
+            raise DemcError(rc, "demc_migration_groups")
+        return sel[: n.value].copy()
+
+    def update_groups_enqueue(self, iter0, n_iters, groups):
+        """update! + store_samples! for a subset of the local groups, enqueued on the handle's stream (no drain)"""
+        g = np.ascontiguousarray(groups, dtype=np.int32)
+        self._ck(self.L.demc_update_groups_async(self.h, iter0, n_iters, g.ctypes.data_as(_ip), g.size))
 
     def timing_enable(self, on=True):
         self._ck(self.L.demc_timing_enable(self.h, 1 if on else 0))

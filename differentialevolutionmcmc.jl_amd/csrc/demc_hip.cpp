@@ -87,6 +87,17 @@ struct demc_handle {
     unsigned* st_err = nullptr;             // time-out flag (host-mapped, zero-copy)
     int n_cus = 0;
     int ainv_lds = 1;
+    // update of a subset of the groups (demc_update_groups_async): two device lists used alternately, and the one in force
+    // Each call takes the next of kGlistRing slots: a pinned host copy of the list, a device copy, and an event that marks
+    // the host copy as consumed.  The device copy is refilled by a copy ON THE HANDLE'S STREAM, i.e. behind every kernel that
+    // still reads its previous content.
+    static constexpr int kGlistRing = 8;
+    int* glist_buf[kGlistRing] = {};
+    int* glist_pin[kGlistRing] = {};
+    hipEvent_t glist_ev[kGlistRing] = {};
+    int glist_next = 0;
+    const int* cur_glist = nullptr;
+    int cur_ng = 0;
     std::string err;
     // replay (demc_set_replay): device copies of the caller's draws
     double *rp_group = nullptr, *rp_part = nullptr, *rp_noise = nullptr, *rp_znoise = nullptr, *rp_recomb = nullptr;
@@ -234,6 +245,8 @@ KParams base_params(demc_handle* h) {
     k.rp_group = h->rp_group; k.rp_part = h->rp_part; k.rp_partner = h->rp_partner; k.rp_noise = h->rp_noise;
     k.rp_znoise = h->rp_znoise; k.rp_recomb = h->rp_recomb; k.rp_mig_groups = h->rp_mig_groups;
     k.rp_mig_particle = h->rp_mig_particle; k.rp_n_mig = h->rp_n_mig;
+    k.glist = h->cur_glist;
+    if (h->cur_glist) k.n_groups = h->cur_ng;
     return k;
 }
 
@@ -807,6 +820,11 @@ int32_t demc_create(const demc_config* cfg, demc_handle** out) {
     ALLOC(h->partial, (size_t)h->partial_cap * P); ALLOC(h->aux, P);
     ALLOC(h->dimtab, D);
     ALLOC(h->dimseg, (size_t)kMaxDimSeg);
+    for (int i = 0; i < demc_handle::kGlistRing; ++i) {
+        ALLOC(h->glist_buf[i], (size_t)c.n_groups);
+        HIPCHK(hipHostMalloc((void**)&h->glist_pin[i], (size_t)c.n_groups * sizeof(int), hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&h->glist_ev[i], hipEventDisableTiming));
+    }
     ALLOC(h->mig_rows, (size_t)c.n_groups_total * (D + 3));
     ALLOC(h->scratch_theta, P * D); ALLOC(h->scratch_w, P);
     if (c.store_history && c.n_rows > 0) {
@@ -876,6 +894,11 @@ int32_t demc_destroy(demc_handle* h) {
     if (h->user_module) hipModuleUnload(h->user_module);
     if (h->user_hyper) hipFree(h->user_hyper);
     free_replay(h);
+    for (int i = 0; i < demc_handle::kGlistRing; ++i) {
+        if (h->glist_buf[i]) hipFree(h->glist_buf[i]);
+        if (h->glist_pin[i]) hipHostFree(h->glist_pin[i]);
+        if (h->glist_ev[i]) hipEventDestroy(h->glist_ev[i]);
+    }
     if (h->st_gran) hipFree(h->st_gran);
     if (h->st_err) hipHostFree(h->st_err);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -1274,7 +1297,7 @@ static bool migration_due_h(demc_handle* h, int64_t iter) {
     return demc_migration_due(&h->c, iter) != 0;
 }
 
-static int32_t step_impl(demc_handle* h, int64_t iter0, int32_t n_iters, bool with_migration) {
+static int32_t step_impl(demc_handle* h, int64_t iter0, int32_t n_iters, bool with_migration, bool drain = true) {
     return guarded(h, [&]() -> int32_t {
     if (!h) return DEMC_EINVAL;
     USE_DEVICE(h);
@@ -1290,11 +1313,12 @@ static int32_t step_impl(demc_handle* h, int64_t iter0, int32_t n_iters, bool wi
                 return fail(h, DEMC_EINVAL, "sharded handle: drive the exchange with demc_migration_pack/apply + demc_update");
             migration_enqueue(h, iter, h->mig_rows, h->mig_rows, true, true);
         }
-        if ((h->res_ok || h->st_ok) && !h->rp_active) {  // every iteration up to the next migration in one launch
+        const bool st_ok = h->st_ok && !h->cur_glist;  // (a subset update never uses the form whose workgroups wait on each other)
+        if ((h->res_ok || st_ok) && !h->rp_active) {  // every iteration up to the next migration in one launch
             int run = 1;  // capped so that a single launch stays in the millisecond range whatever the caller asks for
-            const int cap = h->st_ok ? 64 : 1024;
+            const int cap = st_ok ? 64 : 1024;
             while (run < cap && iter + run < iter0 + n_iters && !(with_migration && migration_due_h(h, iter + run))) ++run;
-            int rc = h->st_ok ? launch_stream(h, iter, run) : launch_resident(h, iter, run);
+            int rc = st_ok ? launch_stream(h, iter, run) : launch_resident(h, iter, run);
             if (rc != DEMC_OK) return rc;
             iter += run - 1;
             continue;
@@ -1306,6 +1330,10 @@ static int32_t step_impl(demc_handle* h, int64_t iter0, int32_t n_iters, bool wi
             int rc = run_sweep(h, iter, (unsigned)b, mask, store_row);
             if (rc != DEMC_OK) return rc;
         }
+    }
+    if (!drain) {
+        HIPCHK(hipGetLastError());
+        return DEMC_OK;
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
@@ -1319,6 +1347,57 @@ static int32_t step_impl(demc_handle* h, int64_t iter0, int32_t n_iters, bool wi
 
 int32_t demc_step(demc_handle* h, int64_t iter0, int32_t n_iters) { return step_impl(h, iter0, n_iters, true); }
 int32_t demc_update(demc_handle* h, int64_t iter0, int32_t n_iters) { return step_impl(h, iter0, n_iters, false); }
+
+int32_t demc_update_groups_async(demc_handle* h, int64_t iter0, int32_t n_iters, const int32_t* groups, int32_t n) {
+    if (!h || n < 0 || (n > 0 && !groups)) return DEMC_EINVAL;
+    if (n == 0) return DEMC_OK;
+    if (h->family == FAM_USER) return fail(h, DEMC_EUNSUPPORTED, "subset updates are not available for source plug-in models");
+    const int G = h->c.n_groups;
+    for (int i = 0; i < n; ++i)
+        if (groups[i] < 0 || groups[i] >= G) return fail(h, DEMC_EINVAL, "group index outside this handle");
+    if (hipSetDevice(h->c.device_id) != hipSuccess) return fail(h, DEMC_EHIP, "hipSetDevice");
+    const int slot = h->glist_next;
+    h->glist_next = (slot + 1) % demc_handle::kGlistRing;
+    int* dev = h->glist_buf[slot];
+    if (hipEventSynchronize(h->glist_ev[slot]) != hipSuccess) return fail(h, DEMC_EHIP, "group-list ring");
+    std::memcpy(h->glist_pin[slot], groups, (size_t)n * sizeof(int));
+    if (hipMemcpyAsync(dev, h->glist_pin[slot], (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipEventRecord(h->glist_ev[slot], h->stream) != hipSuccess)
+        return fail(h, DEMC_EHIP, "copying the group list");
+    h->cur_glist = dev;
+    h->cur_ng = n;
+    const int32_t rc = step_impl(h, iter0, n_iters, false, false);
+    h->cur_glist = nullptr;
+    h->cur_ng = 0;
+    return rc;
+}
+
+int32_t demc_migration_groups(const demc_config* cfg, int64_t iter, int32_t* sel, int32_t* n_sel) {
+    if (!cfg || !sel || !n_sel) return DEMC_EINVAL;
+    // select_groups (migration.jl:31-35) exactly as k_mig_apply draws it: N = rand(2:n_groups), ordered sample without
+    // replacement by a partial Fisher-Yates shuffle, words from the STEP stream
+    const int ng = cfg->n_groups_total > 0 ? cfg->n_groups_total : cfg->n_groups;
+    *n_sel = 0;
+    if (ng < 2) return DEMC_OK;
+    try {
+        std::vector<int> perm((size_t)ng);
+        for (int i = 0; i < ng; ++i) perm[(size_t)i] = i;
+        const U4 r0 = draw_block(cfg->seed, S_STEP, 0, (uint64_t)iter, 0, 0);
+        const int ns = 2 + (int)mulhi32(r0.z, (uint32_t)(ng - 1));
+        U4 r = r0;
+        for (int i = 0; i < ns; ++i) {
+            if ((i & 3) == 0) r = draw_block(cfg->seed, S_STEP, 0, (uint64_t)iter, 0, 1 + (uint32_t)(i >> 2));
+            const uint32_t w = (i & 3) == 0 ? r.x : (i & 3) == 1 ? r.y : (i & 3) == 2 ? r.z : r.w;
+            const int j = i + (int)mulhi32(w, (uint32_t)(ng - i));
+            std::swap(perm[(size_t)i], perm[(size_t)j]);
+        }
+        for (int i = 0; i < ns; ++i) sel[i] = perm[(size_t)i];
+        *n_sel = ns;
+    } catch (...) {
+        return DEMC_ENOMEM;
+    }
+    return DEMC_OK;
+}
 
 int32_t demc_migration_due(const demc_config* cfg, int64_t iter) {
     if (!cfg) return 0;

@@ -79,6 +79,8 @@ struct KParams {
     const DimSeg* dimseg;       // [n_seg] the same table run-length encoded (n_seg = 0: too many segments, use dimtab)
     int n_seg;
     int ainv_lds;               // K1: A^-1 [d][d] is staged in LDS (else read from L2: wide data)
+    const int* glist;           // update of a SUBSET of the handle's groups (demc_update_groups_async): launch group i is local
+                                // group glist[i], n_groups counts the subset; null: all groups, in order
     const unsigned char* mask;  // [D] or null
     // history (slot keyed)
     double* hist;             // [rows][P][D]
@@ -152,6 +154,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));  // C/D fragment of v_mfm
 __device__ inline int slot_of(const KParams& p, int q, int& g, int& pl) {
     g = q / p.n_act;
     pl = p.a_lo + (q - g * p.n_act);
+    if (p.glist) g = p.glist[g];
     return g * p.Np + pl;
 }
 __device__ inline int slot_of(const KParams& p, int q) {
@@ -702,6 +705,8 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
         g = blockIdx.x / p.n_split;
         sp = blockIdx.x % p.n_split;
     }
+    const int gi = g;  // position in this launch (indexes launch-private buffers); g = the local group it stands for
+    if (p.glist) g = p.glist[g];
     const int g_glob = p.group_offset + g;
     const int D = p.D, Np = p.Np, d = p.d;
     const bool even = (D & 1) == 0;
@@ -1592,7 +1597,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
         DEMC_STAMP(17);  // cross terms of this workgroup's chunk done
         // this workgroup's partial per particle (waves in fixed order) -> two granules, tagged with the step's epoch
         const unsigned epoch = (unsigned)(step + 1);
-        unsigned long long* gran = p.st_gran + (((size_t)(step & 1) * p.n_groups + g) * p.st_C) * p.st_nact_max * 2;
+        unsigned long long* gran = p.st_gran + (((size_t)(step & 1) * p.n_groups + gi) * p.st_C) * p.st_nact_max * 2;
         if (tid < n_act) {
             double v = 0.0;
             for (int wv = 0; wv < WG / 64; ++wv) v += part_l[(size_t)wv * p.st_nact_max + tid];

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
         g = blockIdx.x / p.n_act;
         qg = blockIdx.x % p.n_act;
     }
+    if (p.glist) g = p.glist[g];
     const int pl = p.a_lo + qg;
     const size_t slot = (size_t)g * Np + pl;
     const int g_glob = p.group_offset + g;

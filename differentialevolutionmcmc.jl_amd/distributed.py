@@ -17,7 +17,7 @@ class ShardedDriver:
     """Drives one engine shard.  `engine` follows the engine interface (HipEngine, or the CPU oracle when a TEST
     injects it); `dist` is torch.distributed (or None for a single shard)."""
 
-    def __init__(self, engine, dist=None, device=None, stream_ordered=False):
+    def __init__(self, engine, dist=None, device=None, stream_ordered=False, async_migration=False):
         import torch
         self.torch = torch
         self.eng = engine
@@ -31,9 +31,20 @@ class ShardedDriver:
         self.rows = torch.zeros((G, D + 3), dtype=torch.float64, device=self.device)
         self.all_rows = torch.zeros((Gt, D + 3), dtype=torch.float64, device=self.device)
         self.on_device = self.device.type == "cuda"
-        # True: the engine's stream IS torch's current stream (engine.set_stream(torch.cuda.current_stream().cuda_stream))
+        # stream_ordered: the driver owns ONE torch stream, hands it to the engine (demc_set_stream) and issues its own work
+        # (the collective, the staging copies) under it, so that pack -> gather -> apply -> update are ordered by the stream
+        # alone.  (torch's default stream has the handle 0, which demc_set_stream reads as "the engine's own stream" -- an
+        # explicit stream avoids that trap.)
         self.stream_ordered = bool(stream_ordered) and self.on_device
+        self.stream = None
+        if self.stream_ordered:
+            self.stream = torch.cuda.Stream(device=self.device)
+            engine.set_stream(self.stream.cuda_stream)
         self.n_exchanges = 0
+        # per-group-asynchronous migration: the groups an exchange does not select start their update while the
+        # all-gather is still in flight (on a side stream); only the selected groups wait for it
+        self.async_migration = bool(async_migration)
+        self.side = torch.cuda.Stream(device=self.device) if (self.async_migration and self.on_device and self.stream_ordered) else None
 
     def _exchange(self, it):
         t = self.torch
@@ -64,18 +75,70 @@ class ShardedDriver:
             self.eng.migration_apply(it, self.all_rows.numpy())
         self.n_exchanges += 1
 
+    def _exchange_async(self, it, run):
+        """migration of iteration `it` + the update of iterations [it, it + run), with the groups the exchange did not select
+        updating while the collective is in flight.  Groups never interact inside update! (main.jl:135-167), so the result is
+        the one _exchange + update give, bit for bit."""
+        t = self.torch
+        G, off = self.eng.cfg.n_groups, self.eng.cfg.group_offset
+        sel = self.eng.migration_groups(it)
+        mine = sorted(int(g) - off for g in sel if off <= int(g) < off + G)
+        rest = [g for g in range(G) if g not in set(mine)]
+        if self.on_device:
+            self.eng.migration_pack_enqueue(it, self.rows.data_ptr())
+            if self.dist:
+                main = t.cuda.current_stream()
+                self.side.wait_stream(main)
+                with t.cuda.stream(self.side):
+                    self.dist.all_gather_into_tensor(self.all_rows, self.rows)  # the one collective, off the main stream
+            else:
+                self.all_rows.copy_(self.rows)
+            self.eng.update_groups_enqueue(it, run, rest)                        # overlaps the gather
+            if self.dist:
+                t.cuda.current_stream().wait_stream(self.side)
+            self.eng.migration_apply_enqueue(it, self.all_rows.data_ptr())
+            self.eng.update_groups_enqueue(it, run, mine)
+        else:
+            self.rows.copy_(t.from_numpy(self.eng.migration_pack(it)))
+            work = self.dist.all_gather_into_tensor(self.all_rows, self.rows, async_op=True) if self.dist else None
+            if work is None:
+                self.all_rows.copy_(self.rows)
+            self.eng.update_groups_enqueue(it, run, rest)
+            if work is not None:
+                work.wait()
+            self.eng.migration_apply(it, self.all_rows.numpy())
+            self.eng.update_groups_enqueue(it, run, mine)
+        self.n_exchanges += 1
+
     def step(self, iter0, n_iters):
         """n_iters of step!/pstep! (main.jl:84-107); runs of iterations without a migration event go to the engine
         as one call."""
+        if self.stream is not None:
+            with self.torch.cuda.stream(self.stream):
+                return self._step(iter0, n_iters)
+        return self._step(iter0, n_iters)
+
+    def _step(self, iter0, n_iters):
         it, end = iter0, iter0 + n_iters
         while it < end:
-            if self.eng.migration_due(it):
-                self._exchange(it)
+            due = self.eng.migration_due(it)
             run = 1
             while it + run < end and not self.eng.migration_due(it + run):
                 run += 1
-            self.eng.update(it, run)
+            if due and self.async_migration and (self.stream_ordered or not self.on_device):
+                self._exchange_async(it, run)
+            else:
+                if due:
+                    self._exchange(it)
+                self.eng.update(it, run)
             it += run
+
+    def synchronize(self):
+        """drain the engine's stream (the asynchronous form only enqueues)"""
+        if self.stream is not None:
+            self.stream.synchronize()
+        elif self.on_device:
+            self.torch.cuda.current_stream().synchronize()
 
 
 def gather_history(driver, row0, row1):

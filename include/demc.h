@@ -204,6 +204,16 @@ int32_t demc_migration_apply(demc_handle* h, int64_t iter, const double* dev_all
  * demc_update then need no host synchronisation in between.  dev pointers must stay valid until the stream has passed. */
 int32_t demc_migration_pack_async(demc_handle* h, int64_t iter, double* dev_rows);
 int32_t demc_migration_apply_async(demc_handle* h, int64_t iter, const double* dev_all_rows);
+/* Per-group-asynchronous migration: groups the migration of an iteration did not select are untouched by the
+ * exchange, so their update need not wait for it.
+ *   demc_migration_groups     : select_groups' ordered sub-group of iteration `iter` (GLOBAL group indices, sel has room for
+ *                               n_groups_total entries) -- a pure function of (seed, iter), what k_mig_apply derives on the device.
+ *   demc_update_groups_async  : update! + store_samples! (like demc_update) for a SUBSET of this handle's groups (local indices),
+ *                               enqueued on the handle's stream WITHOUT draining it.
+ * A sharded driver enqueues  pack -> [all-gather on a side stream] ; update(groups not selected) ; wait for the gather ;
+ * apply ; update(selected groups)  -- the collective overlaps the update of the unselected groups (distributed.py). */
+int32_t demc_migration_groups(const demc_config* cfg, int64_t iter, int32_t* sel, int32_t* n_sel);
+int32_t demc_update_groups_async(demc_handle* h, int64_t iter0, int32_t n_iters, const int32_t* local_groups, int32_t n);
 /* shift_particles! (migration.jl:84-91) with a HOST-drawn plan: for every k, slot dst_slot[k] receives the row
  * (theta, weight, id) that slot src_slot[k] held BEFORE the call -- all reads precede all writes, so a cycle is a
  * rotation.  For a caller that keeps migration!'s own random choices (select_groups / select_particles,

@@ -1193,11 +1193,17 @@ int orc_migration_apply(orc_handle* h, int64_t iter, const double* all_rows) {
 
 /* ------------------------------------------------------------------ step ------ */
 /* step!/pstep! main.jl:84-107 */
-static int step_impl(orc_handle* h, int64_t iter0, int32_t n_iters, int with_migration);
-int orc_step(orc_handle* h, int64_t iter0, int32_t n_iters) { return step_impl(h, iter0, n_iters, 1); }
+static int step_impl(orc_handle* h, int64_t iter0, int32_t n_iters, int with_migration, const int32_t* groups, int32_t n_sub);
+int orc_step(orc_handle* h, int64_t iter0, int32_t n_iters) { return step_impl(h, iter0, n_iters, 1, NULL, 0); }
 /* update! + store_samples! only (main.jl:86-87), for a driver that runs the exchange itself */
-int orc_update(orc_handle* h, int64_t iter0, int32_t n_iters) { return step_impl(h, iter0, n_iters, 0); }
-static int step_impl(orc_handle* h, int64_t iter0, int32_t n_iters, int with_migration) {
+int orc_update(orc_handle* h, int64_t iter0, int32_t n_iters) { return step_impl(h, iter0, n_iters, 0, NULL, 0); }
+/* the same for a subset of the local groups (groups never interact inside update!, main.jl:135-167) */
+int orc_update_groups(orc_handle* h, int64_t iter0, int32_t n_iters, const int32_t* groups, int32_t n) {
+    if (!h || n < 0 || (n > 0 && !groups)) return ORC_EINVAL;
+    if (n == 0) return ORC_OK;
+    return step_impl(h, iter0, n_iters, 0, groups, n);
+}
+static int step_impl(orc_handle* h, int64_t iter0, int32_t n_iters, int with_migration, const int32_t* groups, int32_t n_sub) {
     if (!h || h->family < 0) return ORC_EINVAL;
     const int D = h->c.D, Np = h->c.Np;
     const int nthreads = h->c.n_threads > 0 ? h->c.n_threads : 1;
@@ -1224,17 +1230,20 @@ static int step_impl(orc_handle* h, int64_t iter0, int32_t n_iters, int with_mig
                 double* snap_w = (double*)malloc(sizeof(double) * (size_t)Np);
                 double* prop = (double*)malloc(sizeof(double) * (size_t)D);
 #pragma omp for schedule(dynamic)
-                for (int g = 0; g < h->c.n_groups; ++g) /* p_update! main.jl:135-148: one task per group */
-                    sweep_group(h, iter, (uint32_t)b, g, mask, snap_rows, snap_w, prop);
+                for (int gi = 0; gi < (groups ? n_sub : h->c.n_groups); ++gi) /* p_update! main.jl:135-148: one task per group */
+                    sweep_group(h, iter, (uint32_t)b, groups ? groups[gi] : gi, mask, snap_rows, snap_w, prop);
                 free(snap_rows); free(snap_w); free(prop);
             }
         }
         /* store_samples! utilities.jl:161-180: samples[iter, :, p.id] = p.theta */
         const int64_t row = iter - 1;
         if (h->hist && row >= 0 && row < h->c.n_rows)
-            for (int64_t s = 0; s < h->P; ++s) {
-                memcpy(h->hist + (row * h->P + s) * D, h->theta + s * D, sizeof(double) * (size_t)D);
-                h->id_hist[row * h->P + s] = h->id[s];
+            for (int gi = 0; gi < (groups ? n_sub : h->c.n_groups); ++gi) {
+                const int64_t g = groups ? groups[gi] : gi;
+                for (int64_t s = g * Np; s < (g + 1) * Np; ++s) {
+                    memcpy(h->hist + (row * h->P + s) * D, h->theta + s * D, sizeof(double) * (size_t)D);
+                    h->id_hist[row * h->P + s] = h->id[s];
+                }
             }
     }
     return ORC_OK;

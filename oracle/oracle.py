@@ -89,6 +89,7 @@ def lib():
         L.orc_get_history.argtypes = [C.c_void_p, C.c_int64, C.c_int64, _dp, _bp, _dp, _lp]
         L.orc_step.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
         L.orc_update.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
+        L.orc_update_groups.argtypes = [C.c_void_p, C.c_int64, C.c_int32, _ip, C.c_int32]
         L.orc_logpost.argtypes = [C.c_void_p, _dp, C.c_int64, _dp]
         L.orc_loglike.argtypes = [C.c_void_p, _dp, C.c_int64, _dp]
         L.orc_prior.argtypes = [C.c_void_p, _dp, C.c_int64, _dp]
@@ -221,6 +222,13 @@ class Oracle:
 
     def update(self, iter0, n_iters=1):
         self._ck(self.L.orc_update(self.h, iter0, n_iters))
+
+    def update_groups_enqueue(self, iter0, n_iters, groups):
+        g = np.ascontiguousarray(groups, dtype=np.int32)
+        self._ck(self.L.orc_update_groups(self.h, iter0, n_iters, g.ctypes.data_as(_ip), g.size))
+
+    def migration_groups(self, it):
+        return self.migration_plan(it)
 
     def logpost(self, theta):
         theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(-1, self.D)

@@ -34,7 +34,7 @@ def _mk(orc, ng, off, total):
     return o
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, async_migration=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
@@ -45,7 +45,7 @@ def _worker(rank, world, port, q):
     eng = _mk(orc, G, rank * G, 8)
     _, th0 = _problem()
     eng.set_state(th0[rank * G * 6:(rank + 1) * G * 6])
-    drv = ShardedDriver(eng, dist)
+    drv = ShardedDriver(eng, dist, async_migration=async_migration)
     drv.step(1, 25)
     drv.step(26, 15)  # split call: iteration numbering must carry over
     hist = gather_history(drv, 0, 40)
@@ -58,12 +58,15 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_world2_equals_single_shard(orc):
+@pytest.mark.parametrize("async_migration", [False, True])
+def test_world2_equals_single_shard(orc, async_migration):
+    """async_migration: the groups an exchange does not select update while the all-gather is in flight;
+    same bits either way"""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, async_migration)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=240) for _ in range(3)]
@@ -84,13 +87,14 @@ def test_world2_equals_single_shard(orc):
         np.testing.assert_array_equal(a, b)
 
 
-def test_single_shard_driver_matches_step(orc):
+@pytest.mark.parametrize("async_migration", [False, True])
+def test_single_shard_driver_matches_step(orc, async_migration):
     from demc_amd.distributed import ShardedDriver
     a, b = _mk(orc, 8, 0, 8), _mk(orc, 8, 0, 8)
     th0 = _problem()[1]
     a.set_state(th0)
     b.set_state(th0)
     a.step(1, 30)
-    ShardedDriver(b).step(1, 30)
+    ShardedDriver(b, async_migration=async_migration).step(1, 30)
     for x, y in zip(a.get_history(0, 30), b.get_history(0, 30)):
         np.testing.assert_array_equal(x, y)
