@@ -621,11 +621,14 @@ int launch_stream(demc_handle* h, long long iter0, int n_iters) {
     // epoch tags restart at 1 in every launch: the granules of the previous launch must not match them
     HIPCHK(hipMemsetAsync(h->st_gran, 0, 2 * (size_t)c.n_groups * h->st_C * h->st_nact_max * 2 * sizeof(unsigned long long), h->stream));
     tick(h, 0, true);
-    void* args[] = {&k};
-    // cooperative launch: not for a grid barrier, but for its launch-time check that every workgroup of the grid is
-    // co-resident (the hand-over between the workgroups of a group spins on their progress)
-    hipError_t e = hipLaunchCooperativeKernel((const void*)k1_stream_instance(h->st_wg, tail_of(k), is_plain(h, k)),
-                                              dim3(c.n_groups * h->st_C), dim3(h->st_wg), args, (unsigned)h->st_lds, h->stream);
+    // Every workgroup of this grid must be resident at once (the workgroups of a group spin on each other's progress).  The
+    // grid is sized for that by construction -- at most one workgroup per CU (plan_stream: n_groups * C <= CUs, and each
+    // takes most of a CU's LDS) -- so a plain launch has the same residency as a cooperative one, without its launch-time
+    // cost (+15-19 us, MI355X_MICROARCH.md "coop-launch"); every spin in the kernel is bounded regardless.
+    if (c.n_groups * h->st_C > h->n_cus) return fail(h, DEMC_EINVAL, "streaming-resident grid exceeds the CU count");
+    hipLaunchKernelGGL(k1_stream_instance(h->st_wg, tail_of(k), is_plain(h, k)), dim3(c.n_groups * h->st_C), dim3(h->st_wg), h->st_lds,
+                       h->stream, k);
+    const hipError_t e = hipGetLastError();
     tick(h, 0, false);
     if (e != hipSuccess) return fail(h, DEMC_EHIP, std::string("streaming-resident launch: ") + hipGetErrorString(e));
     return DEMC_OK;

@@ -39,7 +39,11 @@ def run(out_dir, tag, prof_args, bench_args):
                                                         os.path.join(ROOT, "bench.py")] + bench_args
     env = dict(os.environ, TMPDIR="/tmp")
     with open(os.path.join(out_dir, tag + ".log"), "w") as log:
-        subprocess.run(cmd, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, check=True, timeout=600)
+        rc = subprocess.run(cmd, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, timeout=600).returncode
+    if rc != 0:  # (a profiled process that fails AFTER its outputs were generated is reported, not fatal)
+        print(f"  pass {tag}: exit status {rc}", flush=True)
+        if not glob.glob(os.path.join(d, "**", "*.csv"), recursive=True):
+            raise SystemExit(f"pass {tag} produced no output")
     print("  pass", tag, "done", flush=True)
     return d
 

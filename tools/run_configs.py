@@ -15,39 +15,14 @@ from demc_amd import families as F  # noqa: E402
 
 
 def build(name, rng):
-    inf = np.inf
-    if name == "cfg1":  # Gaussian_Example.jl: D=2, N=50, 4 groups x 10
-        data = rng.normal(0, 1, 50)
-        return dict(G=4, Np=10, D=2, fam=F.FAM_GAUSSIAN, data=data, dims=[50], hyper=None, pk=[1, 2], pa=[0, 0], pb=[1, 1],
-                    pref=[0, 0], lo=[-inf, 0], hi=[inf, inf], extra={},
-                    init=lambda P: np.stack([rng.normal(0, 1, P), np.abs(rng.standard_cauchy(P)) + .1], 1))
-    if name == "cfg2":  # MvNormal D=8, 32 x 64, N=1e4
-        d, N = 8, 10000
-        A = rng.normal(0, 1, (d, d)); S = A @ A.T / d + 0.5 * np.eye(d)
-        X = rng.normal(0, 1, d) + rng.normal(0, 1, (N, d)) @ np.linalg.cholesky(S).T
-        return dict(G=32, Np=64, D=d, fam=F.FAM_MVN_FULL, data=X, dims=[N, d], hyper=S, pk=[1] * d, pa=[0] * d, pb=[1] * d,
-                    pref=[0] * d, lo=[-inf] * d, hi=[inf] * d, extra={}, init=lambda P: rng.normal(0, 1, (P, d)))
-    if name == "cfg4":  # hierarchical Binomial, S=1e4 subjects, one GPU's share of 128 groups = 16 groups x 32
-        S_, n = 10000, 50.0
-        b0 = rng.normal(0, 1, S_)
-        k = rng.binomial(50, 1 / (1 + np.exp(-(1 + b0)))).astype(float)
-        Dd = S_ + 2
-        m0 = np.zeros(Dd, np.uint8); m0[:2] = 1
-        return dict(G=16, Np=32, D=Dd, fam=F.FAM_HIER_BINOMIAL, data=k, dims=[S_], hyper=[n], pk=[1, 2] + [5] * S_,
-                    pa=[1, 0] + [0] * S_, pb=[1, 1] + [1] * S_, pref=[0, 0] + [1] * S_, lo=[-inf, 0] + [-inf] * S_, hi=[inf] * Dd,
-                    extra=dict(masks=np.stack([m0, 1 - m0])),
-                    init=lambda P: np.concatenate([rng.normal(1, 1, (P, 1)), np.abs(rng.standard_cauchy((P, 1))) + .3,
-                                                   rng.normal(0, 1, (P, S_))], 1))
-    if name == "cfg5":  # LBA 3 accumulators, 5e4 trials, one GPU's share of 512 groups = 64 groups x 128, snooker on
-        N, na = 50000, 3
-        choice = rng.integers(1, na + 1, N).astype(float); rt = rng.uniform(0.45, 1.6, N); mr = rt.min()
-        Dd = na + 3
-        return dict(G=64, Np=128, D=Dd, fam=F.FAM_LBA, data=np.concatenate([choice, rt]), dims=[N, na], hyper=None,
-                    pk=[1] * na + [1, 1, 3], pa=[1] * na + [.8, .2, 0.], pb=[5] * na + [.2, .1, mr], pref=[0] * Dd, lo=[0] * Dd,
-                    hi=[inf] * (Dd - 1) + [mr], extra=dict(theta_snooker=0.1),
-                    init=lambda P: np.concatenate([rng.uniform(.5, 4, (P, na)), rng.uniform(.5, 1.1, (P, 1)),
-                                                   rng.uniform(.05, .4, (P, 1)), rng.uniform(.05, mr * .9, (P, 1))], 1))
-    raise KeyError(name)
+    """the BASELINE configs as demc_amd.workloads builds them (bench.py's data), in this tool's older dict shape"""
+    from demc_amd import workloads as W
+    w = W.BUILDERS[name]()
+    extra = dict(w["engine"])
+    if w["masks"] is not None:
+        extra["masks"] = w["masks"]
+    return dict(G=w["G"], Np=w["Np"], D=w["D"], fam=w["fam"], data=w["data"], dims=w["dims"], hyper=w["hyper"], pk=w["pk"], pa=w["pa"],
+                pb=w["pb"], pref=w["pref"], lo=w["lo"], hi=w["hi"], extra=extra, init=lambda P: w["init"](P, rng))
 
 
 def main():
