@@ -24,6 +24,7 @@
 
 #include "demc_kernels.hpp"
 #include "demc_longrow.hpp"
+#include "demc_resmvn.hpp"
 
 using namespace demc;
 
@@ -87,6 +88,10 @@ struct demc_handle {
     unsigned* st_err = nullptr;             // time-out flag (host-mapped, zero-copy)
     int n_cus = 0;
     int ainv_lds = 1;
+    // lean resident kernel of the default sampler on MvNormal-full (demc_resmvn.hpp): geometry for SUFFSTAT / STREAMING
+    bool lean_ok = false, lean_stream_ok = false;
+    int lean_wg = 0;
+    size_t lean_lds = 0, lean_stream_lds = 0;
     // update of a subset of the groups (demc_update_groups_async): two device lists used alternately, and the one in force
     // Each call takes the next of kGlistRing slots: a pinned host copy of the list, a device copy, and an event that marks
     // the host copy as consumed.  The device copy is refilled by a copy ON THE HANDLE'S STREAM, i.e. behind every kernel that
@@ -544,6 +549,71 @@ int launch_resident(demc_handle* h, long long iter0, int n_iters) {
     return DEMC_OK;
 }
 
+// ---- lean resident kernel (demc_resmvn.hpp): default sampler, MvNormal full Sigma, D = d <= 32, one pass per phase ----
+void plan_lean(demc_handle* h) {
+    const demc_config& c = h->c;
+    h->lean_ok = h->lean_stream_ok = false;
+    if (h->family != FAM_MVN_FULL || c.D != h->d || h->d > 32 || c.fuse != 0 || c.schedule != DEMC_SCHED_TWO_COLOUR ||
+        c.partner_kind != DEMC_PARTNER_CURRENT || c.Np < 4)
+        return;
+    if (const char* e = experiment("DEMC_LEAN"))  // A/B experiments
+        if (e[0] == '0') return;
+    if (h->n_seg < 1) return;  // (the prior table must fit its run-length form)
+    for (const DimTab& t : h->h_tab)
+        if (t.kind == PR_NORMAL_REF) return;  // (hierarchical scale priors: the general kernel)
+    const int nact_max = c.Np - c.Np / 2;
+    if (nact_max * 4 > 512) return;
+    const int wg = nact_max * 4 > 256 ? 512 : 256;
+    const size_t D = (size_t)c.D, Np = (size_t)c.Np;
+    const size_t base = (Np * D + Np + (size_t)nact_max + 16 + (size_t)(wg / 4) * (D + 2)) * sizeof(double);
+    if (c.loglike_mode == DEMC_LOGLIKE_SUFFSTAT) {
+        if (base > kMaxDynLds || !h->res_ok) return;
+        h->lean_ok = true; h->lean_wg = wg; h->lean_lds = base;
+        return;
+    }
+    // STREAMING: only where the streaming-resident form applies (plan_stream: small populations), and only with one wave per
+    // SIMD (256 threads: what the observation stage needs beyond 256 VGPRs then lives in AGPRs, not scratch)
+    if (!h->st_ok || wg != 256) return;
+    size_t bytes = base + ((size_t)(wg / 4) * h->dpad + (size_t)(wg / 64) * nact_max) * sizeof(double) +
+                   2 * sizeof(unsigned) * (size_t)h->st_C * nact_max + 16;
+    if (bytes > kMaxDynLds) return;
+    const size_t xbytes = (size_t)(h->st_chunk_tiles + 1) * (h->dpad / 4) * 64 * sizeof(double);
+    // (the X chunk rides in LDS exactly when plan_stream found room for it; this kernel's other buffers are no larger)
+    if (h->st_x_lds) {
+        if (bytes + xbytes > kMaxDynLds) return;
+        bytes += xbytes;
+    }
+    h->lean_stream_ok = true; h->lean_wg = wg; h->lean_stream_lds = bytes;
+}
+
+int launch_lean(demc_handle* h, long long iter0, int n_iters, bool stream) {
+    const demc_config& c = h->c;
+    KParams k = base_params(h);
+    k.iter = iter0; k.n_iters = n_iters; k.n_rows = h->hist ? c.n_rows : 0;
+    k.sx = stream ? nullptr : h->sx;
+    k.Ainv = h->Ainv;
+    if (stream) {
+        k.st_C = h->st_C; k.st_nact_max = h->st_nact_max; k.st_x_lds = h->st_x_lds; k.st_chunk_tiles = h->st_chunk_tiles;
+        k.n_tiles = h->n_tiles; k.Xf = h->Xf; k.st_gran = h->st_gran; k.st_err = h->st_err;
+        HIPCHK(hipMemsetAsync(h->st_gran, 0, 2 * (size_t)c.n_groups * h->st_C * h->st_nact_max * 2 * sizeof(unsigned long long), h->stream));
+        if (k.n_groups * h->st_C > h->n_cus) return fail(h, DEMC_EINVAL, "streaming-resident grid exceeds the CU count");
+    }
+    tick(h, 0, true);
+    const unsigned grid = (unsigned)(k.n_groups * (stream ? h->st_C : 1));
+    const size_t lds = stream ? h->lean_stream_lds : h->lean_lds;
+    // instances with the row length folded in (cfg3: 32, cfg2: 8) when the prior table is one segment
+    const int dt = (h->n_seg == 1 && (c.D == 32 || c.D == 8)) ? c.D : 0;
+    void (*fn)(KParams) = nullptr;
+    if (stream) fn = dt == 8 ? k_res_mvn<256, true, 8> : dt == 32 ? k_res_mvn<256, true, 32> : k_res_mvn<256, true, 0>;
+    else if (h->lean_wg == 512) fn = dt == 8 ? k_res_mvn<512, false, 8> : dt == 32 ? k_res_mvn<512, false, 32> : k_res_mvn<512, false, 0>;
+    else fn = dt == 8 ? k_res_mvn<256, false, 8> : dt == 32 ? k_res_mvn<256, false, 32> : k_res_mvn<256, false, 0>;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(h->lean_wg), lds, h->stream, k);
+    tick(h, 0, false);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, DEMC_EHIP, std::string("lean resident launch: ") + hipGetErrorString(e));
+    return DEMC_OK;
+}
+
 // ---- streaming-resident form: resident K1 with the observation stream inside (k_propose<..., STREAM>) ----
 // 256-thread form: one wave per SIMD, i.e. the whole register file (512 per lane, AGPRs included) behind each wave -- what does
 // not fit the 256 architectural VGPRs spills to AGPRs instead of scratch memory; 512 threads when a colour needs the lanes.
@@ -725,8 +795,15 @@ int size_k1_lds(demc_handle* h) {
                 HIPCHK(hipFuncSetAttribute((const void*)k1_stream_instance(wgs, tail, plain != 0),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
     HIPCHK(hipFuncSetAttribute((const void*)k_longrow<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
+    {
+        void (*lean[])(KParams) = {k_res_mvn<256, false, 0>, k_res_mvn<256, false, 8>, k_res_mvn<256, false, 32>,
+                                   k_res_mvn<512, false, 0>, k_res_mvn<512, false, 8>, k_res_mvn<512, false, 32>,
+                                   k_res_mvn<256, true, 0>,  k_res_mvn<256, true, 8>,  k_res_mvn<256, true, 32>};
+        for (auto f : lean) HIPCHK(hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
+    }
     plan_resident(h);
     plan_stream(h);
+    plan_lean(h);
     HIPCHK(hipFuncSetAttribute((const void*)k_mig_pack, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
     return DEMC_OK;
 }
@@ -1321,7 +1398,13 @@ static int32_t step_impl(demc_handle* h, int64_t iter0, int32_t n_iters, bool wi
             int run = 1;  // capped so that a single launch stays in the millisecond range whatever the caller asks for
             const int cap = st_ok ? 64 : 1024;
             while (run < cap && iter + run < iter0 + n_iters && !(with_migration && migration_due_h(h, iter + run))) ++run;
-            int rc = st_ok ? launch_stream(h, iter, run) : launch_resident(h, iter, run);
+            // the default sampler on MvNormal-full has a lean kernel of its own (same draws, same decisions)
+            KParams kp = base_params(h);
+            const bool plain = is_plain(h, kp);
+            int rc;
+            if (st_ok && plain && h->lean_stream_ok) rc = launch_lean(h, iter, run, true);
+            else if (!st_ok && plain && h->lean_ok) rc = launch_lean(h, iter, run, false);
+            else rc = st_ok ? launch_stream(h, iter, run) : launch_resident(h, iter, run);
             if (rc != DEMC_OK) return rc;
             iter += run - 1;
             continue;

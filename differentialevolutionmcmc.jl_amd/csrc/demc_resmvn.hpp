@@ -1,0 +1,458 @@
+// demc_resmvn.hpp -- the resident kernel of the DEFAULT sampler on the full-Sigma MvNormal family, written lean.
+//
+// k_propose's resident form (demc_kernels.hpp) carries every option of the sampler (snooker, recombination, block masks,
+// history partners, optimiser updates, traces, every model family, several passes per phase, any lane geometry); its colour
+// phase is a chain of ~12 dependent LDS / barrier steps with ~300 spilled scalars.  The BASELINE workloads cfg2 and cfg3 run
+// the reference's DEFAULTS (random_gamma, no snooker, kappa = 1, no blocks, Metropolis: DE(), structs.jl:80-101) on
+// MvNormal(mu, Sigma) with D = d <= 32 -- this file is that one case and nothing else:
+//   * four lanes per particle, ONE pass per colour phase (moving half <= WG/4 particles), a lane owns whole noise blocks
+//     (scalars 4m..4m+3, m = sl, sl+4, ...), so a phase draws one PART block and at most two NOISE blocks per lane;
+//   * theta' stays in REGISTERS from proposal to write-back; LDS sees it once, centred, for the transposition into MFMA
+//     operand order (y = Sigma^-1 (theta' - xbar) on v_mfma_f64_16x16x4_f64, one 16-particle tile per wave);
+//   * the group coin of every iteration of the launch is drawn once, at kernel start; bounds / prior table and A^-1
+//     fragments live in registers for the whole launch;
+//   * select_base: cumulative weights on the DPP network (wave_cdf) by wave 0 while the other waves draw, then a two-level
+//     search (chunk offsets, then inside the chunk);
+//   * SUFFSTAT: the whole update here.  STREAMING (STREAM = true): additionally the observation stream of the
+//     streaming-resident form (C workgroups per group, granule hand-over) -- same protocol as k_propose<...,STREAM>.
+// Same addressed draws and the same per-scalar arithmetic as k_propose: proposals and decisions are the ones the general
+// kernel produces (tests/test_gpu_parity.py::test_lean_resident_kernel_*); prior sums run in a different lane order
+// (log-densities equal to rounding).
+#pragma once
+#include "demc_kernels.hpp"
+
+namespace demc {
+
+// Rare paths kept OUT OF LINE: inlined into the unrolled per-scalar code they made the colour phase ~10 000 instructions of
+// straight-line code (eight copies each of log / sqrt / sincospi and of the whole prior switch) -- more than the instruction
+// cache holds, so every phase re-fetched its own code.  The common path (crossover proposal, Normal prior) is a few hundred.
+__device__ __attribute__((noinline)) double resmvn_prior_slow(const DimTab* t, double x) { return prior_term(*t, x, 0.0, 0.0); }
+// mutation noise of one dim pair (mutation.jl:15-18): Box-Muller on the pair's two 32-bit uniforms
+__device__ __attribute__((noinline)) double2 resmvn_box_muller(uint32_t w0, uint32_t w1) {
+    const double rad = sqrt(-2.0 * log(1.0 - u32unit(w0)));
+    double sn, cs;
+    sincospi(2.0 * u32unit(w1), &sn, &cs);
+    return make_double2(rad * cs, rad * sn);
+}
+
+// DT > 0: an instance for D = d = DT (a multiple of 4) with one table segment (32: BASELINE cfg3, 8: cfg2): every "is this
+// scalar inside the row" test, the ragged-block paths and the segment lookup fold away at compile time (the general instance,
+// DT = 0, spends a third of its proposal stage on that control flow).
+template <int WG, bool STREAM, int DT = 0>
+__global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(KParams p) {
+    extern __shared__ double lds[];
+    __shared__ unsigned char s_mut[1024];  // beta coin of every iteration of this launch (n_iters <= 1024)
+    __shared__ DimSeg s_seg[kMaxDimSeg];   // bounds / prior table, run-length encoded (usually ONE segment for this family)
+    for (int i = threadIdx.x; i < p.n_seg * (int)(sizeof(DimSeg) / sizeof(double)); i += WG)
+        reinterpret_cast<double*>(s_seg)[i] = reinterpret_cast<const double*>(p.dimseg)[i];
+    DEMC_STAMP_INIT();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = DT ? DT : p.D, Np = p.Np, d = DT ? DT : p.d;  // D == d
+    int g, c_idx = 0;
+    if (STREAM) {
+        if ((p.n_groups & 7) == 0) {
+            const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+            c_idx = j % p.st_C;
+            g = (j / p.st_C) * 8 + xcd;
+        } else {
+            g = blockIdx.x / p.st_C;
+            c_idx = blockIdx.x % p.st_C;
+        }
+    } else
+        g = blockIdx.x;
+    const int gi = g;
+    if (p.glist) g = p.glist[g];
+    const int g_glob = p.group_offset + g;
+    double* grows = p.theta + (size_t)g * Np * D;
+    double* gw = p.weight + (size_t)g * Np;
+    const bool wr_hbm = !STREAM || c_idx == 0;
+    const bool even = DT > 0 || (D & 1) == 0;
+    const int half = Np / 2, nact_max = Np - half;
+    // LDS: tile [Np][D] | weights [Np] | cdf [nact_max] + chunk offsets [16] | centred theta' rows [WG/4][D+2] |
+    //      STREAM: y rows [WG/4][dpad] | per-wave partials [WG/64][nact_max] | granule payloads [C][nact_max] u32x2 | X chunk
+    double* tile = lds;
+    double* w_s = tile + (size_t)Np * D;
+    double* cdf = w_s + Np;
+    double* coff = cdf + nact_max;
+    const int scr_stride = D + 2;
+    double* scr = coff + 16;
+    double* ybuf = scr + (size_t)(WG / 4) * scr_stride;
+    double* part_l = ybuf + (STREAM ? (size_t)(WG / 4) * p.dpad : 0);
+    unsigned* part_c = reinterpret_cast<unsigned*>(part_l + (STREAM ? (size_t)(WG / 64) * nact_max : 0));
+    double* xs = reinterpret_cast<double*>((reinterpret_cast<size_t>(part_c + (STREAM ? 2 * (size_t)p.st_C * nact_max : 0)) + 15) & ~(size_t)15);
+    const int xt_lo = STREAM ? c_idx * p.st_chunk_tiles : 0;
+    const int xt_hi = STREAM ? (xt_lo + p.st_chunk_tiles < p.n_tiles ? xt_lo + p.st_chunk_tiles : p.n_tiles) : 0;
+
+    // ---- once per launch: the group into LDS, the coins of every iteration, the loop-invariant tables into registers ----
+    if (even) {
+        const int n16 = (Np * D) >> 1;
+        for (int c0 = wave * 64; c0 < n16; c0 += WG)
+            if (c0 + lane < n16) lds_dma16(grows + 2 * (size_t)(c0 + lane), tile + 2 * (size_t)c0);
+    } else
+        for (int i = tid; i < Np * D; i += WG) tile[i] = grows[i];
+    for (int i = tid; i < Np; i += WG) w_s[i] = gw[i];
+    for (int i = tid; i < p.n_iters; i += WG) {
+        const U4 r = draw_block(p.seed, S_GROUP, 0, (uint64_t)(p.iter + i), (uint32_t)g_glob, 0);
+        s_mut[i] = u53(r.x, r.y) <= p.beta ? 1 : 0;  // mutate_or_crossover! main.jl:199-207
+    }
+    if (STREAM) {
+        for (int i = tid; i < (WG / 4) * p.dpad; i += WG) ybuf[i] = 0.0;
+        if (p.st_x_lds && xt_lo < xt_hi) {
+            const double* src = p.Xf + (size_t)xt_lo * (p.dpad >> 2) * 64;
+            const int n16 = ((xt_hi - xt_lo) * (p.dpad >> 2) * 64) >> 1;
+            for (int c0 = wave * 64; c0 < n16; c0 += WG)
+                if (c0 + lane < n16) lds_dma16(src + 2 * (size_t)(c0 + lane), xs + 2 * (size_t)c0);
+        }
+        if (p.st_x_lds)
+            for (int i = tid; i < (p.dpad >> 2) * 64; i += WG) xs[(size_t)p.st_chunk_tiles * (p.dpad >> 2) * 64 + i] = 0.0;
+    }
+    // lane geometry: particle slot q = tid / 4 of the pass, lane sl of the particle owns noise blocks m = sl and sl + 4,
+    // i.e. scalars 4 sl .. 4 sl + 3 and 16 + 4 sl .. 16 + 4 sl + 3 (D <= 32)
+    const int q = tid >> 2, sl = tid & 3;
+    const int jA = 4 * sl, jB = 16 + 4 * sl;  // first scalar of the lane's two blocks
+    // xbar of the lane's 8 scalars, and the table segment of each (4 bits apiece; the entries themselves stay in LDS)
+    double xb[8];
+    unsigned segs = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int j = (e < 4 ? jA : jB - 4) + e;
+        const int jj = j < D ? j : 0;
+        xb[e] = p.xbar[jj];
+        unsigned sg = 0;
+        for (int i = 1; i < p.n_seg; ++i) sg += (jj >= p.dimseg[i].start) ? 1u : 0u;
+        segs |= sg << (4 * e);
+    }
+    // A^-1 fragments for the MFMA preparation (B operand: k = 4 ks + (lane >> 4), column 16 nt + (lane & 15))
+    double bfrag[2][8];
+    {
+        const int kq = lane >> 4, col = lane & 15;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int k = 4 * ks + kq, c = 16 * nt + col;
+                bfrag[nt][ks] = (k < d && c < d) ? p.Ainv[k * d + c] : 0.0;
+            }
+    }
+    const int mc0 = lane & 15, mc1 = mc0 + 16;  // the two columns this lane sees of every MFMA result
+    const double sx0 = (p.sx && mc0 < d) ? p.sx[mc0] : 0.0, sx1 = (p.sx && mc1 < d) ? p.sx[mc1] : 0.0;
+    if (even || (STREAM && p.st_x_lds)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const double eps = p.eps, eps2 = p.eps - (-p.eps);
+    const long long n_steps = (long long)p.n_iters * 2;
+    for (long long step = 0; step < n_steps; ++step) {
+        DEMC_STAMP_RESET();
+        const int ph = (int)(step & 1);
+        const int it_rel = (int)(step >> 1);
+        const long long iter = p.iter + it_rel;
+        const int a_lo = ph ? half : 0, n_act = ph ? Np - half : half;
+        const int pool_lo = ph ? 0 : half, pool_n = ph ? half : Np - half;
+        const long long store_row = (p.hist && iter - 1 < p.n_rows) ? iter - 1 : -1;
+        const bool is_mut = s_mut[it_rel] != 0;
+        const bool use_base = !is_mut && iter <= p.burnin;  // crossover.jl:164
+        const bool valid = q < n_act;
+        const int pl = a_lo + (valid ? q : 0);
+        const size_t slot = (size_t)g * Np + pl;
+        const uint32_t eslot = (uint32_t)g_glob * (uint32_t)Np + (uint32_t)pl;
+
+        // ---- select_base's cumulative weights (wave 0) while the other waves draw ----
+        if (use_base && wave == 0) {
+            const double* pw = w_s + pool_lo;
+            double e[4], m = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e[r] = (lane + 64 * r < pool_n) ? pw[lane + 64 * r] : -INFINITY;
+                m = fmax(m, e[r]);
+            }
+            m = wave_max(m);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e[r] = (lane + 64 * r < pool_n) ? exp(e[r] - m) : 0.0;
+            if (pool_n <= 64) {
+                double e1[1] = {e[0]};
+                wave_cdf<1>(e1, pool_n);
+                e[0] = e1[0];
+            } else if (pool_n <= 128) {
+                double e2[2] = {e[0], e[1]};
+                wave_cdf<2>(e2, pool_n);
+                e[0] = e2[0]; e[1] = e2[1];
+            } else
+                wave_cdf<4>(e, pool_n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (lane + 64 * r < pool_n) cdf[lane + 64 * r] = e[r];
+        }
+        DEMC_STAMP(0);  // wave 0: cumulative weights in LDS
+        // ---- per-particle scalars: lane sl draws PART block sl, the quad shares them (crossover.jl:156-166, utilities.jl:57) ----
+        const U4 mine = draw_block(p.seed, S_PART, 0, (uint64_t)iter, eslot, (uint32_t)sl);
+        const U4 r0 = bcast_u4<0>(mine, 4, 0), ri = bcast_u4<1>(mine, 4, 0), rg = bcast_u4<2>(mine, 4, 0), ra = bcast_u4<3>(mine, 4, 0);
+        const double u_base = u53(r0.z, r0.w), u_acc = u53(ra.x, ra.y);
+        uint32_t ia, ib;
+        pick_pair(ri.x, ri.y, (uint32_t)pool_n, ia, ib);  // two_colour: the pool is the resting half, self is not in it
+        const double g1 = 0.5 + (1.0 - 0.5) * u53(rg.x, rg.y);
+        const double g2 = use_base ? 0.5 + (1.0 - 0.5) * u53(rg.z, rg.w) : 0.0;
+        // noise: block sl (scalars jA..jA+3) and block sl + 4 (scalars jB..jB+3)
+        const U4 nzA = draw_block(p.seed, S_NOISE, 0, (uint64_t)iter, eslot, (uint32_t)sl);
+        U4 nzB = nzA;
+        if (jB < D) nzB = draw_block(p.seed, S_NOISE, 0, (uint64_t)iter, eslot, (uint32_t)(sl + 4));
+        const uint32_t nw[8] = {nzA.x, nzA.y, nzA.z, nzA.w, nzB.x, nzB.y, nzB.z, nzB.w};
+
+        DEMC_STAMP(1);  // particle and noise blocks drawn
+        int ibase = 0;
+        if (use_base) {
+            lds_barrier();  // cdf visible
+            const double total = cdf[pool_n - 1];
+            if (!(total > 0.0) || !(total < INFINITY)) {
+                ibase = (int)(u_base * pool_n);
+                ibase = ibase < pool_n ? ibase : pool_n - 1;
+            } else {  // first i with cdf[i] >= t, else last: binary search (cdf is monotone)
+                const double t = u_base * total;
+                int lo = 0, hi = pool_n - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (cdf[mid] >= t) hi = mid; else lo = mid + 1;
+                }
+                ibase = lo;
+            }
+        }
+        DEMC_STAMP(4);  // base picked
+        // ---- proposal of the lane's 8 scalars, bounds, prior ----
+        const double* pt = tile + (size_t)pl * D;
+        const double* Pa = tile + (size_t)(pool_lo + (int)ia) * D;
+        const double* Pb = tile + (size_t)(pool_lo + (int)ib) * D;
+        const double* Pc = tile + (size_t)(pool_lo + ibase) * D;
+        double v8[8];
+        int oob = 0;
+        double prior = 0.0;
+        const bool one_seg = DT > 0 || p.n_seg == 1;  // the usual case for this family: every scalar shares one table entry
+        // ... which is then wave-uniform: through readfirstlane its fields sit in SGPRs and the switch on the prior kind is a
+        // scalar branch (as a per-lane value it compiles to one exec-masked region per prior kind and scalar)
+        auto uni = [](double x) {
+            return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+        };
+        DimTab tb1 = s_seg[0].t;
+        tb1.lo = uni(tb1.lo); tb1.hi = uni(tb1.hi); tb1.a = uni(tb1.a); tb1.b = uni(tb1.b); tb1.c = uni(tb1.c);
+        tb1.kind = __builtin_amdgcn_readfirstlane(tb1.kind);
+        auto load4 = [&](const double* row, int j0, double (&o)[4]) {  // four consecutive scalars of a tile row
+            if (even && j0 + 3 < D) {
+                const double2 a = *reinterpret_cast<const double2*>(row + j0), b = *reinterpret_cast<const double2*>(row + j0 + 2);
+                o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+            } else
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = j0 + e < D ? row[j0 + e] : 0.0;
+        };
+        double zz[8];  // mutation sweeps only: the standard normals of the lane's scalars
+        if (is_mut) {
+#pragma unroll
+            for (int pe = 0; pe < 4; ++pe) {
+                const double2 z = resmvn_box_muller(nw[2 * pe], nw[2 * pe + 1]);
+                zz[2 * pe] = z.x;
+                zz[2 * pe + 1] = z.y;
+            }
+        }
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int j0 = blk ? jB : jA;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v8[4 * blk + e] = 0.0;
+            if (j0 >= D) continue;
+            double tt[4], aa[4], bb[4], cc[4];
+            load4(pt, j0, tt);
+            if (!is_mut) {
+                load4(Pa, j0, aa);
+                load4(Pb, j0, bb);
+                if (use_base) load4(Pc, j0, cc);
+            }
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const int e = 4 * blk + e4, j = j0 + e4;
+                if (j < D) {
+                    const double tj = tt[e4];
+                    double v;
+                    if (is_mut)  // pt + Normal(0, sigma)  mutation.jl:15-18
+                        v = tj + p.sigma * zz[e];
+                    else {  // ((Pt + g1*(Pm-Pn)) + g2*(Pb-Pt)) + b  crossover.jl:168
+                        const double t1 = aa[e4] - bb[e4];
+                        double t6 = tj + t1 * g1;
+                        if (use_base) {
+                            const double t4 = cc[e4] - tj;
+                            t6 = t6 + t4 * g2;
+                        }
+                        v = t6 + (-eps + eps2 * u32unit(nw[e]));
+                    }
+                    v8[e] = v;
+                    if (one_seg) {
+                        oob |= !(v >= tb1.lo && v <= tb1.hi);  // in_bounds utilities.jl:70-78
+                        if (tb1.kind == PR_NORMAL) {
+                            const double z = (v - tb1.a) * tb1.b;
+                            prior += tb1.c - 0.5 * (z * z);
+                        } else if (tb1.kind != PR_FLAT)
+                            prior += resmvn_prior_slow(&tb1, v);
+                    } else {
+                        const DimTab* tb = &s_seg[(segs >> (4 * e)) & 15u].t;
+                        oob |= !(v >= tb->lo && v <= tb->hi);
+                        if (tb->kind != PR_FLAT) prior += resmvn_prior_slow(tb, v);
+                    }
+                }
+            }
+        }
+        DEMC_STAMP(5);  // proposal, bounds, prior of the lane's scalars
+        prior = subgroup_sum(prior, 4);
+        oob = subgroup_sum(oob, 4);
+        // ---- y = A^-1 (theta' - xbar) on the matrix cores: centred rows through LDS into operand order ----
+        {
+            double* row = scr + (size_t)q * scr_stride;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int j = (e < 4 ? jA : jB - 4) + e;
+                if (j < D) row[j] = v8[e] - xb[e];
+            }
+        }
+        wave_lds_sync();
+        double aux, S = 0.0;
+        {
+            const int kq = lane >> 4, rowi = lane & 15;
+            const int wrow0 = wave * 16;  // the wave's 16 particles are rows 0..15 of the A operand
+            const double* trow = scr + (size_t)(wrow0 + rowi) * scr_stride;
+            d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+            const bool two_tiles = d > 16;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                if (4 * ks < d) {
+                    const int k = 4 * ks + kq;
+                    const double a = k < d ? trow[k] : 0.0;
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[0][ks], acc0, 0, 0, 0);
+                    if (two_tiles) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[1][ks], acc1, 0, 0, 0);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pr = kq + 4 * r;
+                double* tr = scr + (size_t)(wrow0 + pr) * scr_stride;
+                const double y0 = mc0 < d ? acc0[r] : 0.0, y1 = mc1 < d ? acc1[r] : 0.0;
+                double a_ = 0.0, s_ = 0.0;
+                if (mc0 < d) a_ = fma(tr[mc0], y0, a_);
+                if (mc1 < d) a_ = fma(tr[mc1], y1, a_);
+                if (!STREAM)
+                    s_ = fma(y1, sx1, y0 * sx0);
+                else {
+                    double* yrow = ybuf + (size_t)(wrow0 + pr) * p.dpad;
+                    if (mc0 < d) yrow[mc0] = y0;
+                    if (mc1 < d) yrow[mc1] = y1;
+                }
+                a_ = subgroup_sum(a_, 16);
+                s_ = subgroup_sum(s_, 16);
+                if (rowi == 0) {
+                    tr[D] = a_;
+                    tr[D + 1] = s_;
+                }
+            }
+            wave_lds_sync();
+            aux = scr[(size_t)q * scr_stride + D];
+            if (!STREAM) S = scr[(size_t)q * scr_stride + D + 1];
+        }
+        DEMC_STAMP(7);  // A^-1 product and its dot products
+        if (STREAM) {
+            // ---- the observation stream: cross terms of the phase's proposals against this workgroup's chunk of tiles ----
+            __syncthreads();
+            {
+                const int nw_ = WG / 64;
+                const int nt = xt_hi - xt_lo, per_w = (nt + nw_ - 1) / nw_;
+                const int t_lo = wave * per_w < nt ? wave * per_w : nt, t_hi = t_lo + per_w < nt ? t_lo + per_w : nt;
+                lds_ptr outw = (lds_ptr)(part_l + (size_t)wave * nact_max);
+                if (p.st_x_lds)
+                    cross_stage<lds_cptr>((lds_cptr)ybuf, p.dpad, n_act, (lds_cptr)xs, t_lo, t_hi, p.st_chunk_tiles, outw, lane);
+                else
+                    cross_stage<glb_cptr>((lds_cptr)ybuf, p.dpad, n_act, (glb_cptr)(p.Xf + (size_t)xt_lo * (p.dpad >> 2) * 64), t_lo, t_hi,
+                                          p.n_tiles - xt_lo, outw, lane);
+            }
+            __syncthreads();
+            const unsigned epoch = (unsigned)(step + 1);
+            unsigned long long* gran = p.st_gran + (((size_t)(step & 1) * p.n_groups + gi) * p.st_C) * nact_max * 2;
+            if (tid < n_act) {
+                double v = 0.0;
+                for (int wv = 0; wv < WG / 64; ++wv) v += part_l[(size_t)wv * nact_max + tid];
+                unsigned long long* mine_g = gran + ((size_t)c_idx * nact_max + tid) * 2;
+                store_granule(mine_g, epoch, (unsigned)__double2loint(v));
+                store_granule(mine_g + 1, epoch, (unsigned)__double2hiint(v));
+            }
+            {
+                const int tot = p.st_C * n_act * 2;
+                unsigned spins = 0;
+                for (;;) {
+                    int ok = 1;
+                    for (int e = tid; e < tot; e += WG) {
+                        const int cc = e / (2 * n_act), r = e - cc * 2 * n_act;
+                        const unsigned long long x = load_granule(gran + (size_t)cc * nact_max * 2 + r);
+                        ok &= (unsigned)(x >> 32) == epoch;
+                        part_c[(size_t)cc * nact_max * 2 + r] = (unsigned)x;
+                    }
+                    if (__syncthreads_and(ok)) break;
+                    if (++spins > (1u << 22)) {
+                        if (tid == 0) *p.st_err = 1u;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            if (valid) {  // S = sum over the chunks, in chunk order: the same bits in every workgroup of the group
+                double acc_s = 0.0;
+                for (int cc = 0; cc < p.st_C; ++cc) {
+                    const unsigned* h2 = part_c + ((size_t)cc * nact_max + q) * 2;
+                    acc_s += __hiloint2double((int)h2[1], (int)h2[0]);
+                }
+                S = acc_s;
+            }
+        }
+        DEMC_STAMP(8);  // (STREAM: cross terms streamed and handed over)
+        // ---- compute_posterior! + mh_update! + store_samples! (utilities.jl:92-99, 55-58, 201-210, 161-180) ----
+        const double w = w_s[pl];
+        const double wp = oob ? -INFINITY : prior + (p.c0 - 0.5 * (p.c1 - 2.0 * S + (double)p.N * aux));
+        const double ex = exp(wp - w);
+        const int acc = (ex >= 1.0) || (u_acc <= ex);
+        if (valid) {
+            if (sl == 0) {
+                if (acc) {
+                    if (wr_hbm) p.weight[slot] = wp;
+                    w_s[pl] = wp;
+                }
+                if (store_row >= 0 && wr_hbm) {
+                    const size_t hrow = (size_t)store_row * p.P + slot;
+                    p.acc_hist[hrow] = (unsigned char)acc;
+                    p.lp_hist[hrow] = acc ? wp : w;
+                    p.id_hist[hrow] = (int)p.id[slot];
+                }
+            }
+            double* trow = p.theta + slot * D;
+            double* lrow = tile + (size_t)pl * D;
+            double* hrow = (store_row >= 0 && wr_hbm) ? p.hist + ((size_t)store_row * p.P + slot) * D : nullptr;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const int j = blk ? jB : jA;
+                if (j >= D) continue;
+                if (!acc && !hrow) continue;
+                if (j + 3 < D && (D & 3) == 0) {  // whole block: 32-byte accesses (a rejected particle's row comes from the tile)
+                    const double2 a01 = acc ? make_double2(v8[4 * blk], v8[4 * blk + 1]) : *reinterpret_cast<const double2*>(lrow + j);
+                    const double2 a23 = acc ? make_double2(v8[4 * blk + 2], v8[4 * blk + 3]) : *reinterpret_cast<const double2*>(lrow + j + 2);
+                    if (acc) {
+                        *reinterpret_cast<double2*>(lrow + j) = a01; *reinterpret_cast<double2*>(lrow + j + 2) = a23;
+                        if (wr_hbm) { *reinterpret_cast<double2*>(trow + j) = a01; *reinterpret_cast<double2*>(trow + j + 2) = a23; }
+                    }
+                    if (hrow) { *reinterpret_cast<double2*>(hrow + j) = a01; *reinterpret_cast<double2*>(hrow + j + 2) = a23; }
+                } else
+                    for (int e = 0; e < 4 && j + e < D; ++e) {
+                        const double x = acc ? v8[4 * blk + e] : lrow[j + e];
+                        if (acc) {
+                            lrow[j + e] = x;
+                            if (wr_hbm) trow[j + e] = x;
+                        }
+                        if (hrow) hrow[j + e] = x;
+                    }
+            }
+        }
+        DEMC_STAMP(9);  // accept + row moves
+        __syncthreads();  // the other colour reads what this phase wrote (rows, weights)
+        DEMC_STAMP(10);
+    }
+}
+
+}  // namespace demc

@@ -374,8 +374,41 @@ def test_plain_instance_equals_general_instance(demc, fuse):
     prob = make_problem("mvn_full", np.random.default_rng(63), N=300, d=12)
     th0 = prob["init"](8 * 40)
     a, b = (_run_fuse_mode(demc, prob, th0, fuse, 8, 40, 12, 25, alpha=0.3, burnin=10, loglike_mode=1, trace=tr) for tr in (0, 1))
-    for x, y in zip(a, b):
-        assert np.array_equal(x, y)
+    for i, (x, y) in enumerate(zip(a, b)):
+        if i in (2, 5) and fuse == 0:
+            # fuse = 0: the default sampler on MvNormal-full runs in its own lean resident kernel (demc_resmvn.hpp), whose lanes
+            # own different scalars: the prior sums run in another order (log-densities to rounding, everything else exact)
+            np.testing.assert_allclose(x, y, rtol=1e-12)
+        else:
+            assert np.array_equal(x, y), f"array {i}"
+
+
+@pytest.mark.parametrize("G,Np,d,N,mode,kw", [
+    (256, 256, 32, 2000, 1, dict()),                      # BASELINE cfg3 shape in SUFFSTAT mode: 512 threads, 128 particles per phase
+    (32, 64, 8, 10000, 0, dict()),                        # BASELINE cfg2: STREAMING, 8 workgroups per group
+    (5, 9, 7, 300, 1, dict(beta=0.5)),                    # odd everything, mutation in half of the sweeps
+    (6, 30, 31, 400, 0, dict()),                          # D = 31: ragged last noise block, STREAMING
+    (3, 20, 3, 100, 1, dict(lo=-0.5)),                    # D < 4: one lane per particle does all the work; a bound that bites
+    (300, 8, 16, 200, 1, dict()),                         # more groups than CUs
+])
+def test_lean_resident_kernel_equals_the_general_kernel(demc, G, Np, d, N, mode, kw):
+    """The default sampler on MvNormal-full (D = d <= 32, one pass per colour phase) has a lean resident kernel; trace = 1 selects
+    the general k_propose instances.  Same proposals, acceptances, ids and samples across burn-in (base term), mutation sweeps
+    and migrations; log-densities to rounding (prior sums in another lane order; STREAMING: same chunking)."""
+    kw = dict(kw)
+    prob = make_problem("mvn_full", np.random.default_rng(95), N=N, d=d)
+    lo = kw.pop("lo", None)
+    if lo is not None:
+        prob = dict(prob, lo=[lo] * d)
+    th0 = prob["init"](G * Np)
+    if lo is not None:
+        th0 = np.abs(th0)
+    a, b = (_run_fuse_mode(demc, prob, th0, 0, G, Np, d, 16, alpha=0.3, burnin=8, loglike_mode=mode, trace=tr, **kw) for tr in (0, 1))
+    for i, (x, y) in enumerate(zip(a, b)):
+        if i in (2, 5):
+            np.testing.assert_allclose(x, y, rtol=1e-11)
+        else:
+            assert np.array_equal(x, y), f"array {i}"
 
 
 def test_resident_form_over_a_grid_of_shapes(demc):
