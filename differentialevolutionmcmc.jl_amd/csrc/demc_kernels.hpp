@@ -437,6 +437,25 @@ __device__ inline double prior_term(const DimTab& t, double x, double inv_sref, 
     }
 }
 
+// Rare paths kept OUT OF LINE: inlined into the unrolled per-scalar code they made the colour phase ~10 000 instructions of
+// straight-line code (eight copies each of log / sqrt / sincospi and of the whole prior switch) -- more than the instruction
+// cache holds, so every phase re-fetched its own code.  The common path (crossover proposal, Normal prior) is a few hundred.
+__device__ __attribute__((noinline)) double prior_term_outofline(const DimTab* t, double x) { return prior_term(*t, x, 0.0, 0.0); }
+__device__ __attribute__((noinline)) double prior_term_ref_outofline(const DimTab* t, double x, double inv_sref, double log_sref) {
+    return prior_term(*t, x, inv_sref, log_sref);
+}
+__device__ __attribute__((noinline)) U4 draw_block_outofline(uint64_t seed, uint32_t stream, uint32_t sweep, uint64_t iter, uint32_t entity,
+                                                            uint32_t block) {
+    return draw_block(seed, stream, sweep, iter, entity, block);
+}
+// mutation noise of one dim pair (mutation.jl:15-18): Box-Muller on the pair's two 32-bit uniforms
+__device__ __attribute__((noinline)) double2 box_muller_outofline(uint32_t w0, uint32_t w1) {
+    const double rad = sqrt(-2.0 * log(1.0 - u32unit(w0)));
+    double sn, cs;
+    sincospi(2.0 * u32unit(w1), &sn, &cs);
+    return make_double2(rad * cs, rad * sn);
+}
+
 // In-kernel stamps (diagnostic build only: make STAMPS=1; tools/k1_stamps.py reads them back through the trace).
 // Thread 0 of every workgroup (as many as fit in the P-long trace array) stores the s_memtime delta since kernel start into tr_w[24*blockIdx.x + i]; the
 // product build compiles them away.

@@ -272,12 +272,10 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
             nz_block = k >> 1;
         }
         const double u0 = u32unit((k & 1) ? nz.z : nz.x), u1 = u32unit((k & 1) ? nz.w : nz.y);
-        if (kind == 2) {  // pt + Normal(0, sigma): mutation.jl:15-18
-            const double rad = sqrt(-2.0 * log(1.0 - u0));
-            double sn, cs;
-            sincospi(2.0 * u1, &sn, &cs);
-            v0 = in.t.x + p.sigma * (rad * cs);
-            v1 = in.t.y + p.sigma * (rad * sn);
+        if (kind == 2) {  // pt + Normal(0, sigma): mutation.jl:15-18 (rare sweep: out of line, see box_muller_outofline)
+            const double2 z = box_muller_outofline((k & 1) ? nz.z : nz.x, (k & 1) ? nz.w : nz.y);
+            v0 = in.t.x + p.sigma * z.x;
+            v1 = in.t.y + p.sigma * z.y;
             return;
         }
         auto cross = [&](double tj, double aj, double bj2, double cj, double uu) -> double {
@@ -299,7 +297,7 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
         if (has1) v1 = cross(in.t.y, in.a.y, in.b.y, in.c.y, u1);
         if (p.kappa != 1.0) {  // recombination! crossover.jl:301-312
             if (rc_block != (k >> 1)) {
-                rc = draw_block(p.seed, S_RECOMB, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)(k >> 1));
+                rc = draw_block_outofline(p.seed, S_RECOMB, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)(k >> 1));
                 rc_block = k >> 1;
             }
             if (u32unit((k & 1) ? rc.z : rc.x) <= 1.0 - p.kappa) v0 = in.t.x;
@@ -418,7 +416,14 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
             oob |= !(v >= t.lo && v <= t.hi);  // in_bounds utilities.jl:70-78 (NaN fails)
             if (p.fitness_kind == 0 && t.kind != PR_FLAT) {
                 const int q = e ? q1 : q0;
-                prior += prior_term(t, v, s_ref[0][q], s_ref[1][q]);
+                if (t.kind == PR_NORMAL_REF) {  // Normal(a, theta'[ref]): the bulk of a hierarchical row
+                    const double z = (v - t.a) * s_ref[0][q];
+                    prior += -(z * z + kLog2Pi) / 2.0 - s_ref[1][q];
+                } else if (t.kind == PR_NORMAL) {
+                    const double z = (v - t.a) * t.b;
+                    prior += t.c - 0.5 * (z * z);
+                } else
+                    prior += prior_term_ref_outofline(&s_seg[q].t, v, s_ref[0][q], s_ref[1][q]);  // (the entry in LDS: no local copy)
             }
             // likelihood term of the subject behind this scalar
             const long long s = (long long)j0 + e - 2;

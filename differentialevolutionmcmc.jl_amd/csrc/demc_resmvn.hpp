@@ -23,18 +23,6 @@
 
 namespace demc {
 
-// Rare paths kept OUT OF LINE: inlined into the unrolled per-scalar code they made the colour phase ~10 000 instructions of
-// straight-line code (eight copies each of log / sqrt / sincospi and of the whole prior switch) -- more than the instruction
-// cache holds, so every phase re-fetched its own code.  The common path (crossover proposal, Normal prior) is a few hundred.
-__device__ __attribute__((noinline)) double resmvn_prior_slow(const DimTab* t, double x) { return prior_term(*t, x, 0.0, 0.0); }
-// mutation noise of one dim pair (mutation.jl:15-18): Box-Muller on the pair's two 32-bit uniforms
-__device__ __attribute__((noinline)) double2 resmvn_box_muller(uint32_t w0, uint32_t w1) {
-    const double rad = sqrt(-2.0 * log(1.0 - u32unit(w0)));
-    double sn, cs;
-    sincospi(2.0 * u32unit(w1), &sn, &cs);
-    return make_double2(rad * cs, rad * sn);
-}
-
 // DT > 0: an instance for D = d = DT (a multiple of 4) with one table segment (32: BASELINE cfg3, 8: cfg2): every "is this
 // scalar inside the row" test, the ragged-block paths and the segment lookup fold away at compile time (the general instance,
 // DT = 0, spends a third of its proposal stage on that control flow).
@@ -245,7 +233,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
         if (is_mut) {
 #pragma unroll
             for (int pe = 0; pe < 4; ++pe) {
-                const double2 z = resmvn_box_muller(nw[2 * pe], nw[2 * pe + 1]);
+                const double2 z = box_muller_outofline(nw[2 * pe], nw[2 * pe + 1]);
                 zz[2 * pe] = z.x;
                 zz[2 * pe + 1] = z.y;
             }
@@ -287,11 +275,11 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
                             const double z = (v - tb1.a) * tb1.b;
                             prior += tb1.c - 0.5 * (z * z);
                         } else if (tb1.kind != PR_FLAT)
-                            prior += resmvn_prior_slow(&tb1, v);
+                            prior += prior_term_outofline(&s_seg[0].t, v);  // (the entry in LDS: a pointer to the register copy would spill it)
                     } else {
                         const DimTab* tb = &s_seg[(segs >> (4 * e)) & 15u].t;
                         oob |= !(v >= tb->lo && v <= tb->hi);
-                        if (tb->kind != PR_FLAT) prior += resmvn_prior_slow(tb, v);
+                        if (tb->kind != PR_FLAT) prior += prior_term_outofline(tb, v);
                     }
                 }
             }

@@ -24,7 +24,8 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STEPS, WARMUP = 20, 5
-DOMINANT = {("cfg3", "streaming"): "k_cross_mfma", ("cfg3", "suffstat"): "k_propose<", ("cfg2", "streaming"): "k_propose<",
+# (the default sampler on MvNormal-full runs in the lean resident kernel k_res_mvn; other samplers in k_propose<..., RES>)
+DOMINANT = {("cfg3", "streaming"): "k_cross_mfma", ("cfg3", "suffstat"): "k_res_mvn|k_propose<", ("cfg2", "streaming"): "k_res_mvn|k_propose<",
             ("cfg4", "streaming"): "k_longrow", ("cfg5", "streaming"): "k_obs_loglike"}
 MFMA_CTRS = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_F64", "SQ_INSTS_VALU_MFMA_MOPS_F64", "GRBM_GUI_ACTIVE",
              "SQ_WAVE_CYCLES", "SQ_INSTS_VALU"]
@@ -34,6 +35,8 @@ VALU_CTRS = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ
 
 def run(out_dir, tag, prof_args, bench_args):
     d = os.path.join(out_dir, tag)
+    if os.environ.get("COLLECT_REUSE") == "1" and glob.glob(os.path.join(d, "**", "*.csv"), recursive=True):
+        return d  # reduce the raw passes of an earlier collection again (no GPU needed)
     shutil.rmtree(d, ignore_errors=True)
     cmd = ["rocprofv3", "--kernel-trace"] + prof_args + ["--output-format", "csv", "-d", d, "--", "python3",
                                                         os.path.join(ROOT, "bench.py")] + bench_args
@@ -73,7 +76,11 @@ def short(name):
 def dominant_kernel(names, pat, resident):
     """the kernel of the run that matches the pattern: for k_propose, the resident / streaming-resident instance (its 4th
     template argument `true`) -- the initial evaluation runs in a non-resident instance and is not the roofline's subject"""
-    cand = [n for n in names if pat in n]
+    for alt in pat.split("|"):
+        cand = [n for n in names if alt in n]
+        if cand:
+            pat = alt
+            break
     if pat == "k_propose<" and resident:
         res = [n for n in cand if len(n.split(",")) >= 4 and n.split(",")[3].strip().startswith("true")]
         cand = res or cand
@@ -111,7 +118,7 @@ def main():
         dom = dominant_kernel(totals, DOMINANT[(cfg, mode)], resident=True)
         if dom:
             e = res[dom]
-            resident = DOMINANT[(cfg, mode)] == "k_propose<"
+            resident = "k_propose<" in DOMINANT[(cfg, mode)]
             rec = {"kernel": dom, "note": "HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 half-count of wide streaming reads)"}
             if resident:  # a launch covers several iterations: reduce to bytes per iteration over the whole run
                 rec["bytes_per_iteration"] = totals[dom] / (STEPS + WARMUP)
