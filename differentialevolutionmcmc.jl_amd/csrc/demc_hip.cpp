@@ -54,6 +54,10 @@ struct demc_handle {
     std::vector<DimTab> h_tab;  // host copy: bounds and priors arrive in separate calls
     DimSeg* dimseg = nullptr;   // run-length form of the table (kMaxDimSeg entries)
     int n_seg = 0;              // 0: more segments than kMaxDimSeg, the kernels read dimtab
+    int seg_start[kMaxDimSeg] = {0};
+    unsigned seg_plain = 0;     // segments with a flat / Normal / Normal(a, theta[ref]) prior
+    struct MaskRuns { int n = 0; unsigned in = 0; int start[kMaxMaskRun] = {0}; };
+    std::vector<MaskRuns> mask_runs;  // per block sweep: the mask run-length encoded (n = 0: too many runs)
     double *hist = nullptr, *lp_hist = nullptr, *mig_rows = nullptr, *scratch_theta = nullptr, *scratch_w = nullptr;
     long long* id = nullptr;
     unsigned char *prop_oob = nullptr, *tr_acc = nullptr, *masks = nullptr, *acc_hist = nullptr;
@@ -239,6 +243,10 @@ KParams base_params(demc_handle* h) {
     k.theta = h->theta; k.weight = h->weight; k.id = h->id; k.prop = h->prop; k.prop_prior = h->prop_prior;
     k.prop_adj = h->prop_adj; k.prop_oob = h->prop_oob; k.tr_idx = h->tr_idx; k.tr_w = h->tr_w; k.tr_acc = h->tr_acc;
     k.dimtab = h->dimtab; k.dimseg = h->dimseg; k.n_seg = h->n_seg; k.ainv_lds = h->ainv_lds; k.mask = nullptr;
+    std::memcpy(k.seg_start, h->seg_start, sizeof k.seg_start);
+    k.seg_plain = h->seg_plain;
+    std::memset(k.mrun_start, 0, sizeof k.mrun_start);
+    k.n_mrun = 1; k.mrun_in = 1u;  // no block mask: one run, inside
     k.hist = h->hist; k.acc_hist = h->acc_hist; k.lp_hist = h->lp_hist; k.id_hist = h->id_hist;
     k.P = h->P; k.store_row = -1; k.tile_in_lds = h->tile_in_lds;
     k.family = h->family; k.N = h->N; k.d = h->d; k.n_acc = h->n_acc; k.n_partials = 1;
@@ -459,6 +467,7 @@ int launch_phase(demc_handle* h, KParams& k) {
     if (k.lpp > 64 && h->hier_scr && k.fuse_obs && k.fuse_accept && k.mode == MODE_STEP && !h->rp_active && c.fuse != 2 && h->n_seg > 0) {
         const size_t lr_lds = ((((size_t)c.D + 1) & ~(size_t)1) + (size_t)k.pool_n + ((size_t)k.pool_n + 15) / 16) * sizeof(double);
         if (lr_lds <= kMaxDynLds) {
+            if (const char* e = experiment("DEMC_LR_EXIT")) k.n_split = -std::atoi(e);  // A/B experiments
             tick(h, 0, true);
             hipLaunchKernelGGL(k_longrow<512>, dim3((unsigned)n_prop), dim3(512), lr_lds, h->stream, k);
             tick(h, 0, false);
@@ -709,6 +718,12 @@ int run_sweep(demc_handle* h, long long iter, unsigned sweep, const unsigned cha
     const int Np = h->c.Np;
     KParams k = base_params(h);
     k.iter = iter; k.sweep = sweep; k.mask = mask; k.store_row = store_row;
+    if (mask && sweep < h->mask_runs.size()) {
+        const auto& mr = h->mask_runs[sweep];
+        k.n_mrun = mr.n; k.mrun_in = mr.in;
+        std::memcpy(k.mrun_start, mr.start, sizeof k.mrun_start);
+    } else if (mask)
+        k.n_mrun = 0;
     if (h->c.schedule == DEMC_SCHED_TWO_COLOUR) {
         const int half = Np / 2;
         k.a_lo = 0; k.n_act = half; k.pool_lo = half; k.pool_n = Np - half; k.exclude_self = 0;
@@ -1218,6 +1233,12 @@ static int upload_dimtab(demc_handle* h) {
         }
     }
     h->n_seg = n > 0 ? n : 0;
+    h->seg_plain = 0;
+    for (int q = 0; q < kMaxDimSeg; ++q) {
+        h->seg_start[q] = q < h->n_seg ? segs[q].start : 0;
+        const int kd = segs[q].t.kind;
+        if (q < h->n_seg && (kd == PR_FLAT || kd == PR_NORMAL || kd == PR_NORMAL_REF)) h->seg_plain |= 1u << q;
+    }
     HIPCHK(hipMemcpy(h->dimseg, segs, sizeof segs, hipMemcpyHostToDevice));
     return DEMC_OK;
 }
@@ -1270,6 +1291,19 @@ int32_t demc_set_blocks(demc_handle* h, const uint8_t* masks, int32_t n_blocks) 
     if (n_blocks > 0) {
         ALLOC(h->masks, (size_t)n_blocks * h->c.D);
         HIPCHK(hipMemcpy(h->masks, masks, (size_t)n_blocks * h->c.D, hipMemcpyHostToDevice));
+    }
+    h->mask_runs.assign((size_t)n_blocks, demc_handle::MaskRuns());
+    for (int b = 0; b < n_blocks; ++b) {  // run-length form of each mask (kernarg table of the long-row kernel)
+        auto& mr = h->mask_runs[(size_t)b];
+        const uint8_t* mk = masks + (size_t)b * h->c.D;
+        for (int j = 0; j < h->c.D; ++j)
+            if (j == 0 || (mk[j] != 0) != (mk[j - 1] != 0)) {
+                if (mr.n == kMaxMaskRun) { mr.n = -1; break; }
+                mr.start[mr.n] = j;
+                if (mk[j]) mr.in |= 1u << mr.n;
+                ++mr.n;
+            }
+        if (mr.n < 0) mr = demc_handle::MaskRuns();
     }
     return DEMC_OK;
     });

@@ -48,6 +48,7 @@ struct DimSeg {
     double pad2;
 };
 constexpr int kMaxDimSeg = 16;
+constexpr int kMaxMaskRun = 16;
 
 // Everything a sweep needs, passed by value as the kernarg.
 struct KParams {
@@ -140,6 +141,14 @@ struct KParams {
     const double* Xf;               // [n_tiles+1][dpad/4][64] fragment-ordered data (demc_set_model)
     unsigned long long* st_gran;    // [2][n_groups][st_C][st_nact_max][2] hand-over granules {epoch:32 | half of a double:32}
     unsigned* st_err;               // set to 1 if a hand-over timed out (never, with co-resident workgroups)
+    // run-length tables IN the kernarg (scalar loads, no memory behind them) for wave-uniform look-ups (demc_longrow.hpp):
+    // first scalars of the table segments; first scalars of the runs of the sweep's block mask, bit r of mrun_in = run r
+    // lies inside the block (no blocks: one run, inside); n_mrun = 0: more runs than kMaxMaskRun.  Bit q of seg_plain:
+    // segment q has a flat, Normal or Normal(a, theta[ref]) prior.
+    int seg_start[kMaxDimSeg];
+    int mrun_start[kMaxMaskRun];
+    int n_mrun;
+    unsigned mrun_in, seg_plain;
 };
 // a replayed uniform replaces the drawn one unless it is NaN
 __device__ inline double replayed(const double* tab, size_t i, double drawn) {
@@ -449,12 +458,13 @@ __device__ __attribute__((noinline)) U4 draw_block_outofline(uint64_t seed, uint
     return draw_block(seed, stream, sweep, iter, entity, block);
 }
 // mutation noise of one dim pair (mutation.jl:15-18): Box-Muller on the pair's two 32-bit uniforms
-__device__ __attribute__((noinline)) double2 box_muller_outofline(uint32_t w0, uint32_t w1) {
+__device__ inline double2 box_muller(uint32_t w0, uint32_t w1) {
     const double rad = sqrt(-2.0 * log(1.0 - u32unit(w0)));
     double sn, cs;
     sincospi(2.0 * u32unit(w1), &sn, &cs);
     return make_double2(rad * cs, rad * sn);
 }
+__device__ __attribute__((noinline)) double2 box_muller_outofline(uint32_t w0, uint32_t w1) { return box_muller(w0, w1); }
 
 // In-kernel stamps (diagnostic build only: make STAMPS=1; tools/k1_stamps.py reads them back through the trace).
 // Thread 0 of every workgroup (as many as fit in the P-long trace array) stores the s_memtime delta since kernel start into tr_w[24*blockIdx.x + i]; the
@@ -468,12 +478,21 @@ __device__ __attribute__((noinline)) double2 box_muller_outofline(uint32_t w0, u
         if (threadIdx.x == 0 && ((long long)blockIdx.x + 1) * 24 <= p.P)                                          \
             p.tr_w[blockIdx.x * 24 + (i)] = (double)(__builtin_amdgcn_s_memtime() - t_start__);                   \
     } while (0)
+#define DEMC_STAMP_AT(i, thr, val)                                                                                 \
+    do {                                                                                                           \
+        if (threadIdx.x == (thr) && ((long long)blockIdx.x + 1) * 24 <= p.P) p.tr_w[blockIdx.x * 24 + (i)] = (double)(val); \
+    } while (0)
+#define DEMC_STAMP_NOW() (__builtin_amdgcn_s_memtime() - t_start__)
 #define DEMC_STAMP_INIT() unsigned long long t_start__ = __builtin_amdgcn_s_memtime()
 #define DEMC_STAMP_RESET() t_start__ = __builtin_amdgcn_s_memtime()  // resident form: stamps are relative to the step's start
 #else
 #define DEMC_STAMP(i) \
     do {              \
     } while (0)
+#define DEMC_STAMP_AT(i, thr, val) \
+    do {                           \
+    } while (0)
+#define DEMC_STAMP_NOW() 0
 #define DEMC_STAMP_INIT() \
     do {                  \
     } while (0)

@@ -12,6 +12,11 @@
 //     shared through SGPRs -- no LDS, no barrier; the base pick (burn-in only) is the one step that waits for the group's
 //     cumulative weights, and the first batch of row loads and noise draws goes out before that wait.
 //   * Scalars outside the block of a block sweep (reset!, crossover.jl:336-352) cost neither noise draws nor partner loads.
+//   * A lane's unit of work is one noise block (four consecutive scalars).  When the 256 scalars of a wave's 64 blocks share
+//     one table segment, lie wholly inside or wholly outside the block of the sweep and all have a subject behind them --
+//     every wave of a hierarchical row except the first and the last -- the four scalars go through one branch-free body
+//     with the table entry in SGPRs (four independent softplus chains for the scheduler to interleave); the general
+//     per-pair body stays for the waves at the edges.  Sums are formed in the same order by both.
 // Same addressed draws, same arithmetic and the same lane -> dim-pair mapping as k_propose with a workgroup per particle,
 // so proposals, priors and decisions are the ones that kernel produces (tests/test_gpu_parity.py::test_longrow_*).
 //
@@ -33,8 +38,16 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
     __shared__ DimSeg s_seg[kMaxDimSeg];
     __shared__ int s_base;
     __shared__ double s_ref[2][kMaxDimSeg];
+    __shared__ double s_hyp[2];
     DEMC_STAMP_INIT();
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef DEMC_EXPERIMENTS  // (A/B build only: leave the kernel at a given point, to time what lies before it)
+#define DEMC_LR_EXIT(n) \
+    if (p.n_split == -(n)) return
+#else
+#define DEMC_LR_EXIT(n)
+#endif
+    DEMC_LR_EXIT(1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave: an SGPR)
     const int D = p.D, Np = p.Np;
     for (int i = tid; i < p.n_seg * (int)(sizeof(DimSeg) / sizeof(double)); i += WG)
         reinterpret_cast<double*>(s_seg)[i] = reinterpret_cast<const double*>(p.dimseg)[i];
@@ -131,7 +144,7 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
         }
     }
 
-    DEMC_STAMP(12);  // per-particle scalars drawn
+    DEMC_STAMP_AT(12, 64, DEMC_STAMP_NOW());  // per-particle scalars drawn (stamps: wave 1, a typical wave; wave 0 picks the base)
     // ---- select_base (crossover.jl:282-289) over the partner pool: stabilised softmax, cumulative weights in the fixed
     // two-level order shared with the oracle and k_propose (chunks of 16, sequential inside and over the chunks).  Wave 0
     // alone; the other waves go straight to their first row loads and noise draws and meet it at the barrier below.
@@ -219,7 +232,7 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
         double2 kk;          // hierarchical Binomial: counts of the pair's two subjects
         bool keep0, keep1;   // reset!: scalar outside the block of this sweep
     };
-    auto load_pair = [&](int k, bool with_base) -> PairIn {
+    auto load_pair = [&](int k, bool with_base, bool all_rows = false) -> PairIn {
         PairIn r;
         const int j0 = 2 * k;
         const bool has1 = j0 + 1 < D;
@@ -246,7 +259,8 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
         }
         // a scalar pair wholly outside the block keeps its values: no partner rows needed (mutation ignores the mask)
         // (a snooker proposal still needs its rows: adjust_loglike's norms run over every scalar, crossover.jl:268-273)
-        const bool frozen = kind == 0 && r.keep0 && (r.keep1 || !has1);
+        // (all_rows: the partner loads go out without waiting for the mask bytes -- the few general rounds of a fast sweep)
+        const bool frozen = !all_rows && kind == 0 && r.keep0 && (r.keep1 || !has1);
         if ((kind == 0 || kind == 1) && !frozen) {
             r.a = ld2(Pa);
             r.b = ld2(Pb2);
@@ -257,8 +271,24 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
     };
     U4 nz = {0, 0, 0, 0}, rc = nz;  // the noise / recombination block last drawn by this lane, and which one it is
     int nz_block = -1, rc_block = -1;
+    bool base_on = false;
+    auto cross = [&](double tj, double aj, double bj2, double cj, double uu) -> double {
+        const double bj = -eps + eps2 * uu;  // b = Uniform(-eps, eps) crossover.jl:166
+        if (kind == 1) {  // (Pt + gamma*(Pr1 - Pr2)) + b  crossover.jl:253
+            const double dj = tj - aj;
+            const double t1 = dj * cm - dj * cn;
+            return (tj + t1 * g1) + bj;
+        }
+        const double t1 = aj - bj2;  // ((Pt + g1*(Pm-Pn)) + g2*(Pb-Pt)) + b  crossover.jl:168
+        double t6 = tj + t1 * g1;
+        if (base_on) {
+            const double t4 = cj - tj;
+            t6 = t6 + t4 * g2;
+        }
+        return t6 + bj;
+    };
     // proposal of both scalars of pair k from loaded rows (recombination! and reset! applied)
-    auto propose_pair = [&](int k, const PairIn& in, bool base_on, double& v0, double& v1) {
+    auto propose_pair = [&](int k, const PairIn& in, double& v0, double& v1) {
         const int j0 = 2 * k, j1 = j0 + 1;
         const bool has1 = j1 < D;
         v0 = in.t.x; v1 = in.t.y;
@@ -278,21 +308,6 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
             v1 = in.t.y + p.sigma * z.y;
             return;
         }
-        auto cross = [&](double tj, double aj, double bj2, double cj, double uu) -> double {
-            const double bj = -eps + eps2 * uu;  // b = Uniform(-eps, eps) crossover.jl:166
-            if (kind == 1) {  // (Pt + gamma*(Pr1 - Pr2)) + b  crossover.jl:253
-                const double dj = tj - aj;
-                const double t1 = dj * cm - dj * cn;
-                return (tj + t1 * g1) + bj;
-            }
-            const double t1 = aj - bj2;  // ((Pt + g1*(Pm-Pn)) + g2*(Pb-Pt)) + b  crossover.jl:168
-            double t6 = tj + t1 * g1;
-            if (base_on) {
-                const double t4 = cj - tj;
-                t6 = t6 + t4 * g2;
-            }
-            return t6 + bj;
-        };
         v0 = cross(in.t.x, in.a.x, in.b.x, in.c.x, u0);
         if (has1) v1 = cross(in.t.y, in.a.y, in.b.y, in.c.y, u1);
         if (p.kappa != 1.0) {  // recombination! crossover.jl:301-312
@@ -307,14 +322,41 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
         if (keep1) v1 = in.t.y;
     };
 
-    // This lane's dim pairs, in the order it visits them: both pairs of noise block tid, then of block tid + WG, ...
+    // This lane's noise blocks, in the order it visits them: tid, tid + WG, ...; block m = dim pairs 2m and 2m + 1
+    const int n_blocks = (D + 3) >> 2;
     auto pair_at = [&](int i) -> int { return 2 * (tid + (i >> 1) * WG) + (i & 1); };
-    // first batch of row loads before anything waits: this lane's first pair (the base row follows once the pick is known)
-    const int k_first = 2 * tid;
-    const bool any = 2 * k_first < D;
-    PairIn cur = {};
-    if (any) cur = load_pair(k_first, false);
-
+    auto ld2_at = [&](const double* row, int k) -> double2 {
+        const int j0 = 2 * k;
+        return even ? *reinterpret_cast<const double2*>(row + j0) : make_double2(row[j0], j0 + 1 < D ? row[j0 + 1] : 0.0);
+    };
+    // ---- which body serves a wave's 64 blocks (scalars [j_lo, j_lo + 256)): the branch-free one when they are all there,
+    // share a table segment with a plain prior, have a subject each, and lie on one side of the sweep's block.  Decided
+    // from the run-length tables in the kernarg -- scalar loads and SALU only, nothing to wait for -- and remembered for
+    // the region [reg_lo, reg_hi) around the wave's position.  (No calls inside the branch-free body -- values live across
+    // a call are spilled around it: recombination, mutation and the rarer prior families take the general body.) ----
+    const bool fast_ok = even && (kind == 0 || kind == 1 || kind == 2) && !p.write_prop && (hier_b || hier_g) && p.kappa == 1.0 && p.n_mrun > 0;
+    int reg_lo = 0, reg_hi = 0, reg_q = 0;
+    bool reg_inb = false;
+    auto classify = [&](int j_lo, bool& inb, int& q) -> bool {
+        const int j_hi = j_lo + 255;
+        if (!(fast_ok && j_hi < D)) return false;
+        if (!(j_lo >= reg_lo && j_hi < reg_hi)) {
+            int qq = 0, r = 0;
+            for (int i = 1; i < p.n_seg; ++i) qq += (j_lo >= p.seg_start[i]) ? 1 : 0;
+            for (int i = 1; i < p.n_mrun; ++i) r += (j_lo >= p.mrun_start[i]) ? 1 : 0;
+            const int lo_s = p.seg_start[qq], hi_s = qq + 1 < p.n_seg ? p.seg_start[qq + 1] : D;
+            const int lo_m = p.mrun_start[r], hi_m = r + 1 < p.n_mrun ? p.mrun_start[r + 1] : D;
+            reg_q = qq;
+            reg_inb = ((p.mrun_in >> r) & 1u) != 0;
+            reg_lo = ((p.seg_plain >> qq) & 1u) ? (lo_s > lo_m ? lo_s : lo_m) : D;  // (other priors: an empty region)
+            reg_hi = hi_s < hi_m ? hi_s : hi_m;
+            reg_lo = reg_lo > 2 ? reg_lo : 2;  // scalar 2 + s belongs to subject s: a region holds scalars with subjects only
+            reg_hi = (long long)reg_hi < S + 2 ? reg_hi : (int)(S + 2);
+        }
+        inb = reg_inb;
+        q = reg_q;
+        return j_lo >= reg_lo && j_hi < reg_hi;
+    };
     // snooker: project(Pm,Pd), project(Pn,Pd) need whole-row dot products first (utilities.jl:239-246)
     if (kind == 1) {
         double vm = 0.0, vn = 0.0, vd = 0.0;
@@ -331,7 +373,7 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
     }
     DEMC_STAMP(0);  // wave 0: base pick done
     __syncthreads();  // base pick (wave 0), snooker partial sums, segment table
-    DEMC_STAMP(1);
+    DEMC_STAMP_AT(1, 64, DEMC_STAMP_NOW());
     if (kind == 1) {
         double vm = 0.0, vn = 0.0, vd = 0.0;
         // the tree k_propose's group_sum uses: pairs of waves, then pairs of pairs
@@ -343,45 +385,48 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
         cm = vm / vd; cn = vn / vd;
         __syncthreads();  // s_red is reused by the final reduction
     }
-    bool base_on = false;
     if (use_base) {
         i2 = s_base;
         Pbase = grows + (size_t)i2 * D;
         base_on = true;
-        if (any) {  // the one load that had to wait for the pick
-            const int j0 = 2 * k_first;
-            cur.c = even ? *reinterpret_cast<const double2*>(Pbase + j0) : make_double2(Pbase[j0], j0 + 1 < D ? Pbase[j0 + 1] : 0.0);
-        }
     }
 
-    // the hyper-parameter scalars: value of scalar j under the proposal (any lane may ask; pairs are cheap to re-propose)
-    auto value_of = [&](int j) -> double {
-        const PairIn in = load_pair(j >> 1, base_on);
-        double a0, a1;
-        propose_pair(j >> 1, in, base_on, a0, a1);
-        return (j & 1) ? a1 : a0;
-    };
+    // ---- the scalars every term depends on (the hyper-parameters theta'[0], the observation sd, the prior scales
+    // theta'[ref]): one lane proposes each (a proposal depends on the scalar's index only), LDS hands them round ----
+    {
+        int need = -1;
+        if (tid == 0) need = (hier_b || hier_g) ? 0 : -1;
+        else if (tid == 1) need = hier_g ? 2 + (int)S : -1;
+        else if (tid < 2 + p.n_seg && s_seg[tid - 2].t.kind == PR_NORMAL_REF) need = s_seg[tid - 2].t.ref;
+        if (need >= 0) {
+            const PairIn in = load_pair(need >> 1, base_on);
+            double a0, a1;
+            propose_pair(need >> 1, in, a0, a1);
+            const double val = (need & 1) ? a1 : a0;
+            if (tid < 2)
+                s_hyp[tid] = val;
+            else {  // Normal(a, theta'[ref]) priors (hierarchical scale): 1/scale and log scale per table segment, once
+                s_ref[0][tid - 2] = 1.0 / val;
+                s_ref[1][tid - 2] = log(val);
+            }
+        }
+    }
+    DEMC_STAMP(4);  // hyper-parameter scalars proposed (wave 0)
+    __syncthreads();
     // family constants of the fused likelihood term
     double mu0 = 0.0, sg_obs = 1.0, lsg_obs = 0.0, isg_obs = 1.0;
-    if (hier_b || hier_g) mu0 = value_of(0);
+    if (hier_b || hier_g) mu0 = s_hyp[0];
     if (hier_g) {
-        sg_obs = value_of(2 + (int)S);
+        sg_obs = s_hyp[1];
         lsg_obs = log(sg_obs);
         isg_obs = 1.0 / sg_obs;
     }
     const double n_bin = p.c0;
-    DEMC_STAMP(4);  // hyper-parameter scalars proposed
-
-    // Normal(a, theta'[ref]) priors (hierarchical scale): 1/scale and log scale per table segment, once
-    if (tid < p.n_seg && s_seg[tid].t.kind == PR_NORMAL_REF) {
-        const double sref = value_of(s_seg[tid].t.ref);
-        s_ref[0][tid] = 1.0 / sref;
-        s_ref[1][tid] = log(sref);
-    }
-    __syncthreads();
+    DEMC_LR_EXIT(2);
     int oob = 0;
     double prior = 0.0, like = 0.0, s1 = 0.0, s2 = 0.0;
     unsigned long long wbits = 0;  // which of this lane's pairs lie (partly) inside the block of the sweep
+    unsigned lbits = 0;            // which of its rounds were left to the scalar-per-lane step (their mask is read again)
     int n_done = 0;
     auto process = [&](int k, const PairIn& cur) {
         const int j0 = 2 * k;
@@ -400,7 +445,7 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
         }
         const DimTab tab0 = s_seg[q0].t, tab1 = s_seg[q1].t;
         double v0, v1;
-        propose_pair(k, cur, base_on, v0, v1);
+        propose_pair(k, cur, v0, v1);
         if (kind == 1) {  // adjust_loglike norms (crossover.jl:268-273)
             const double a0 = v0 - cur.a.x, b0 = cur.t.x - cur.a.x;
             s1 += a0 * a0; s2 += b0 * b0;
@@ -454,18 +499,267 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
             if (has1) p.prop[slot * D + j0 + 1] = v1;
         }
     };
-    // the rows of this lane's NEXT pair go out before the current pair's noise is drawn and its terms are formed.  (Deeper
-    // prefetch -- three pairs in flight -- was measured and gains nothing: the pass is bound by VALU issue, Philox rounds
-    // and the softplus of the likelihood, not by memory latency)
-    // (a block's second pair is missing only in the very last block of an odd-ish row, which ends its lane's sequence)
-    for (int i = 0; 2 * pair_at(i) < D; ++i) {
-        const int k = pair_at(i), kn = pair_at(i + 1);
-        PairIn nxt = cur;
-        if (2 * kn < D) nxt = load_pair(kn, base_on);
-        process(k, cur);
-        cur = nxt;
+    // ---- the pass over the row, wave by wave in SPANS: a wave's rounds i (blocks wave*64 + i*WG + lane) that stay inside one
+    // uniform region run in a tight loop compiled for what the region needs -- which rows, which proposal form, whether
+    // there are counts to load -- so that every round issues the same loads in the same order: the rows of the NEXT block go
+    // out first, and the compiler can wait for exactly the current block's (s_waitcnt vmcnt(n) with n = loads of a round)
+    // while they fly.  (With loads under run-time conditions it must wait for all of them, and did: the prefetch of round 1
+    // overlapped nothing.)  The last round of a span re-reads its own block in place of a next one.  Rounds outside a
+    // region (the first and the last blocks of a hierarchical row) take the general per-pair body, one block at a time. ----
+    auto uni = [](double x) {  // a wave-uniform value, held in SGPRs
+        return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+    };
+    const bool prior_on = p.fitness_kind == 0;
+    double T_lo = 0.0, T_hi = 0.0, T_a = 0.0, T_b = 0.0, T_c = 0.0, R_inv = 0.0, R_log = 0.0;  // the region's table entry
+    int T_kind = PR_FLAT;
+    int n_fast_blocks__ = 0;  // (diagnostic build)
+    enum { M_FROZEN = 0, M_SNK_FROZEN = 1, M_DE = 2, M_DE_BASE = 3, M_SNK = 4, M_MUT = 5 };
+    struct Blk {
+        double2 t0, t1, k0, k1, a0, a1, b0, b1, c0, c1;
+    };
+    auto run_span = [&](auto mode_c, auto hb_c, int i0, int i1) {
+        constexpr int MODE = decltype(mode_c)::value;
+        constexpr bool HB = decltype(hb_c)::value;
+        constexpr bool MOVES = MODE == M_DE || MODE == M_DE_BASE || MODE == M_SNK;
+        constexpr bool ROW_A = MODE != M_FROZEN && MODE != M_MUT, ROW_B = MODE == M_DE || MODE == M_DE_BASE, ROW_C = MODE == M_DE_BASE;
+        auto load = [&](int m) -> Blk {
+            Blk r;
+            const size_t o = 4 * (size_t)m;
+            r.t0 = *reinterpret_cast<const double2*>(pt + o);
+            r.t1 = *reinterpret_cast<const double2*>(pt + o + 2);
+            if constexpr (HB) {  // scalar 2 + s belongs to subject s
+                r.k0 = *reinterpret_cast<const double2*>(p.data + o - 2);
+                r.k1 = *reinterpret_cast<const double2*>(p.data + o);
+            }
+            if constexpr (ROW_A) {
+                r.a0 = *reinterpret_cast<const double2*>(Pa + o);
+                r.a1 = *reinterpret_cast<const double2*>(Pa + o + 2);
+            }
+            if constexpr (ROW_B) {
+                r.b0 = *reinterpret_cast<const double2*>(Pb2 + o);
+                r.b1 = *reinterpret_cast<const double2*>(Pb2 + o + 2);
+            }
+            if constexpr (ROW_C) {
+                r.c0 = *reinterpret_cast<const double2*>(Pbase + o);
+                r.c1 = *reinterpret_cast<const double2*>(Pbase + o + 2);
+            }
+            return r;
+        };
+        Blk cur = load(tid + i0 * WG);
+        for (int i = i0; i < i1; ++i) {
+            const int m = tid + i * WG;
+            const Blk nxt = load(tid + (i + 1 < i1 ? i + 1 : i) * WG);
+            ++n_fast_blocks__;
+            double v0 = cur.t0.x, v1 = cur.t0.y, v2 = cur.t1.x, v3 = cur.t1.y;
+            if constexpr (MODE == M_MUT) {  // pt + Normal(0, sigma) on every scalar: mutation.jl:15-18 (a group in ten takes this
+                // sweep -- and its workgroups set the length of the launch, so it runs in the span loops like the others)
+                const U4 nb = draw_block(p.seed, S_NOISE, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)m);
+                const double2 za = box_muller(nb.x, nb.y), zb = box_muller(nb.z, nb.w);
+                v0 = v0 + p.sigma * za.x;
+                v1 = v1 + p.sigma * za.y;
+                v2 = v2 + p.sigma * zb.x;
+                v3 = v3 + p.sigma * zb.y;
+            }
+            if constexpr (MOVES) {
+                const U4 nb = draw_block(p.seed, S_NOISE, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)m);
+                // b = Uniform(-eps, eps) crossover.jl:166
+                const double b0 = -eps + eps2 * u32unit(nb.x), b1 = -eps + eps2 * u32unit(nb.y);
+                const double b2 = -eps + eps2 * u32unit(nb.z), b3 = -eps + eps2 * u32unit(nb.w);
+                if constexpr (MODE == M_SNK) {  // (Pt + gamma*(Pr1 - Pr2)) + b  crossover.jl:253
+                    const double d0 = v0 - cur.a0.x, d1 = v1 - cur.a0.y, d2 = v2 - cur.a1.x, d3 = v3 - cur.a1.y;
+                    v0 = (v0 + (d0 * cm - d0 * cn) * g1) + b0;
+                    v1 = (v1 + (d1 * cm - d1 * cn) * g1) + b1;
+                    v2 = (v2 + (d2 * cm - d2 * cn) * g1) + b2;
+                    v3 = (v3 + (d3 * cm - d3 * cn) * g1) + b3;
+                } else if constexpr (MODE == M_DE_BASE) {  // ((Pt + g1*(Pm-Pn)) + g2*(Pb-Pt)) + b  crossover.jl:168
+                    v0 = ((v0 + (cur.a0.x - cur.b0.x) * g1) + (cur.c0.x - v0) * g2) + b0;
+                    v1 = ((v1 + (cur.a0.y - cur.b0.y) * g1) + (cur.c0.y - v1) * g2) + b1;
+                    v2 = ((v2 + (cur.a1.x - cur.b1.x) * g1) + (cur.c1.x - v2) * g2) + b2;
+                    v3 = ((v3 + (cur.a1.y - cur.b1.y) * g1) + (cur.c1.y - v3) * g2) + b3;
+                } else {
+                    v0 = (v0 + (cur.a0.x - cur.b0.x) * g1) + b0;
+                    v1 = (v1 + (cur.a0.y - cur.b0.y) * g1) + b1;
+                    v2 = (v2 + (cur.a1.x - cur.b1.x) * g1) + b2;
+                    v3 = (v3 + (cur.a1.y - cur.b1.y) * g1) + b3;
+                }
+            }
+            if (MOVES && i < 32) wbits |= 3ull << (2 * i);  // (pairs 2i, 2i + 1 of this lane's sequence)
+            if constexpr (MODE == M_SNK || MODE == M_SNK_FROZEN) {  // adjust_loglike norms (crossover.jl:268-273), scalar by scalar
+                const double a0 = v0 - cur.a0.x, b0 = cur.t0.x - cur.a0.x, a1 = v1 - cur.a0.y, b1 = cur.t0.y - cur.a0.y;
+                const double a2 = v2 - cur.a1.x, b2 = cur.t1.x - cur.a1.x, a3 = v3 - cur.a1.y, b3 = cur.t1.y - cur.a1.y;
+                s1 += a0 * a0; s2 += b0 * b0;
+                s1 += a1 * a1; s2 += b1 * b1;
+                s1 += a2 * a2; s2 += b2 * b2;
+                s1 += a3 * a3; s2 += b3 * b3;
+            }
+            oob |= (int)!(v0 >= T_lo && v0 <= T_hi) | (int)!(v1 >= T_lo && v1 <= T_hi) | (int)!(v2 >= T_lo && v2 <= T_hi) |
+                   (int)!(v3 >= T_lo && v3 <= T_hi);  // in_bounds utilities.jl:70-78 (NaN fails)
+            if (prior_on && T_kind != PR_FLAT) {
+                if (T_kind == PR_NORMAL_REF) {  // Normal(a, theta'[ref]): the bulk of a hierarchical row
+                    const double z0 = (v0 - T_a) * R_inv, z1 = (v1 - T_a) * R_inv, z2 = (v2 - T_a) * R_inv, z3 = (v3 - T_a) * R_inv;
+                    prior += -(z0 * z0 + kLog2Pi) / 2.0 - R_log;
+                    prior += -(z1 * z1 + kLog2Pi) / 2.0 - R_log;
+                    prior += -(z2 * z2 + kLog2Pi) / 2.0 - R_log;
+                    prior += -(z3 * z3 + kLog2Pi) / 2.0 - R_log;
+                } else {  // PR_NORMAL
+                    const double z0 = (v0 - T_a) * T_b, z1 = (v1 - T_a) * T_b, z2 = (v2 - T_a) * T_b, z3 = (v3 - T_a) * T_b;
+                    prior += T_c - 0.5 * (z0 * z0);
+                    prior += T_c - 0.5 * (z1 * z1);
+                    prior += T_c - 0.5 * (z2 * z2);
+                    prior += T_c - 0.5 * (z3 * z3);
+                }
+            }
+            if constexpr (HB) {  // k log p + (n-k) log(1-p), p = logistic(eta): four independent softplus chains
+                const double e0 = mu0 + v0, e1 = mu0 + v1, e2 = mu0 + v2, e3 = mu0 + v3;
+                const double l0 = -n_bin * softplus_fast(-e0) - (n_bin - cur.k0.x) * e0;
+                const double l1 = -n_bin * softplus_fast(-e1) - (n_bin - cur.k0.y) * e1;
+                const double l2 = -n_bin * softplus_fast(-e2) - (n_bin - cur.k1.x) * e2;
+                const double l3 = -n_bin * softplus_fast(-e3) - (n_bin - cur.k1.y) * e3;
+                like += l0; like += l1; like += l2; like += l3;
+            } else {  // Hierarchical_Example.jl:36-44: p.d observations per subject
+                const int n = p.d;
+                const double vv[4] = {v0, v1, v2, v3};
+                for (int e = 0; e < 4; ++e) {
+                    const double mu = mu0 + vv[e];
+                    const long long sb = (long long)4 * m + e - 2;
+                    double l = 0.0;
+                    for (int o = 0; o < n; ++o) {
+                        const double z = (p.data[sb * n + o] - mu) * isg_obs;
+                        l += -(z * z + kLog2Pi) / 2.0 - lsg_obs;
+                    }
+                    like += l;
+                }
+            }
+            *reinterpret_cast<double2*>(scr + 4 * m) = make_double2(v0, v1);
+            *reinterpret_cast<double2*>(scr + 4 * m + 2) = make_double2(v2, v3);
+            cur = nxt;
+        }
+    };
+    {
+        const int w0 = wave * 64;
+        const int n_it = n_blocks > w0 ? (n_blocks - w0 + WG - 1) / WG : 0;  // rounds of this wave
+        int i = 0;
+        while (i < n_it) {
+            if (i == 1) DEMC_STAMP_AT(7, 0, DEMC_STAMP_NOW());  // wave 0: first round done
+            const int j_lo = 4 * (w0 + i * WG);
+            bool inb = false;
+            int q = 0;
+            if (classify(j_lo, inb, q)) {
+                int i1 = i + (reg_hi - 256 - j_lo) / (4 * WG) + 1;  // rounds that stay inside the region
+                i1 = i1 < n_it ? i1 : n_it;
+                const DimTab t = s_seg[q].t;
+                T_lo = uni(t.lo); T_hi = uni(t.hi); T_a = uni(t.a); T_b = uni(t.b); T_c = uni(t.c);
+                T_kind = __builtin_amdgcn_readfirstlane(t.kind);
+                R_inv = uni(s_ref[0][q]); R_log = uni(s_ref[1][q]);
+                if (i + 1 < n_it) DEMC_STAMP_AT(8, WG - 64, DEMC_STAMP_NOW());  // last wave: entering its span
+                const int mode = kind == 2 ? M_MUT : kind == 1 ? (inb ? M_SNK : M_SNK_FROZEN) : (inb ? (base_on ? M_DE_BASE : M_DE) : M_FROZEN);
+                using std::integral_constant;
+                if (hier_b) {
+                    using HBT = integral_constant<bool, true>;
+                    if (mode == M_FROZEN) run_span(integral_constant<int, M_FROZEN>(), HBT(), i, i1);
+                    else if (mode == M_DE_BASE) run_span(integral_constant<int, M_DE_BASE>(), HBT(), i, i1);
+                    else if (mode == M_DE) run_span(integral_constant<int, M_DE>(), HBT(), i, i1);
+                    else if (mode == M_SNK) run_span(integral_constant<int, M_SNK>(), HBT(), i, i1);
+                    else if (mode == M_MUT) run_span(integral_constant<int, M_MUT>(), HBT(), i, i1);
+                    else run_span(integral_constant<int, M_SNK_FROZEN>(), HBT(), i, i1);
+                } else {
+                    using HBF = integral_constant<bool, false>;
+                    if (mode == M_FROZEN) run_span(integral_constant<int, M_FROZEN>(), HBF(), i, i1);
+                    else if (mode == M_DE_BASE) run_span(integral_constant<int, M_DE_BASE>(), HBF(), i, i1);
+                    else if (mode == M_DE) run_span(integral_constant<int, M_DE>(), HBF(), i, i1);
+                    else if (mode == M_SNK) run_span(integral_constant<int, M_SNK>(), HBF(), i, i1);
+                    else if (mode == M_MUT) run_span(integral_constant<int, M_MUT>(), HBF(), i, i1);
+                    else run_span(integral_constant<int, M_SNK_FROZEN>(), HBF(), i, i1);
+                }
+                i = i1;
+            } else if (fast_ok) {  // a round at the edge of a region: left to the scalar-per-lane step below
+                if (i < 32) lbits |= 1u << i;
+                ++i;
+            } else {
+                const int m = tid + i * WG;
+                n_done = 2 * i;
+#pragma nounroll
+                for (int h = 0; h < 2; ++h) {
+                    const int k = 2 * m + h;
+                    if (2 * k < D) {
+                        const PairIn in = load_pair(k, base_on);
+                        process(k, in);
+                    }
+                }
+                ++i;
+            }
+        }
     }
-    DEMC_STAMP(5);  // the pass over the row done
+    DEMC_LR_EXIT(3);
+    DEMC_STAMP_AT(15, 64, DEMC_STAMP_NOW());      // spans done
+    DEMC_STAMP_AT(13, 0, DEMC_STAMP_NOW());       // ... by wave 0
+    DEMC_STAMP_AT(14, WG - 64, DEMC_STAMP_NOW());  // ... by the last wave
+    // ---- the rounds at the edges of the regions (in a hierarchical row: the 256 scalars around the hyper-parameters and
+    // the ragged end), ONE SCALAR PER LANE: every term of a scalar by the lane that holds it, whatever its table entry, its
+    // side of the block and its subject.  Rounds are numbered along the row (round R = scalars [256 R, 256 R + 256), the
+    // R-th of them in wave R % (WG/64)); the left-over ones alternate between the two halves of the workgroup, so a row
+    // with two of them -- head and tail -- costs every wave one step. ----
+    if (fast_ok) {
+        const int n_rounds = (n_blocks + 63) >> 6;
+        int R = 0, r = 0;
+        while (R < n_rounds) {
+            bool inb;
+            int q;
+            if (classify(256 * R, inb, q)) {
+                R = reg_hi >> 8;  // first round not wholly below the region's end
+                continue;
+            }
+            if ((r & 1) == (wave >= WG / 128 ? 1 : 0)) {
+                for (int jj = tid & (WG / 2 - 1); jj < 256 && 256 * R + jj < D; jj += WG / 2) {
+                    const int j = 256 * R + jj;
+                    int qj = 0;
+                    for (int i = 1; i < p.n_seg; ++i) qj += (j >= s_seg[i].start) ? 1 : 0;
+                    const bool keep = p.mask ? !p.mask[j] : false;  // reset! (crossover.jl:336-352)
+                    const double tj = pt[j], aj = Pa[j], bj2 = Pb2[j], cj = kind == 0 && base_on ? Pbase[j] : tj;  // (mutation: all Pt)
+                    const long long sj = (long long)j - 2;  // the subject behind the scalar
+                    const bool subj = sj >= 0 && sj < S;
+                    const double kj = hier_b && subj ? p.data[sj] : 0.0;
+                    const U4 nb = draw_block(p.seed, S_NOISE, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)(j >> 2));
+                    const uint32_t wj = (j & 2) ? ((j & 1) ? nb.w : nb.z) : ((j & 1) ? nb.y : nb.x);
+                    double v;
+                    if (kind == 2) {  // mutation ignores the block (mutation.jl:15-18)
+                        const double2 z = box_muller_outofline((j & 2) ? nb.z : nb.x, (j & 2) ? nb.w : nb.y);
+                        v = tj + p.sigma * ((j & 1) ? z.y : z.x);
+                    } else
+                        v = keep ? tj : cross(tj, aj, bj2, cj, u32unit(wj));
+                    if (kind == 1) {  // adjust_loglike norms (crossover.jl:268-273)
+                        const double a0 = v - aj, b0 = tj - aj;
+                        s1 += a0 * a0; s2 += b0 * b0;
+                    }
+                    const DimTab* tb = &s_seg[qj].t;
+                    oob |= !(v >= tb->lo && v <= tb->hi);  // in_bounds utilities.jl:70-78 (NaN fails)
+                    if (prior_on && tb->kind != PR_FLAT) prior += prior_term_ref_outofline(tb, v, s_ref[0][qj], s_ref[1][qj]);
+                    if (subj) {
+                        if (hier_b) {
+                            const double eta = mu0 + v;
+                            like += -n_bin * softplus_fast(-eta) - (n_bin - kj) * eta;
+                        } else {
+                            const double mu = mu0 + v;
+                            const int n = p.d;
+                            double l = 0.0;
+                            for (int o = 0; o < n; ++o) {
+                                const double z = (p.data[sj * n + o] - mu) * isg_obs;
+                                l += -(z * z + kLog2Pi) / 2.0 - lsg_obs;
+                            }
+                            like += l;
+                        }
+                    }
+                    scr[j] = v;
+                }
+            }
+            ++r;
+            ++R;
+        }
+    }
+    DEMC_STAMP_AT(5, 64, DEMC_STAMP_NOW());  // the pass over the row done
+    DEMC_STAMP_AT(2, 64, n_fast_blocks__);
+    DEMC_STAMP_AT(3, 64, n_done);
+    DEMC_LR_EXIT(4);
     // ---- one reduction for everything: waves on the DPP network, then the fixed tree over the waves through LDS ----
     prior = subgroup_sum(prior, 64); like = subgroup_sum(like, 64); oob = subgroup_sum(oob, 64);
     if (kind == 1) { s1 = subgroup_sum(s1, 64); s2 = subgroup_sum(s2, 64); }
@@ -485,7 +779,7 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
     double adj = 0.0;
     if (kind == 1) adj = (double)(D - 1) * (0.5 * log(tree(s_red[2])) - 0.5 * log(tree(s_red[3])));
 
-    DEMC_STAMP(6);  // reductions done
+    DEMC_STAMP_AT(6, 64, DEMC_STAMP_NOW());  // reductions done
     // ---- compute_posterior! + mh_update! + store_samples! ----
     double wp;
     if (p.fitness_kind == 1)
@@ -509,6 +803,7 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
             p.id_hist[hrow] = (int)p.id[slot];
         }
     }
+    DEMC_LR_EXIT(5);
     double* trow = p.theta + slot * D;
     double* hrow = (p.store_row >= 0) ? p.hist + ((size_t)p.store_row * p.P + slot) * D : nullptr;
     if (acc || hrow) {
@@ -531,7 +826,8 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
                 v0 = pt[j0];
                 v1 = has1 ? pt[j0 + 1] : 0.0;
             }
-            const bool in_block = it < 64 ? ((wbits >> it) & 1ull) != 0 : (p.mask[j0] || (has1 && p.mask[j0 + 1]));
+            const bool noted = it < 64 && !((lbits >> (it >> 1)) & 1u);  // (wbits covers the rounds this lane went through itself)
+            const bool in_block = noted ? ((wbits >> it) & 1ull) != 0 : (!p.mask || p.mask[j0] || (has1 && p.mask[j0 + 1]));
             const bool wr = acc && (!masked || in_block);
             if (even) {
                 if (wr) *reinterpret_cast<double2*>(trow + j0) = make_double2(v0, v1);  // utilities.jl:204
@@ -542,7 +838,7 @@ __global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
             }
         }
     }
-    DEMC_STAMP(9);   // accept + row moves done
+    DEMC_STAMP_AT(9, 64, DEMC_STAMP_NOW());   // accept + row moves done
     DEMC_STAMP(10);
 }
 
