@@ -91,6 +91,8 @@ struct demc_handle {
     unsigned long long* st_gran = nullptr;  // hand-over granules (device)
     unsigned* st_err = nullptr;             // time-out flag (host-mapped, zero-copy)
     int n_cus = 0;
+    size_t lr_two_lds = 0;     // long-row kernel: the dynamic LDS size lr_two_fit was asked for
+    bool lr_two_fit = false;   // ... two 256-thread workgroups with that much LDS fit on a CU
     int ainv_lds = 1;
     // lean resident kernel of the default sampler on MvNormal-full (demc_resmvn.hpp): geometry for SUFFSTAT / STREAMING
     bool lean_ok = false, lean_stream_ok = false;
@@ -465,10 +467,26 @@ int launch_phase(demc_handle* h, KParams& k) {
     if (const char* e = experiment("DEMC_K1_PLAN")) k.plan = k.plan && e[0] == '1';  // A/B experiments
     // long rows of a hierarchical family, whole update fused: the dedicated one-pass kernel (demc_longrow.hpp)
     if (k.lpp > 64 && h->hier_scr && k.fuse_obs && k.fuse_accept && k.mode == MODE_STEP && !h->rp_active && c.fuse != 2 && h->n_seg > 0) {
-        const size_t lr_lds = ((((size_t)c.D + 1) & ~(size_t)1) + (size_t)k.pool_n + ((size_t)k.pool_n + 15) / 16) * sizeof(double);
+        const size_t cdf_doubles = k.pool_n > 256 ? (size_t)k.pool_n + ((size_t)k.pool_n + 15) / 16 : 0;
+        const size_t lr_lds = ((((size_t)c.D + 1) & ~(size_t)1) + cdf_doubles) * sizeof(double);
         if (lr_lds <= kMaxDynLds) {
             if (const char* e = experiment("DEMC_LR_EXIT")) k.n_split = -std::atoi(e);  // A/B experiments
+            // Enough moving particles for two workgroups per CU (counted on the geometry's groups, so that a shard takes the
+            // same form as the whole run): 256 threads each -- one wave per SIMD per workgroup, two particles per CU out of
+            // step, one's prologue and row moves under the other's pass -- when two rows fit in the CU's LDS.
+            if (h->lr_two_lds != lr_lds) {  // (asked once per row size)
+                int nb = 0;
+                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_longrow<256>, 256, lr_lds));
+                h->lr_two_lds = lr_lds;
+                h->lr_two_fit = nb >= 2;
+            }
+            const bool two_per_cu = (long long)h->geo_groups * k.n_act >= 2LL * h->n_cus && h->lr_two_fit;
+            int wg_lr = two_per_cu ? 256 : 512;
+            if (const char* e = experiment("DEMC_LR_WG")) wg_lr = std::atoi(e);  // A/B experiments
             tick(h, 0, true);
+            if (wg_lr == 256)
+                hipLaunchKernelGGL(k_longrow<256>, dim3((unsigned)n_prop), dim3(256), lr_lds, h->stream, k);
+            else
             hipLaunchKernelGGL(k_longrow<512>, dim3((unsigned)n_prop), dim3(512), lr_lds, h->stream, k);
             tick(h, 0, false);
             return DEMC_OK;
@@ -810,6 +828,7 @@ int size_k1_lds(demc_handle* h) {
                 HIPCHK(hipFuncSetAttribute((const void*)k1_stream_instance(wgs, tail, plain != 0),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
     HIPCHK(hipFuncSetAttribute((const void*)k_longrow<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
+    HIPCHK(hipFuncSetAttribute((const void*)k_longrow<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
     {
         void (*lean[])(KParams) = {k_res_mvn<256, false, 0>, k_res_mvn<256, false, 8>, k_res_mvn<256, false, 32>,
                                    k_res_mvn<512, false, 0>, k_res_mvn<512, false, 8>, k_res_mvn<512, false, 32>,

@@ -31,8 +31,9 @@ namespace demc {
 __device__ inline uint32_t wave_get(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
 
 template <int WG>
-__global__ __launch_bounds__(WG, 1) void k_longrow(KParams p) {
-    extern __shared__ double lds[];  // theta' of the particle [D (+1 if odd)] | cumulative pool weights [pool_n + chunks]
+__global__ __launch_bounds__(WG, 512 / WG) void k_longrow(KParams p) {
+    extern __shared__ double lds[];  // theta' of the particle [D (+1 if odd)] | cumulative pool weights [pool_n + chunks], the
+                                     // latter only for pools of more than 256 (smaller ones: in wave 0's registers)
     __shared__ double s_red[5][WG / 64];
     __shared__ int s_redi[WG / 64];
     __shared__ DimSeg s_seg[kMaxDimSeg];
