@@ -335,7 +335,7 @@ __global__ __launch_bounds__(WG, 512 / WG) void k_longrow(KParams p) {
     // from the run-length tables in the kernarg -- scalar loads and SALU only, nothing to wait for -- and remembered for
     // the region [reg_lo, reg_hi) around the wave's position.  (No calls inside the branch-free body -- values live across
     // a call are spilled around it: recombination, mutation and the rarer prior families take the general body.) ----
-    const bool fast_ok = even && (kind == 0 || kind == 1 || kind == 2) && !p.write_prop && (hier_b || hier_g) && p.kappa == 1.0 && p.n_mrun > 0;
+    const bool fast_ok = even && (kind == 0 || kind == 1 || kind == 2) && (hier_b || hier_g) && p.kappa == 1.0 && p.n_mrun > 0;
     int reg_lo = 0, reg_hi = 0, reg_q = 0;
     bool reg_inb = false;
     auto classify = [&](int j_lo, bool& inb, int& q) -> bool {
@@ -769,6 +769,9 @@ __global__ __launch_bounds__(WG, 512 / WG) void k_longrow(KParams p) {
         s_redi[wave] = oob;
     }
     __syncthreads();
+    // (trace / per-phase forms: the proposals go to HBM; the span loops leave that to this copy of the row held in LDS)
+    if (fast_ok && p.write_prop)
+        for (int j = tid; j < D; j += WG) p.prop[slot * D + j] = scr[j];
     auto tree = [&](const double* s) {
         const double lo = (s[0] + s[1]) + (s[2] + s[3]);
         return WG > 256 ? lo + ((s[4] + s[5]) + (s[6] + s[7])) : lo;

@@ -327,6 +327,37 @@ def test_longrow_kernel_against_the_oracle(demc, orc):
                    exact_de=False)
 
 
+def test_longrow_span_loops_against_the_oracle(demc, orc):
+    """the long-row kernel's forms, each teacher-forced against the oracle (the trace is on: proposals are compared scalar by
+    scalar): span loops per uniform region -- crossover with and without the base row (burn-in 2 of 4 iterations), snooker,
+    mutation (beta = 0.4), frozen rows of a block sweep -- with the rounds around the hyper-parameters and at the ragged end
+    done one scalar per lane; two 256-thread workgroups per CU (geometry_groups makes the moving particles outnumber twice
+    the CUs); a block mask with more runs than the kernarg table holds, and a long segment with a Cauchy prior (no span
+    loops: the general body / one scalar per lane throughout)."""
+    prob = make_problem("hier_binomial", np.random.default_rng(93), S=2600)
+    D = prob["D"]
+    m0 = np.zeros(D, np.uint8)
+    m0[:2] = 1
+    blocks = np.stack([m0, 1 - m0])
+    for geo in (0, 512):
+        teacher_forced(demc, orc, prob, n_iter=4, n_groups=2, Np=8, schedule=2, burnin=2, theta_snooker=0.3, beta=0.4,
+                       masks=blocks, exact_de=False, geometry_groups=geo)
+    teacher_forced(demc, orc, prob, n_iter=3, n_groups=2, Np=6, schedule=2, burnin=1, beta=0.3, exact_de=False)  # no blocks
+    stripes = (np.arange(D) // 37 % 2).astype(np.uint8)  # 70 runs
+    teacher_forced(demc, orc, prob, n_iter=3, n_groups=2, Np=6, schedule=2, burnin=1, theta_snooker=0.2,
+                   masks=np.stack([stripes, 1 - stripes]), exact_de=False)
+    cauchy = dict(prob)
+    cauchy["pk"] = [1, 2] + [5] * 1300 + [9] * 1300  # PR_CAUCHY on the second half of the subjects
+    teacher_forced(demc, orc, cauchy, n_iter=3, n_groups=2, Np=6, schedule=2, burnin=1, theta_snooker=0.2, masks=blocks,
+                   exact_de=False)
+    hg = make_problem("hier_gaussian", np.random.default_rng(94), S=1500, n=3)
+    mg = np.zeros(hg["D"], np.uint8)
+    mg[:2] = 1
+    mg[-1] = 1
+    teacher_forced(demc, orc, hg, n_iter=3, n_groups=2, Np=6, schedule=2, burnin=1, theta_snooker=0.2, beta=0.2,
+                   masks=np.stack([mg, 1 - mg]), exact_de=False)
+
+
 def test_streaming_resident_form_with_blocks_and_trace(demc, orc):
     """the streaming-resident kernel under block updates, and teacher-forced against the oracle with the trace on"""
     prob = make_problem("mvn_full", np.random.default_rng(82), N=500, d=6)
