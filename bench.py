@@ -181,7 +181,8 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
         byts = sweeps * (24.0 * D + 17.0 + 16.0 * S) * P * k_iters
         ach = byts / t_s / 1e9
         traffic, src = measured_traffic(a, n_launch, k_iters)
-        rf = dict(bound="hbm", kernel="k_longrow<512> (a workgroup per particle, one pass: proposal, prior, subject terms, accept, store)",
+        inst = "k_longrow<256>, two workgroups per CU" if P // 2 >= 512 else "k_longrow<512>"  # (launch_phase's rule, 256 CUs)
+        rf = dict(bound="hbm", kernel=inst + " (a workgroup per particle, one pass: proposal, prior, subject terms, accept, store)",
                   achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
                   bytes_counted=f"{sweeps} block sweeps x (24*D+17 + 16*S) per particle-update and iteration (SURVEY 8d)",
                   launch_ms=t_s / n_launch * 1e3, launches=n_launch, updates_per_launch=sweeps * P * k_iters / n_launch,

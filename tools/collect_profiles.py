@@ -3,7 +3,8 @@
 
     python3 tools/collect_profiles.py gpurun_out/profiles_rNN [combo ...]     # then copy the summaries into profiles/rNN/
 
-A combo is config:mode (default: every bench row -- cfg3:streaming cfg3:suffstat cfg2:streaming cfg4:streaming cfg5:streaming).
+A combo is config:mode[:flag=value,...] (default: every bench row -- cfg3:streaming cfg3:suffstat cfg2:streaming cfg4:streaming
+cfg5:streaming; extra bench flags name the variant, e.g. cfg4:streaming:n-groups=128 -> bench_cfg4_streaming_n-groups128_*).
 For each it runs `python3 bench.py --config C --mode M --steps 20 --warmup 5 --no-cpu-baseline --accuracy-iters 0`
   * under `rocprofv3 --kernel-trace --stats`                       -> bench_<C>_<M>_kernel_stats.csv and the bench line of that run,
   * under `--kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`  (separate passes, as MI355X_MICROARCH.md prescribes; FETCH_SIZE
@@ -91,11 +92,13 @@ def main():
     out_dir = os.path.abspath(sys.argv[1])
     os.makedirs(out_dir, exist_ok=True)
     combos = [tuple(c.split(":")) for c in sys.argv[2:]] or list(DOMINANT)
-    for cfg, mode in combos:
-        print(f"{cfg} {mode}", flush=True)
-        tag = f"{cfg}_{mode}"
+    for combo in combos:
+        cfg, mode = combo[:2]
+        extra = [kv.split("=") for kv in combo[2].split(",")] if len(combo) > 2 else []
+        print(f"{cfg} {mode} {extra}", flush=True)
+        tag = f"{cfg}_{mode}" + "".join(f"_{k}{v}" for k, v in extra)
         args = ["--config", cfg, "--mode", mode, "--steps", str(STEPS), "--warmup", str(WARMUP), "--no-cpu-baseline",
-                "--accuracy-iters", "0"]
+                "--accuracy-iters", "0"] + [x for k, v in extra for x in ("--" + k, v)]
         d = run(out_dir, f"{tag}_stats", ["--stats"], args)
         for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
             shutil.copy(f, os.path.join(out_dir, f"bench_{tag}_kernel_stats.csv"))
