@@ -11,6 +11,7 @@
 #include "../../include/demc.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <hip/hiprtc.h>
 
 #include <cmath>
@@ -38,6 +39,7 @@ namespace {
 struct Timed {
     hipEvent_t a, b;
     int cls;
+    bool started = false;  // a kernel of the bracket carries the events (LAUNCH_T)
 };
 
 }  // namespace
@@ -91,6 +93,7 @@ struct demc_handle {
     unsigned long long* st_gran = nullptr;  // hand-over granules (device)
     unsigned* st_err = nullptr;             // time-out flag (host-mapped, zero-copy)
     int n_cus = 0;
+    bool bracket_open = false;  // timing: between tick(begin) and tick(end) of a bracket whose kernels carry the events
     size_t lr_two_lds = 0;     // long-row kernel: the dynamic LDS size lr_two_fit was asked for
     bool lr_two_fit = false;   // ... two 256-thread workgroups with that much LDS fit on a CU
     int ainv_lds = 1;
@@ -192,7 +195,11 @@ int dev_alloc(demc_handle* h, T** p, size_t n) {
         if (rc_ != DEMC_OK) return rc_;        \
     } while (0)
 
-void tick(demc_handle* h, int cls, bool begin) {
+// Device time per kernel class (demc_timing_enable): the events of a bracket travel IN the dispatch packets of its kernels
+// (hipExtLaunchKernelGGL: start event on the first, stop event on every one -- the last record stands), so they read the
+// kernels' own begin / end timestamps and put no barrier packets between the launches.  (Events recorded around each launch
+// cost the cfg4 share 28 us per iteration of 160.)  `classic`: record the events around the bracket instead (module launch).
+void tick(demc_handle* h, int cls, bool begin, bool classic = false) {
     if (!h->timing) return;
     if (begin) {
         Timed t;
@@ -206,19 +213,37 @@ void tick(demc_handle* h, int cls, bool begin) {
         take(&t.a);
         take(&t.b);
         t.cls = cls;
-        hipEventRecord(t.a, h->stream);
+        if (classic) {
+            hipEventRecord(t.a, h->stream);
+            t.started = true;
+        }
         h->events.push_back(t);
-    } else
-        hipEventRecord(h->events.back().b, h->stream);
+        h->bracket_open = !classic;
+    } else {
+        if (classic) hipEventRecord(h->events.back().b, h->stream);
+        h->bracket_open = false;
+    }
 }
+
+#define LAUNCH_T(h, kern, grid, block, lds, ...)                                                                          \
+    do {                                                                                                                  \
+        if ((h)->timing && (h)->bracket_open) {                                                                           \
+            Timed& t__ = (h)->events.back();                                                                              \
+            hipExtLaunchKernelGGL(kern, grid, block, lds, (h)->stream, t__.started ? nullptr : t__.a, t__.b, 0, __VA_ARGS__); \
+            t__.started = true;                                                                                           \
+        } else                                                                                                            \
+            hipLaunchKernelGGL(kern, grid, block, lds, (h)->stream, __VA_ARGS__);                                         \
+    } while (0)
 
 void drain_events(demc_handle* h) {
     for (auto& t : h->events) {
-        hipEventSynchronize(t.b);
-        float ms = 0.f;
-        hipEventElapsedTime(&ms, t.a, t.b);
-        h->t_ms[t.cls] += ms;
-        h->t_n[t.cls] += 1;
+        if (t.started) {  // (a bracket may hold no launch at all)
+            hipEventSynchronize(t.b);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, t.a, t.b);
+            h->t_ms[t.cls] += ms;
+            h->t_n[t.cls] += 1;
+        }
         h->event_pool.push_back(t.a);
         h->event_pool.push_back(t.b);
     }
@@ -267,8 +292,7 @@ KParams base_params(demc_handle* h) {
 
 template <int KS>
 void launch_cross(demc_handle* h, const KParams& k, int grid, int k0, int n_chunks, int part0) {
-    hipLaunchKernelGGL((k_cross_mfma<KS, 4>), dim3(grid), dim3(256), 0, h->stream, k, h->Ypad, h->dpad, k0, h->Xf,
-                       h->n_tiles, n_chunks, part0);
+    LAUNCH_T(h, (k_cross_mfma<KS, 4>), dim3(grid), dim3(256), 0, k, h->Ypad, h->dpad, k0, h->Xf, h->n_tiles, n_chunks, part0);
 }
 
 // Kernarg of the JIT-compiled user-likelihood kernel; the same text is prepended to the user's source.
@@ -356,8 +380,8 @@ int launch_loglike(demc_handle* h, KParams& k) {
             if (want < 1 || h->family == FAM_RASTRIGIN) want = 1;
             const int n_chunks = (int)want;
             tick(h, 2, true);
-            hipLaunchKernelGGL(k_obs_loglike, dim3((unsigned)((n_prop + 255) / 256), (unsigned)n_chunks), dim3(256), 0,
-                               h->stream, k, n_chunks);
+            LAUNCH_T(h, k_obs_loglike, dim3((unsigned)((n_prop + 255) / 256), (unsigned)n_chunks), dim3(256), 0,
+                               k, n_chunks);
             tick(h, 2, false);
             k.n_partials = n_chunks;
         } break;
@@ -373,17 +397,17 @@ int launch_loglike(demc_handle* h, KParams& k) {
             u.data = h->data; u.hyper = h->user_hyper;
             size_t sz = sizeof u;
             void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &u, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-            tick(h, 2, true);
+            tick(h, 2, true, true);
             hipError_t e = hipModuleLaunchKernel(h->user_kernel, (unsigned)((n_prop + 255) / 256), (unsigned)want, 1, 256, 1, 1, 0,
                                                  h->stream, nullptr, cfg);
-            tick(h, 2, false);
+            tick(h, 2, false, true);
             if (e != hipSuccess) return fail(h, DEMC_EHIP, std::string("hipModuleLaunchKernel: ") + hipGetErrorString(e));
             k.n_partials = (int)want;
         } break;
         case FAM_HIER_BINOMIAL:
         case FAM_HIER_GAUSSIAN: {
             tick(h, 2, true);
-            hipLaunchKernelGGL(k_hier_loglike, dim3((unsigned)n_prop), dim3(256), 0, h->stream, k);
+            LAUNCH_T(h, k_hier_loglike, dim3((unsigned)n_prop), dim3(256), 0, k);
             tick(h, 2, false);
             k.n_partials = 1;
         } break;
@@ -485,9 +509,9 @@ int launch_phase(demc_handle* h, KParams& k) {
             if (const char* e = experiment("DEMC_LR_WG")) wg_lr = std::atoi(e);  // A/B experiments
             tick(h, 0, true);
             if (wg_lr == 256)
-                hipLaunchKernelGGL(k_longrow<256>, dim3((unsigned)n_prop), dim3(256), lr_lds, h->stream, k);
+                LAUNCH_T(h, k_longrow<256>, dim3((unsigned)n_prop), dim3(256), lr_lds, k);
             else
-            hipLaunchKernelGGL(k_longrow<512>, dim3((unsigned)n_prop), dim3(512), lr_lds, h->stream, k);
+            LAUNCH_T(h, k_longrow<512>, dim3((unsigned)n_prop), dim3(512), lr_lds, k);
             tick(h, 0, false);
             return DEMC_OK;
         }
@@ -495,13 +519,13 @@ int launch_phase(demc_handle* h, KParams& k) {
     tick(h, 0, true);
     const int tail = tail_of(k);
     const size_t lds = tile ? lds_tile + (k.plan ? plan_bytes : 0) : h->k1_lds - h->k1_tile_bytes;
-    hipLaunchKernelGGL(k1_instance(tile, tail, is_plain(h, k), wg), dim3(k.n_groups * n_split), dim3(wg), lds, h->stream, k);
+    LAUNCH_T(h, k1_instance(tile, tail, is_plain(h, k), wg), dim3(k.n_groups * n_split), dim3(wg), lds, k);
     tick(h, 0, false);
     if (k.fuse_accept) return DEMC_OK;
     int rc = launch_loglike(h, k);
     if (rc != DEMC_OK) return rc;
     tick(h, 3, true);
-    hipLaunchKernelGGL(k_accept_store, dim3((unsigned)((n_prop + ppp3 - 1) / ppp3)), dim3(256), 0, h->stream, k);
+    LAUNCH_T(h, k_accept_store, dim3((unsigned)((n_prop + ppp3 - 1) / ppp3)), dim3(256), 0, k);
     tick(h, 3, false);
     return DEMC_OK;
 }
@@ -570,8 +594,8 @@ int launch_resident(demc_handle* h, long long iter0, int n_iters) {
     k.plan = (k.lpp >= 4) ? 1 : 0;
     if (const char* e = experiment("DEMC_K1_PLAN")) k.plan = k.plan && e[0] == '1';  // A/B experiments
     tick(h, 0, true);
-    hipLaunchKernelGGL(k1_resident_instance(h->res_wg, tail_of(k), is_plain(h, k)), dim3(k.n_groups), dim3(h->res_wg), h->res_lds,
-                       h->stream, k);
+    LAUNCH_T(h, k1_resident_instance(h->res_wg, tail_of(k), is_plain(h, k)), dim3(k.n_groups), dim3(h->res_wg), h->res_lds,
+                       k);
     tick(h, 0, false);
     return DEMC_OK;
 }
@@ -634,7 +658,7 @@ int launch_lean(demc_handle* h, long long iter0, int n_iters, bool stream) {
     if (stream) fn = dt == 8 ? k_res_mvn<256, true, 8> : dt == 32 ? k_res_mvn<256, true, 32> : k_res_mvn<256, true, 0>;
     else if (h->lean_wg == 512) fn = dt == 8 ? k_res_mvn<512, false, 8> : dt == 32 ? k_res_mvn<512, false, 32> : k_res_mvn<512, false, 0>;
     else fn = dt == 8 ? k_res_mvn<256, false, 8> : dt == 32 ? k_res_mvn<256, false, 32> : k_res_mvn<256, false, 0>;
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(h->lean_wg), lds, h->stream, k);
+    LAUNCH_T(h, fn, dim3(grid), dim3(h->lean_wg), lds, k);
     tick(h, 0, false);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, DEMC_EHIP, std::string("lean resident launch: ") + hipGetErrorString(e));
@@ -723,8 +747,8 @@ int launch_stream(demc_handle* h, long long iter0, int n_iters) {
     // takes most of a CU's LDS) -- so a plain launch has the same residency as a cooperative one, without its launch-time
     // cost (+15-19 us, MI355X_MICROARCH.md "coop-launch"); every spin in the kernel is bounded regardless.
     if (c.n_groups * h->st_C > h->n_cus) return fail(h, DEMC_EINVAL, "streaming-resident grid exceeds the CU count");
-    hipLaunchKernelGGL(k1_stream_instance(h->st_wg, tail_of(k), is_plain(h, k)), dim3(c.n_groups * h->st_C), dim3(h->st_wg), h->st_lds,
-                       h->stream, k);
+    LAUNCH_T(h, k1_stream_instance(h->st_wg, tail_of(k), is_plain(h, k)), dim3(c.n_groups * h->st_C), dim3(h->st_wg), h->st_lds,
+                       k);
     const hipError_t e = hipGetLastError();
     tick(h, 0, false);
     if (e != hipSuccess) return fail(h, DEMC_EHIP, std::string("streaming-resident launch: ") + hipGetErrorString(e));
@@ -769,12 +793,12 @@ int migration_enqueue(demc_handle* h, long long iter, double* dev_rows, const do
     k.iter = iter;
     tick(h, 4, true);
     if (pack)
-        hipLaunchKernelGGL(k_mig_pack, dim3(h->c.n_groups), dim3(256),
-                           sizeof(double) * ((size_t)h->c.Np + ((size_t)h->c.Np + 15) / 16), h->stream, k, dev_rows);
+        LAUNCH_T(h, k_mig_pack, dim3(h->c.n_groups), dim3(256),
+                           sizeof(double) * ((size_t)h->c.Np + ((size_t)h->c.Np + 15) / 16), k, dev_rows);
     if (apply) {
         const int ngt = h->c.n_groups_total;
         const int grid = ngt < 64 ? ngt : 64;
-        hipLaunchKernelGGL(k_mig_apply, dim3(grid), dim3(256), 2 * sizeof(int) * (size_t)ngt, h->stream, k, dev_all_rows, ngt);
+        LAUNCH_T(h, k_mig_apply, dim3(grid), dim3(256), 2 * sizeof(int) * (size_t)ngt, k, dev_all_rows, ngt);
     }
     tick(h, 4, false);
     return DEMC_OK;
