@@ -115,11 +115,12 @@ def measured_traffic(a, launches, k_iters):
     (profiles/<round>/bench_<config>_<mode>_pmc.json, written by tools/collect_profiles.py: FETCH_SIZE and WRITE_SIZE in
     separate --pmc passes; FETCH_SIZE doubled -- on gfx950 it counts half the bytes of wide streaming reads,
     MI355X_MICROARCH.md, HBM section).  Resident kernels are recorded per iteration and scaled to this run's launches.
-    Only for the config's default shape; otherwise None.  NOT measured in the run that prints it (see traffic_source)."""
-    if a.n_groups is not None or a.Np is not None or a.nobs is not None or a.dim is not None or a.schedule != "two_colour" or a.fuse:
+    Only for shapes that were profiled (the config's default, or an --n-groups variant with a committed summary); otherwise None.  NOT measured in the run that prints it (see traffic_source)."""
+    if a.Np is not None or a.nobs is not None or a.dim is not None or a.schedule != "two_colour" or a.fuse:
         return None, None
+    variant = "" if a.n_groups is None else f"_n-groups{a.n_groups}"  # (tools/collect_profiles.py names flag variants so)
     for rnd in (PROFILE_ROUND,):
-        path = os.path.join(ROOT, "profiles", rnd, f"bench_{a.config}_{a.mode}_pmc.json")
+        path = os.path.join(ROOT, "profiles", rnd, f"bench_{a.config}_{a.mode}{variant}_pmc.json")
         try:
             rec = json.load(open(path))["dominant"]
         except (OSError, KeyError, ValueError):

@@ -50,8 +50,11 @@ __global__ __launch_bounds__(WG, 512 / WG) void k_longrow(KParams p) {
     DEMC_LR_EXIT(1);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave: an SGPR)
     const int D = p.D, Np = p.Np;
-    for (int i = tid; i < p.n_seg * (int)(sizeof(DimSeg) / sizeof(double)); i += WG)
-        reinterpret_cast<double*>(s_seg)[i] = reinterpret_cast<const double*>(p.dimseg)[i];
+    // the prior-table segments go to LDS: loaded now, stored just before the first barrier (no wait on a cold line here)
+    constexpr int kSegDoubles = (int)(sizeof(DimSeg) / sizeof(double));
+    static_assert(kMaxDimSeg * kSegDoubles <= WG, "one segment word per lane");
+    const bool seg_lane = tid < p.n_seg * kSegDoubles;
+    const double seg_word = seg_lane ? reinterpret_cast<const double*>(p.dimseg)[tid] : 0.0;
 
     // particle of this workgroup; the particles of a group share an XCD (their partner rows then share its L2)
     int g, qg;
@@ -75,15 +78,24 @@ __global__ __launch_bounds__(WG, 512 / WG) void k_longrow(KParams p) {
     double* cdf = lds + ((D + 1) & ~1);
     const bool even = (D & 1) == 0;
     const double w_cur = gw[pl];
+    DEMC_STAMP_AT(16, 64, DEMC_STAMP_NOW() + (unsigned long long)(D & 1));  // kernarg in, addresses formed
+    // the partner pool's weights for the base pick, asked for before anything else waits (wave 0, burn-in only)
+    const bool maybe_base = p.mode == MODE_STEP && p.proposal_kind == 0 && p.iter <= p.burnin && wave == 0 && p.pool_n <= 256;
+    double pw_r[4] = {0.0, 0.0, 0.0, 0.0};
+    if (maybe_base) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (lane + 64 * r < p.pool_n) pw_r[r] = gw[p.pool_lo + lane + 64 * r];
+    }
 
     // ---- per-particle scalars: lanes 0..5 of every wave evaluate one Philox block each, the words travel through SGPRs ----
-    bool is_mut = false;
-    {
-        const U4 r = draw_block(p.seed, S_GROUP, p.sweep, (uint64_t)p.iter, (uint32_t)g_glob, 0);
-        is_mut = p.mode == MODE_STEP && u53(r.x, r.y) <= p.beta;  // mutate_or_crossover! main.jl:199-207
-    }
+    // (lane 6 evaluates the group's block -- the coin of mutate_or_crossover! -- in the same pass)
     const bool hist_partners = p.partner_kind == 1;
-    const U4 mine = draw_block(p.seed, S_PART, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)(lane < 6 ? lane : 0));
+    const bool glane = lane == 6;
+    const U4 mine = draw_block(p.seed, glane ? S_GROUP : S_PART, p.sweep, (uint64_t)p.iter, glane ? (uint32_t)g_glob : eslot,
+                               (uint32_t)(lane < 6 ? lane : 0));
+    const bool is_mut = p.mode == MODE_STEP && u53(wave_get(mine.x, 6), wave_get(mine.y, 6)) <= p.beta;  // main.jl:199-207
+    DEMC_STAMP_AT(17, 64, DEMC_STAMP_NOW() + (unsigned long long)(is_mut ? 1 : 0));  // Philox block of the per-particle scalars done
     const double u_snk = u53(wave_get(mine.x, 0), wave_get(mine.y, 0)), u_base = u53(wave_get(mine.z, 0), wave_get(mine.w, 0));
     const uint32_t ri0 = wave_get(mine.x, 1), ri1 = wave_get(mine.y, 1), ri2 = wave_get(mine.z, 1);
     const double u_g1 = u53(wave_get(mine.x, 2), wave_get(mine.y, 2)), u_g2 = u53(wave_get(mine.z, 2), wave_get(mine.w, 2));
@@ -153,13 +165,18 @@ __global__ __launch_bounds__(WG, 512 / WG) void k_longrow(KParams p) {
     if (use_base && wave == 0) {
         const double* pw = gw + p.pool_lo;
         double m = -INFINITY;
-        for (int i = lane; i < n_cdf; i += 64) m = fmax(m, pw[i]);
+        if (n_cdf <= 256) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (lane + 64 * r < n_cdf) m = fmax(m, pw_r[r]);
+        } else
+            for (int i = lane; i < n_cdf; i += 64) m = fmax(m, pw[i]);
         m = wave_max(m);
         int b;
         if (n_cdf <= 256) {  // the usual case: the pool sits in this wave's registers, no LDS round trips (wave_cdf)
             double e[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) e[r] = (lane + 64 * r < n_cdf) ? exp(pw[lane + 64 * r] - m) : 0.0;
+            for (int r = 0; r < 4; ++r) e[r] = (lane + 64 * r < n_cdf) ? exp(pw_r[r] - m) : 0.0;
             if (n_cdf <= 64) {
                 double e1[1] = {e[0]};
                 wave_cdf<1>(e1, n_cdf);
@@ -373,6 +390,7 @@ __global__ __launch_bounds__(WG, 512 / WG) void k_longrow(KParams p) {
         if (lane == 0) { s_red[0][wave] = vm; s_red[1][wave] = vn; s_red[2][wave] = vd; }
     }
     DEMC_STAMP(0);  // wave 0: base pick done
+    if (seg_lane) reinterpret_cast<double*>(s_seg)[tid] = seg_word;
     __syncthreads();  // base pick (wave 0), snooker partial sums, segment table
     DEMC_STAMP_AT(1, 64, DEMC_STAMP_NOW());
     if (kind == 1) {

@@ -63,7 +63,8 @@ names = ["softmax prefix sums done (tile in flight)", "plan written; tile landed
 if a.config:  # k_longrow (demc_longrow.hpp): wave 1's stamps, a typical wave (wave 0 also picks the base)
     m = np.median(full, 0)
     print(f"{len(full)} workgroups of k_longrow; cycles since kernel start (median over workgroups), wave 1 unless noted")
-    for label, v in (("per-particle scalars drawn", m[12]), ("wave 0: base picked", m[0]), ("past the first barrier", m[1]),
+    for label, v in (("kernarg in, addresses formed", m[16]), ("Philox block of the per-particle scalars", m[17]),
+                     ("per-particle scalars drawn", m[12]), ("wave 0: base picked", m[0]), ("past the first barrier", m[1]),
                      ("wave 0: hyper-parameter scalars proposed", m[4]), ("spans done", m[15]), ("... by wave 0", m[13]), ("... by the last wave", m[14]),
                      ("rounds at the edges done (one scalar per lane)", m[5]), ("reductions done (slowest wave in)", m[6]), ("accept + row moves done", m[9])):
         print(f"  {label:45s} {v:9.0f}")
