@@ -226,3 +226,29 @@ def test_repeat_runs_agree_bit_for_bit(demc):
                 e.close()
                 sigs.add(hashlib.md5(b"".join(np.ascontiguousarray(p).tobytes() for p in parts)).hexdigest())
             assert len(sigs) == 1, (case.id, fuse)
+
+
+def test_longrow_repeat_runs_agree_bit_for_bit(demc):
+    """the long-row kernel (span loops, edge rounds one scalar per lane, either workgroup size) twice on fresh handles:
+    the same bits in state, history and chain export"""
+    import hashlib
+    for fam, kw, extra in (("hier_binomial", dict(S=2600), dict(theta_snooker=0.3, beta=0.3)),
+                           ("hier_binomial", dict(S=2600), dict(geometry_groups=512)),
+                           ("hier_gaussian", dict(S=1500, n=3), dict(kappa=0.8))):
+        prob = make_problem(fam, np.random.default_rng(5), **kw)
+        D = prob["D"]
+        m0 = np.zeros(D, np.uint8)
+        m0[:2] = 1
+        th0 = prob["init"](3 * 10)
+        sigs = set()
+        for _ in range(2):
+            e = demc.HipEngine(D=D, n_groups=3, Np=10, n_rows=10, trace=0, burnin=4, seed=77, n_blocks=2, **extra)
+            setup_engine(e, prob)
+            e.set_blocks(np.stack([m0, 1 - m0]))
+            e.set_state(th0)
+            e.step(1, 10)
+            parts = list(e.get_state()) + list(e.get_history(0, 10)) + [e.export_chains(0, 10)]
+            e.close()
+            sigs.add(hashlib.md5(b"".join(np.ascontiguousarray(q).tobytes() for q in parts)).hexdigest())
+        assert len(sigs) == 1, (fam, extra)
+
