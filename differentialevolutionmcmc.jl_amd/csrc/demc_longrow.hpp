@@ -4,21 +4,28 @@
 // hierarchical likelihood, Metropolis accept, state and history write-back), like k_propose's fused tail -- but built for
 // rows that stream from HBM/L2 instead of an LDS tile:
 //   * ONE pass over the row.  The proposal of scalar j, its prior term AND the likelihood term of the subject behind it are
-//     formed together; the few scalars every term needs (the hyper-parameters: theta'[0], theta'[ref], the observation sd)
-//     are proposed first by every lane for itself.  k_propose makes two passes (proposal, then the subjects from an LDS copy).
-//   * The row loads of a lane's NEXT dim pair (current row, partners, base row, subject data) are issued before the Philox
-//     rounds and the arithmetic of the current pair, so a lane always has one round trip to L2/HBM in flight.
-//   * The per-particle scalars (coins, partner indices, gammas, accept uniform) are drawn by four lanes of every wave and
-//     shared through SGPRs -- no LDS, no barrier; the base pick (burn-in only) is the one step that waits for the group's
-//     cumulative weights, and the first batch of row loads and noise draws goes out before that wait.
-//   * Scalars outside the block of a block sweep (reset!, crossover.jl:336-352) cost neither noise draws nor partner loads.
-//   * A lane's unit of work is one noise block (four consecutive scalars).  When the 256 scalars of a wave's 64 blocks share
-//     one table segment, lie wholly inside or wholly outside the block of the sweep and all have a subject behind them --
-//     every wave of a hierarchical row except the first and the last -- the four scalars go through one branch-free body
-//     with the table entry in SGPRs (four independent softplus chains for the scheduler to interleave); the general
-//     per-pair body stays for the waves at the edges.  Sums are formed in the same order by both.
-// Same addressed draws, same arithmetic and the same lane -> dim-pair mapping as k_propose with a workgroup per particle,
-// so proposals, priors and decisions are the ones that kernel produces (tests/test_gpu_parity.py::test_longrow_*).
+//     formed together, theta' parked in LDS for the row moves; the few scalars every term needs (the hyper-parameters:
+//     theta'[0], theta'[ref], the observation sd) are proposed first, one lane each, and handed round through LDS.
+//     k_propose makes two passes (proposal, then the subjects from an LDS copy).
+//   * The pass runs wave by wave in SPANS.  A lane's unit of work is one noise block (four consecutive scalars), a wave's
+//     round 64 blocks.  Rounds that lie inside one uniform region -- one table segment with a plain prior, one side of the
+//     sweep's block, a subject behind every scalar: all of a hierarchical row but its two ends -- run in a loop compiled
+//     for what the region needs (run_span: frozen row, crossover with / without the base row, snooker moving / frozen,
+//     mutation; with or without Binomial counts): the same loads in the same order every round, the next block's rows
+//     requested before the current block's arithmetic, the table entry in SGPRs, four independent softplus chains.  The
+//     static shape is what lets the compiler wait for the current block only (s_waitcnt vmcnt(n)); with the loads under
+//     run-time conditions it waits for all of them and the prefetch overlaps nothing.
+//   * Regions are found from run-length tables in the kernarg (segment starts, runs of the block mask): scalar loads and
+//     SALU.  The rounds at the ends of regions are done one scalar per lane by all waves together; a sweep the span loops
+//     do not cover (recombination, an odd D, more mask runs than the table holds) takes the general per-pair body, which
+//     skips the noise draws and partner loads of scalars outside the block (reset!, crossover.jl:336-352).
+//   * The per-particle scalars (coins, partner indices, gammas, accept uniform, the group's mutation coin) are drawn by
+//     seven lanes of every wave and shared through SGPRs -- no LDS, no barrier; the base pick (burn-in only) is done by
+//     wave 0 in registers.
+//   * 512 threads per workgroup, or 256 with two workgroups per CU when the launch has that many (launch_phase).
+// Same addressed draws and the same arithmetic per scalar as k_propose with a workgroup per particle: proposals and decisions
+// are the ones that kernel produces; the sums of the prior and likelihood terms run in another order (tests/
+// test_gpu_parity.py::test_longrow_*).
 //
 // Reference: crossover!/snooker_update!/mutation!/recombination!/reset!/in_bounds/compute_posterior!/mh_update!/
 // store_samples! (crossover.jl:30-99,154-257,301-352; mutation.jl:13-25; utilities.jl:70-99,161-180,201-226).
