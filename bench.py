@@ -194,13 +194,23 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
         t_s = tm["loglike"]["ms"] * 1e-3
         n_launch = max(1, tm["loglike"]["launches"])
         evals = float(N) * P * k_iters
-        # algorithmic FP64 flop per (trial, proposal): per accumulator 2 x (phi, Phi) pairs = 2 x [exp ~ 24 + erfcx
-        # polynomial 2*(deg+1) + 8] + density/cdf algebra 14, plus the product, floor and log ~ 30  
-        flop_per_eval = na * (2 * (24 + 2 * 13 + 8) + 14) + 30
+        # executed FP64 flop per (trial, proposal): per accumulator 2 x (phi, Phi) pairs = 2 x [two degree-8 polynomials
+        # 2*2*8 + interval look-up 6] + density/cdf algebra 14, plus the product, floor and log ~ 30  (DESIGN section 5).
+        # (Round 2 replaced the exp + erfcx form, 420 flop per evaluation, by the Phi / phi tables: fewer flop AND less time --
+        # the flop fraction fell while the evaluations per second rose; the pipe counters say how busy the VALU is.)
+        flop_per_eval = na * (2 * (2 * 2 * 8 + 6) + 14) + 30
         ach = evals * flop_per_eval / t_s / 1e12
-        rf = dict(bound="valu", kernel="k_obs_loglike (LBA: thread per proposal, wave-uniform trial loads, erfcx table in LDS)",
+        busy, busy_src = None, None
+        try:
+            pj = os.path.join(ROOT, "profiles", PROFILE_ROUND, f"bench_{a.config}_{a.mode}_pipe_pmc.json")
+            busy = [v["valu_busy_frac"] for k, v in json.load(open(pj)).items() if "k_obs_loglike" in k][0]
+            busy_src = f"profiles/{PROFILE_ROUND}/{os.path.basename(pj)} (rocprofv3 --pmc pass of this command, not this run)"
+        except (OSError, KeyError, ValueError, IndexError):
+            pass
+        rf = dict(bound="valu", kernel="k_obs_loglike (LBA: thread per proposal, wave-uniform trial loads, Phi / phi polynomial tables in LDS)",
                   achieved=ach, peak=PEAK_FP64_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP64_TFLOPS,
                   flop_counted=f"{flop_per_eval} FP64 flop per (trial, proposal) evaluation x N x proposals",
+                  valu_busy_frac=busy, valu_busy_source=busy_src,
                   trial_proposal_evaluations_per_s=evals / t_s, launch_ms=t_s / n_launch * 1e3, launches=n_launch,
                   updates_per_launch=P * k_iters / n_launch, traffic=None, traffic_source=None, wasted_traffic_ratio=None)
     rf["timing"] = "HIP events recorded on the timed iterations, on the stream the kernels run on"

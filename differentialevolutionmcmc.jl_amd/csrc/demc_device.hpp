@@ -15,6 +15,7 @@
 #include <cmath>
 
 #include "demc_erfcx_table.hpp"
+#include "demc_phi_table.hpp"
 
 namespace demc {
 
@@ -165,12 +166,26 @@ __device__ inline double erfcx_pos(const double* tab, double y) {
     for (int k = kErfcxDeg - 1; k >= 0; --k) r = fma(r, dz, a[k]);
     return r;
 }
-// phi(x) and Phi(x) from ONE exponential: Phi(-|x|) = 0.5 erfcx(|x|/sqrt2) exp(-x^2/2)
-__device__ inline void phi_Phi(const double* tab, double x, double& ph, double& Ph) {
-    const double e = exp(-0.5 * x * x);
-    ph = e * kInvSqrt2Pi;
-    const double r = 0.5 * erfcx_pos(tab, fabs(x) * kInvSqrt2) * e;
-    Ph = x < 0.0 ? r : 1.0 - r;
+// phi(z) and Phi(z) from the generated piecewise polynomials (tools/gen_phi_table.py: absolute error 1.1e-16, z clamped to
+// [-8.5, 8.5] beyond which both are 0 / 1 in double precision): two degree-8 Horner chains on one interval look-up, no exp.
+// For sums of order one -- the LBA density and distribution function -- where absolute accuracy is what counts; the
+// log-survival of the LNR keeps the exp + erfcx form (relative accuracy in the tail).  tab points at a copy of kPhiTable.
+// A NaN argument gives NaN.
+__device__ inline void phi_Phi_table(const double* tab, double z, double& ph, double& Ph) {
+    double zc = z < -kPhiZmax ? -kPhiZmax : z;
+    zc = zc > kPhiZmax ? kPhiZmax : zc;
+    int idx = (int)((zc + kPhiZmax) * (double)kPhiPerUnit);
+    idx = idx < kPhiIntervals - 1 ? idx : kPhiIntervals - 1;
+    const double dz = zc - fma((double)idx + 0.5, 1.0 / kPhiPerUnit, -kPhiZmax);
+    const double* a = tab + idx * (2 * (kPhiDeg + 1));
+    double P = a[kPhiDeg], q = a[2 * kPhiDeg + 1];
+#pragma unroll
+    for (int k = kPhiDeg - 1; k >= 0; --k) {
+        P = fma(P, dz, a[k]);
+        q = fma(q, dz, a[kPhiDeg + 1 + k]);
+    }
+    Ph = P;
+    ph = q;
 }
 // log Phi(-z) (log-survival of a standard normal), finite far into the tail
 __device__ inline double log_Phi_neg(const double* tab, double z) {
@@ -181,12 +196,13 @@ __device__ inline double log_Phi_neg(const double* tab, double z) {
 // LBA (Examples/Run_LBA.jl:33-37; SequentialSamplingModels conventions: b = A + k, sigma = 1,
 // normalised by 1 - P(all drifts <= 0), density floored at 1e-10)
 // density and distribution function of one accumulator at decision time t, sharing the four phi / Phi values
+// (tab: kPhiTable)
 __device__ inline void lba_dens_cdf(const double* tab, double v, double b, double A, double t, double inv_t, double inv_A,
                                     double& dens, double& cdf) {
     const double n1 = (b - A) * inv_t - v, n2 = b * inv_t - v;  // (b - A - t v)/t, (b - t v)/t
     double p1, P1, p2, P2;
-    phi_Phi(tab, n1, p1, P1);
-    phi_Phi(tab, n2, p2, P2);
+    phi_Phi_table(tab, n1, p1, P1);
+    phi_Phi_table(tab, n2, p2, P2);
     dens = inv_A * (v * (P2 - P1) + (p1 - p2));
     cdf = 1.0 + (t * inv_A) * ((n1 * P1 - n2 * P2) + (p1 - p2));
 }

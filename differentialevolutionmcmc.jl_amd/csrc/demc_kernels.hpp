@@ -244,8 +244,8 @@ __device__ inline double loglike_from_stats(const KParams& p, double s, double a
 }
 
 // Sum over observations i = i0, i0+stride, ... < i1 of the per-observation statistic of one proposal `th`
-// (Gaussian: z^2; Binomial / LBA / LNR: the log-density; rastrigin: the objective on i == 0).  tab = erfcx table (LDS)
-// or nullptr for the families that do not need it.
+// (Gaussian: z^2; Binomial / LBA / LNR: the log-density; rastrigin: the objective on i == 0).  tab = the family's table in
+// LDS (LBA: kPhiTable, LNR: kErfcxTable) or nullptr for the families that do not need one.
 __device__ inline double obs_range_sum(const KParams& p, const double* th, long long i0, long long i1, int stride,
                                        const double* tab) {
     double acc = 0.0;
@@ -276,7 +276,7 @@ __device__ inline double obs_range_sum(const KParams& p, const double* th, long 
             double pneg = 1.0;
             for (int a = 0; a < na; ++a) {
                 double ph, Ph;
-                phi_Phi(tab, -nu[a], ph, Ph);
+                phi_Phi_table(tab, -nu[a], ph, Ph);
                 pneg *= Ph;
             }
             const double inv = 1.0 / (1.0 - pneg);
@@ -1784,9 +1784,14 @@ __global__ __launch_bounds__(256, 2) void k_cross_mfma(KParams p, const double* 
 // so data loads are wave-uniform (scalar) and the loop is pure FP64 VALU.  grid = (proposal blocks, chunks).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_obs_loglike(KParams p, int n_chunks) {
-    __shared__ double s_erfcx[kErfcxIntervals * (kErfcxDeg + 1)];  // LDS copy of the erfcx table (LBA / LNR only)
-    if (p.family == FAM_LBA || p.family == FAM_LNR) {
-        for (int i = threadIdx.x; i < kErfcxIntervals * (kErfcxDeg + 1); i += 256) s_erfcx[i] = kErfcxTable[i];
+    // LDS copy of the family's table: Phi / phi polynomials (LBA), erfcx polynomials (LNR)
+    constexpr int kTabPhi = kPhiIntervals * 2 * (kPhiDeg + 1), kTabErfcx = kErfcxIntervals * (kErfcxDeg + 1);
+    __shared__ double s_tab[kTabPhi > kTabErfcx ? kTabPhi : kTabErfcx];
+    if (p.family == FAM_LBA) {
+        for (int i = threadIdx.x; i < kTabPhi; i += 256) s_tab[i] = kPhiTable[i];
+        __syncthreads();
+    } else if (p.family == FAM_LNR) {
+        for (int i = threadIdx.x; i < kTabErfcx; i += 256) s_tab[i] = kErfcxTable[i];
         __syncthreads();
     }
     const int q = blockIdx.x * 256 + threadIdx.x;
@@ -1797,7 +1802,7 @@ __global__ __launch_bounds__(256) void k_obs_loglike(KParams p, int n_chunks) {
     const double* th = p.prop + slot * p.D;
     const long long per = (p.N + n_chunks - 1) / n_chunks;
     const long long i0 = chunk * per, i1 = (i0 + per < p.N) ? i0 + per : p.N;
-    const double acc = obs_range_sum(p, th, i0, i1, 1, s_erfcx);
+    const double acc = obs_range_sum(p, th, i0, i1, 1, s_tab);
     p.partial[(size_t)chunk * p.P + slot] = acc;
 }
 
