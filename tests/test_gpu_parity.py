@@ -332,8 +332,8 @@ def test_longrow_span_loops_against_the_oracle(demc, orc):
     scalar): span loops per uniform region -- crossover with and without the base row (burn-in 2 of 4 iterations), snooker,
     mutation (beta = 0.4), frozen rows of a block sweep -- with the rounds around the hyper-parameters and at the ragged end
     done one scalar per lane; two 256-thread workgroups per CU (geometry_groups makes the moving particles outnumber twice
-    the CUs); a block mask with more runs than the kernarg table holds, and a long segment with a Cauchy prior (no span
-    loops: the general body / one scalar per lane throughout)."""
+    the CUs); a block mask with more runs than the kernarg table holds, a long segment with a Cauchy prior and an odd row length (no
+    span loops: the general body / one scalar per lane throughout)."""
     prob = make_problem("hier_binomial", np.random.default_rng(93), S=2600)
     D = prob["D"]
     m0 = np.zeros(D, np.uint8)
@@ -350,6 +350,11 @@ def test_longrow_span_loops_against_the_oracle(demc, orc):
     cauchy["pk"] = [1, 2] + [5] * 1300 + [9] * 1300  # PR_CAUCHY on the second half of the subjects
     teacher_forced(demc, orc, cauchy, n_iter=3, n_groups=2, Np=6, schedule=2, burnin=1, theta_snooker=0.2, masks=blocks,
                    exact_de=False)
+    odd = make_problem("hier_binomial", np.random.default_rng(95), S=2601)  # D = 2603: unaligned rows, the general body
+    mo = np.zeros(odd["D"], np.uint8)
+    mo[:2] = 1
+    teacher_forced(demc, orc, odd, n_iter=3, n_groups=2, Np=6, schedule=2, burnin=1, theta_snooker=0.2, beta=0.3,
+                   masks=np.stack([mo, 1 - mo]), exact_de=False)
     hg = make_problem("hier_gaussian", np.random.default_rng(94), S=1500, n=3)
     mg = np.zeros(hg["D"], np.uint8)
     mg[:2] = 1
