@@ -37,6 +37,15 @@ namespace demc {
 // value held by lane `src` of the wave, as a wave-uniform scalar
 __device__ inline uint32_t wave_get(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
 
+// (A/B build only, make EXPERIMENTS=1: leave the kernel at a given point, to time what lies before it --
+// tools/lr_exit_experiment.py; the product build compiles these away)
+#ifdef DEMC_EXPERIMENTS
+#define DEMC_LR_EXIT(n) \
+    if (p.n_split == -(n)) return
+#else
+#define DEMC_LR_EXIT(n)
+#endif
+
 template <int WG>
 __global__ __launch_bounds__(WG, 512 / WG) void k_longrow(KParams p) {
     extern __shared__ double lds[];  // theta' of the particle [D (+1 if odd)] | cumulative pool weights [pool_n + chunks], the
@@ -48,12 +57,6 @@ __global__ __launch_bounds__(WG, 512 / WG) void k_longrow(KParams p) {
     __shared__ double s_ref[2][kMaxDimSeg];
     __shared__ double s_hyp[2];
     DEMC_STAMP_INIT();
-#ifdef DEMC_EXPERIMENTS  // (A/B build only: leave the kernel at a given point, to time what lies before it)
-#define DEMC_LR_EXIT(n) \
-    if (p.n_split == -(n)) return
-#else
-#define DEMC_LR_EXIT(n)
-#endif
     DEMC_LR_EXIT(1);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave: an SGPR)
     const int D = p.D, Np = p.Np;
