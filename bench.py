@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--accuracy-iters", type=int, default=1500, help="length of the untimed accuracy leg (0: skip)")
     ap.add_argument("--async-migration", action="store_true",
                     help="groups an exchange does not select update while the all-gather is in flight (SURVEY 8f #3)")
+    ap.add_argument("--collective", default="library", choices=["library", "torch"],
+                    help="home of the one all-gather per migration: the engine's own RCCL communicator behind the C-ABI "
+                         "(demc_comm_init; torch only carries the 128-byte id) or torch.distributed (backend nccl = RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -351,12 +354,24 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible and there is no CPU fallback")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1 or os.environ.get("DEMC_FORCE_DIST") == "1":  # the latter: exercise the RCCL path with one rank
-        import torch.distributed as dist_
+    multi = world > 1 or os.environ.get("DEMC_FORCE_DIST") == "1"  # the latter: exercise the collective path with one rank
+    library = multi and a.collective == "library"
+    store = None
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
+    if multi and not library:
+        import torch.distributed as dist_
         dist_.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         dist = dist_
+    elif library:
+        # Control plane = the launcher's key-value store and nothing else: it carries the communicator id from rank 0 to the
+        # others.  (Under torch.distributed.run the agent hosts the store; started bare, rank 0 does.)  No process group.
+        from datetime import timedelta
+        from torch.distributed import TCPStore
+        agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"
+        store = TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, is_master=(rank == 0 and not agent),
+                         timeout=timedelta(seconds=600))
 
     w = build_workload(a)
     G, Np, D = w["G"], w["Np"], w["D"]
@@ -367,26 +382,42 @@ def main():
                              loglike_mode=0 if a.mode == "streaming" else 1, trace=0, fuse=a.fuse, **w["engine"])
     W.configure(eng, w)
     eng.set_state(w["init"](P, np.random.default_rng(20260003 + rank)))
-    drv = ShardedDriver(eng, dist, torch.device("cuda", local), stream_ordered=True, async_migration=a.async_migration)
+    if library:
+        # the whole sharded iteration behind the C-ABI: demc_step on a handle that owns its RCCL communicator
+        key = "demc/comm_id/" + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+        if rank == 0:
+            store.set(key, eng.comm_unique_id())
+        eng.comm_init(store.get(key), rank, world)
+        eng.comm_set_overlap(a.async_migration)
+        step = eng.step_enqueue
+    else:
+        drv = ShardedDriver(eng, dist, torch.device("cuda", local), stream_ordered=True, async_migration=a.async_migration)
+        step = drv.step
 
-    def sync():
-        if dist:
+    def sync():  # barrier + device drained, on both sides of the timed region
+        if library:
+            eng.synchronize()
+            eng.comm_allreduce([])  # an all-reduce of one word over the engine's communicator = the barrier
+        elif dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    drv.step(1, a.warmup)
+    step(1, a.warmup)
     sync()
     if not a.no_roofline:
         eng.timing_enable(True)  # HIP events on the handle's stream around every launch of the timed iterations
     t0 = time.perf_counter()
-    drv.step(1 + a.warmup, a.steps)
+    step(1 + a.warmup, a.steps)
     sync()
     dt = time.perf_counter() - t0
     tm = None
     if not a.no_roofline:
         tm = eng.timing_read()
         eng.timing_enable(False)
-    if dist:
+    n_gathers = eng.comm_stats()["exchanges"] if library else (drv.n_exchanges if multi else 0)
+    if library:
+        dt = float(eng.comm_allreduce([dt], "max")[0])  # MAX over ranks
+    elif dist:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -409,6 +440,9 @@ def main():
     roofline = None
     if tm is not None:
         roofline = roofline_of(a, w, tm, a.steps, P, dt / a.steps)
+    if library:
+        eng.comm_allreduce([])  # nobody leaves (and rank 0 keeps the store up) before everybody has finished
+        eng.comm_destroy()
     eng.close()
 
     if rank == 0:
@@ -427,7 +461,11 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": describe(a, w, world), "particles_per_gpu": P, "block_sweeps_per_step": sweeps,
                        "parallelism": f"groups sharded x{world}, one all-gather per migration" +
-                                      (" (asynchronous: unselected groups update during the gather)" if a.async_migration else "")},
+                                      (" (asynchronous: unselected groups update during the gather)" if a.async_migration else ""),
+                       "collective": None if not multi else
+                                     ("ncclAllGather on the engine's own communicator (demc_comm_init, behind the C-ABI)" if library
+                                      else "torch.distributed.all_gather_into_tensor (backend nccl = RCCL)"),
+                       "all_gathers_rank0": n_gathers},
             "particle_parameter_updates_per_s": value * D,
             "accuracy": accuracy, "roofline": roofline, "cpu_baseline": cpu,
         }

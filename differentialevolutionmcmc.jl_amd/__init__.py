@@ -5,7 +5,7 @@ gfx950 kernels behind the C-ABI of include/demc.h); importing this package witho
 any sampling call raises -- there is no CPU fallback.
 """
 from . import _ffi, families
-from ._ffi import DemcError, HipEngine
+from ._ffi import DemcError, HipEngine, MultiEngine
 from .chains import Chains
 from .families import (Beta, BinomialLikelihood, Cauchy, Exponential, Flat, Gamma, GaussianLikelihood, LogNormal, HierBinomialLikelihood,
                        HierGaussianLikelihood, LBALikelihood, LNRLikelihood, MvNormalFullLikelihood,
@@ -20,4 +20,4 @@ DEMCMC = __name__
 
 __all__ = ["DE", "Particle", "DEModel", "sample", "MCMCThreads", "HIPBackend", "fixed_gamma", "variable_gamma",
            "random_gamma", "evaluate_fun", "compute_posterior", "optimize", "get_optimal", "resample", "as_union",
-           "mh_update", "maximize", "minimize", "Chains", "Priors", "HipEngine", "DemcError"]
+           "mh_update", "maximize", "minimize", "Chains", "Priors", "HipEngine", "MultiEngine", "DemcError"]

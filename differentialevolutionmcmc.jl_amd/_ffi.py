@@ -21,7 +21,13 @@ EXPORTS = [
     "demc_migration_pack", "demc_migration_apply", "demc_migration_pack_async", "demc_migration_apply_async", "demc_migration_groups",
     "demc_update_groups_async", "demc_apply_migration", "demc_get_weights", "demc_logpost",
     "demc_get_trace", "demc_set_replay", "demc_timing_enable", "demc_timing_read",
+    "demc_step_async", "demc_synchronize",
+    "demc_comm_unique_id", "demc_comm_init", "demc_comm_destroy", "demc_comm_set_overlap", "demc_migration_exchange",
+    "demc_migration_exchange_async", "demc_comm_allreduce", "demc_comm_stats",
+    "demc_create_multi", "demc_destroy_multi", "demc_multi_last_error", "demc_multi_size", "demc_multi_shard", "demc_multi_step",
 ]
+COMM_ID_BYTES = 128
+_NOT_STATUS = {"demc_last_error": C.c_char_p, "demc_multi_last_error": C.c_char_p, "demc_multi_shard": C.c_void_p}
 
 
 class DemcError(RuntimeError):
@@ -146,8 +152,24 @@ def load():
     L.demc_set_replay.argtypes = [H, C.POINTER(DemcReplay)]
     L.demc_timing_enable.argtypes = [H, C.c_int32]
     L.demc_timing_read.argtypes = [H, _dp, C.c_int32]
-    for name in EXPORTS:  # every entry point returns an int32 status, except the error string
-        getattr(L, name).restype = C.c_char_p if name == "demc_last_error" else C.c_int32
+    L.demc_step_async.argtypes = [H, C.c_int64, C.c_int32]
+    L.demc_synchronize.argtypes = [H]
+    L.demc_comm_unique_id.argtypes = [C.c_void_p, C.c_int32]
+    L.demc_comm_init.argtypes = [H, C.c_void_p, C.c_int32, C.c_int32]
+    L.demc_comm_destroy.argtypes = [H]
+    L.demc_comm_set_overlap.argtypes = [H, C.c_int32]
+    L.demc_migration_exchange.argtypes = [H, C.c_int64]
+    L.demc_migration_exchange_async.argtypes = [H, C.c_int64]
+    L.demc_comm_allreduce.argtypes = [H, _dp, C.c_int32, C.c_int32]
+    L.demc_comm_stats.argtypes = [H, _lp]
+    L.demc_create_multi.argtypes = [C.POINTER(DemcConfig), C.c_int32, _ip, C.POINTER(H)]
+    L.demc_destroy_multi.argtypes = [H]
+    L.demc_multi_last_error.argtypes = [H]
+    L.demc_multi_size.argtypes = [H]
+    L.demc_multi_shard.argtypes = [H, C.c_int32]
+    L.demc_multi_step.argtypes = [H, C.c_int64, C.c_int32]
+    for name in EXPORTS:  # every entry point returns an int32 status, except the error strings and the shard accessor
+        getattr(L, name).restype = _NOT_STATUS.get(name, C.c_int32)
     _lib = L
     return L
 
@@ -176,23 +198,28 @@ class HipEngine:
     """One demc_handle (one GPU, one shard of groups).  Method names and array shapes are the engine interface
     the host driver (sampler.py / distributed.py) is written against."""
 
-    def __init__(self, **cfg):
+    def __init__(self, _shard_of=None, **cfg):
         self.L = load()
         self.cfg = make_config(**cfg)
         self.h = C.c_void_p()
-        rc = self.L.demc_create(C.byref(self.cfg), C.byref(self.h))
-        if rc != OK:
-            msg = self.L.demc_last_error(self.h).decode() if self.h else "demc_create failed"
-            if self.h:
-                self.L.demc_destroy(self.h)
-                self.h = C.c_void_p()
-            raise DemcError(rc, msg)
+        self._owned = _shard_of is None
+        if _shard_of is not None:  # a shard of a MultiEngine: the set owns the handle
+            self.h = C.c_void_p(_shard_of)
+        else:
+            rc = self.L.demc_create(C.byref(self.cfg), C.byref(self.h))
+            if rc != OK:
+                msg = self.L.demc_last_error(self.h).decode() if self.h else "demc_create failed"
+                if self.h:
+                    self.L.demc_destroy(self.h)
+                    self.h = C.c_void_p()
+                raise DemcError(rc, msg)
         self.P = self.cfg.n_groups * self.cfg.Np
         self.D = self.cfg.D
 
     def close(self):
         if getattr(self, "h", None):
-            self.L.demc_destroy(self.h)
+            if self._owned:
+                self.L.demc_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):
@@ -293,6 +320,51 @@ class HipEngine:
     def update(self, iter0, n_iters=1):
         self._ck(self.L.demc_update(self.h, iter0, n_iters))
 
+    def step_enqueue(self, iter0, n_iters=1):
+        """demc_step without the drain (demc_step_async); synchronize() waits and reports"""
+        self._ck(self.L.demc_step_async(self.h, iter0, n_iters))
+
+    def synchronize(self):
+        self._ck(self.L.demc_synchronize(self.h))
+
+    # ---- the communicator behind the C-ABI (one process per GPU; include/demc.h "The one collective") ----
+    @staticmethod
+    def comm_unique_id():
+        """ncclGetUniqueId as 128 bytes (rank 0 calls it, the host carries the bytes to the other ranks)"""
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        rc = load().demc_comm_unique_id(buf, COMM_ID_BYTES)
+        if rc != OK:
+            raise DemcError(rc, "demc_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("unique id must be 128 bytes")
+        self._ck(self.L.demc_comm_init(self.h, C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES), rank, world))
+
+    def comm_destroy(self):
+        self._ck(self.L.demc_comm_destroy(self.h))
+
+    def comm_set_overlap(self, on=True):
+        self._ck(self.L.demc_comm_set_overlap(self.h, 1 if on else 0))
+
+    def migration_exchange(self, it):
+        self._ck(self.L.demc_migration_exchange(self.h, it))
+
+    def migration_exchange_enqueue(self, it):
+        self._ck(self.L.demc_migration_exchange_async(self.h, it))
+
+    def comm_allreduce(self, values, op="sum"):
+        """host doubles reduced over the ranks of the handle's communicator (empty: a barrier)"""
+        v = np.ascontiguousarray(np.atleast_1d(np.asarray(values, dtype=np.float64))).copy()
+        self._ck(self.L.demc_comm_allreduce(self.h, _d(v) if v.size else None, v.size, {"sum": 0, "max": 1, "min": 2}[op]))
+        return v
+
+    def comm_stats(self):
+        out = np.zeros(3, np.int64)
+        self._ck(self.L.demc_comm_stats(self.h, out.ctypes.data_as(_lp)))
+        return dict(world=int(out[0]), rank=int(out[1]), exchanges=int(out[2]))
+
     def logpost(self, theta):
         theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(-1, self.D)
         out = np.empty(theta.shape[0])
@@ -359,3 +431,68 @@ class HipEngine:
         self._ck(self.L.demc_timing_read(self.h, _d(out), 1 if reset else 0))
         names = ("propose", "loglike_prep", "loglike", "accept_store", "migration")
         return {n: dict(ms=out[i], launches=int(out[5 + i])) for i, n in enumerate(names)}
+
+
+class MultiEngine:
+    """demc_create_multi: ONE host thread drives several shards (GPUs).  `cfg` describes the whole population; shard r is
+    an ordinary engine (self.shards[r]) for the per-shard calls, step() runs step! over the set."""
+
+    def __init__(self, n_shards, device_ids=None, **cfg):
+        self.L = load()
+        self.cfg = make_config(**cfg)
+        self.m = C.c_void_p()
+        dev = None if device_ids is None else np.ascontiguousarray(device_ids, dtype=np.int32)
+        rc = self.L.demc_create_multi(C.byref(self.cfg), n_shards, None if dev is None else dev.ctypes.data_as(_ip), C.byref(self.m))
+        if rc != OK:
+            msg = self.L.demc_multi_last_error(self.m).decode() if self.m else "demc_create_multi failed"
+            if self.m:
+                self.L.demc_destroy_multi(self.m)
+                self.m = C.c_void_p()
+            raise DemcError(rc, msg)
+        G = self.cfg.n_groups // n_shards
+        self.shards = []
+        for r in range(n_shards):
+            kw = {k: getattr(self.cfg, k) for k in CFG_KEYS}
+            kw.update(n_groups=G, group_offset=r * G, n_groups_total=self.cfg.n_groups,
+                      device_id=r if dev is None else int(dev[r]))
+            self.shards.append(HipEngine(_shard_of=self.L.demc_multi_shard(self.m, r), **kw))
+        self.P = self.cfg.n_groups * self.cfg.Np
+        self.D = self.cfg.D
+
+    def each(self, fn):
+        """the per-shard set-up calls are the same on every shard: fn(shard_engine)"""
+        for e in self.shards:
+            fn(e)
+
+    def set_state(self, theta, weight=None, ids=None):
+        theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(self.P, self.D)
+        for e in self.shards:
+            lo = e.cfg.group_offset * e.cfg.Np
+            e.set_state(theta[lo:lo + e.P], None if weight is None else np.asarray(weight)[lo:lo + e.P],
+                        None if ids is None else np.asarray(ids)[lo:lo + e.P])
+
+    def get_state(self):
+        parts = [e.get_state() for e in self.shards]
+        return tuple(np.concatenate([p[i] for p in parts]) for i in range(3))
+
+    def get_history(self, row0, row1):
+        parts = [e.get_history(row0, row1) for e in self.shards]
+        return tuple(np.concatenate([p[i] for p in parts], axis=1) for i in range(4))
+
+    def step(self, iter0, n_iters=1):
+        rc = self.L.demc_multi_step(self.m, iter0, n_iters)
+        if rc != OK:
+            raise DemcError(rc, self.L.demc_multi_last_error(self.m).decode())
+
+    def close(self):
+        if getattr(self, "m", None):
+            for e in self.shards:
+                e.close()
+            self.L.demc_destroy_multi(self.m)
+            self.m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

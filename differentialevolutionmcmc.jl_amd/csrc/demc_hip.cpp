@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <hip/hiprtc.h>
+#include <rccl/rccl.h>
 
 #include <cmath>
 #include <cstdio>
@@ -121,6 +122,18 @@ struct demc_handle {
     bool rp_active = false, rp_has_step = false;
     double rp_u_step = 0.0;
     int geo_groups = 0;  // groups the lane geometry is sized for (demc_config.geometry_groups, else n_groups)
+    // the one collective of the path: an RCCL communicator owned by the handle (demc_comm_init), or lent by the
+    // single-process multi-GPU set the handle is a shard of (demc_create_multi)
+    ncclComm_t comm = nullptr;
+    bool own_comm = false;
+    int comm_rank = 0, comm_world = 1;
+    bool comm_overlap = false;        // demc_comm_set_overlap: unselected groups update while the all-gather is in flight
+    hipStream_t side = nullptr;       // ... on this stream
+    hipEvent_t ev_pack = nullptr, ev_gath = nullptr;
+    double* red_dev = nullptr;        // demc_comm_allreduce staging
+    size_t red_cap = 0;
+    long long n_exchanges = 0;        // all-gathers issued (diagnostic, demc_comm_stats)
+    struct demc_multi* multi = nullptr;
     // timing
     bool timing = false;
     std::vector<Timed> events;
@@ -646,8 +659,8 @@ int launch_lean(demc_handle* h, long long iter0, int n_iters, bool stream) {
     if (stream) {
         k.st_C = h->st_C; k.st_nact_max = h->st_nact_max; k.st_x_lds = h->st_x_lds; k.st_chunk_tiles = h->st_chunk_tiles;
         k.n_tiles = h->n_tiles; k.Xf = h->Xf; k.st_gran = h->st_gran; k.st_err = h->st_err;
-        HIPCHK(hipMemsetAsync(h->st_gran, 0, 2 * (size_t)c.n_groups * h->st_C * h->st_nact_max * 2 * sizeof(unsigned long long), h->stream));
         if (k.n_groups * h->st_C > h->n_cus) return fail(h, DEMC_EINVAL, "streaming-resident grid exceeds the CU count");
+        HIPCHK(hipMemsetAsync(h->st_gran, 0, 2 * (size_t)c.n_groups * h->st_C * h->st_nact_max * 2 * sizeof(unsigned long long), h->stream));
     }
     tick(h, 0, true);
     const unsigned grid = (unsigned)(k.n_groups * (stream ? h->st_C : 1));
@@ -739,6 +752,7 @@ int launch_stream(demc_handle* h, long long iter0, int n_iters) {
     k.plan = (k.lpp >= 4) ? 1 : 0;
     k.st_C = h->st_C; k.st_nact_max = h->st_nact_max; k.st_rows = h->st_rows; k.st_x_lds = h->st_x_lds;
     k.st_chunk_tiles = h->st_chunk_tiles; k.n_tiles = h->n_tiles; k.Xf = h->Xf; k.st_gran = h->st_gran; k.st_err = h->st_err;
+    if (c.n_groups * h->st_C > h->n_cus) return fail(h, DEMC_EINVAL, "streaming-resident grid exceeds the CU count");
     // epoch tags restart at 1 in every launch: the granules of the previous launch must not match them
     HIPCHK(hipMemsetAsync(h->st_gran, 0, 2 * (size_t)c.n_groups * h->st_C * h->st_nact_max * 2 * sizeof(unsigned long long), h->stream));
     tick(h, 0, true);
@@ -746,7 +760,6 @@ int launch_stream(demc_handle* h, long long iter0, int n_iters) {
     // grid is sized for that by construction -- at most one workgroup per CU (plan_stream: n_groups * C <= CUs, and each
     // takes most of a CU's LDS) -- so a plain launch has the same residency as a cooperative one, without its launch-time
     // cost (+15-19 us, MI355X_MICROARCH.md "coop-launch"); every spin in the kernel is bounded regardless.
-    if (c.n_groups * h->st_C > h->n_cus) return fail(h, DEMC_EINVAL, "streaming-resident grid exceeds the CU count");
     LAUNCH_T(h, k1_stream_instance(h->st_wg, tail_of(k), is_plain(h, k)), dim3(c.n_groups * h->st_C), dim3(h->st_wg), h->st_lds,
                        k);
     const hipError_t e = hipGetLastError();
@@ -1019,6 +1032,7 @@ int32_t demc_create(const demc_config* cfg, demc_handle** out) {
 int32_t demc_destroy(demc_handle* h) {
     return guarded(nullptr, [&]() -> int32_t {
     if (!h) return DEMC_OK;
+    if (h->multi) return DEMC_EINVAL;  // a shard of a multi-GPU set goes with the set (demc_destroy_multi)
     if (h->stream) hipStreamSynchronize(h->stream);
     drain_events(h);
     for (hipEvent_t e : h->event_pool) hipEventDestroy(e);
@@ -1039,6 +1053,12 @@ int32_t demc_destroy(demc_handle* h) {
     }
     if (h->st_gran) hipFree(h->st_gran);
     if (h->st_err) hipHostFree(h->st_err);
+    if (h->side) hipStreamSynchronize(h->side);
+    if (h->comm && h->own_comm) ncclCommDestroy(h->comm);
+    if (h->ev_pack) hipEventDestroy(h->ev_pack);
+    if (h->ev_gath) hipEventDestroy(h->ev_gath);
+    if (h->side) hipStreamDestroy(h->side);
+    if (h->red_dev) hipFree(h->red_dev);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
     return DEMC_OK;
@@ -1283,6 +1303,9 @@ static int upload_dimtab(demc_handle* h) {
         if (q < h->n_seg && (kd == PR_FLAT || kd == PR_NORMAL || kd == PR_NORMAL_REF)) h->seg_plain |= 1u << q;
     }
     HIPCHK(hipMemcpy(h->dimseg, segs, sizeof segs, hipMemcpyHostToDevice));
+    // the lean resident kernel reads the table in its run-length form and knows no Normal(a, theta[ref]) prior: priors and
+    // bounds arrive AFTER demc_set_model in every caller, so its plan is taken again whenever the table changes
+    if (h->family >= 0) plan_lean(h);
     return DEMC_OK;
 }
 
@@ -1454,21 +1477,113 @@ static bool migration_due_h(demc_handle* h, int64_t iter) {
     return demc_migration_due(&h->c, iter) != 0;
 }
 
-static int32_t step_impl(demc_handle* h, int64_t iter0, int32_t n_iters, bool with_migration, bool drain = true) {
-    return guarded(h, [&]() -> int32_t {
-    if (!h) return DEMC_EINVAL;
-    USE_DEVICE(h);
-    if (h->family < 0) return fail(h, DEMC_EINVAL, "demc_set_model has not been called");
-    if (iter0 < 1 || n_iters < 0) return fail(h, DEMC_EINVAL, "iter0 is 1-based (de.iter, main.jl:34)");
+#define NCCLCHK(expr)                                                                                         \
+    do {                                                                                                      \
+        ncclResult_t r_ = (expr);                                                                             \
+        if (r_ != ncclSuccess) return fail(h, DEMC_ERCCL, std::string(#expr) + ": " + ncclGetErrorString(r_)); \
+    } while (0)
+
+// this shard's rows inside the [n_groups_total][D+3] exchange buffer: rank r's block starts at r * n_groups rows, which is
+// where an IN-PLACE ncclAllGather expects the send buffer (recvbuff + rank * sendcount)
+static double* own_rows(demc_handle* h) { return h->mig_rows + (size_t)h->c.group_offset * ((size_t)h->c.D + 3); }
+
+// the ONE collective of the path: all-gather of every shard's candidate rows (migration.jl:11-19 split around it), enqueued
+// on stream s.  No host synchronisation.
+static int gather_enqueue(demc_handle* h, hipStream_t s) {
+    const size_t cnt = (size_t)h->c.n_groups * ((size_t)h->c.D + 3);
+    NCCLCHK(ncclAllGather(own_rows(h), h->mig_rows, cnt, ncclDouble, h->comm, s));
+    h->n_exchanges += 1;
+    return DEMC_OK;
+}
+
+// migration! of iteration `iter` on a handle that owns a communicator: pack -> all-gather -> apply, stream-ordered
+static int exchange_enqueue(demc_handle* h, int64_t iter) {
+    migration_enqueue(h, iter, own_rows(h), nullptr, true, false);
+    int rc = gather_enqueue(h, h->stream);
+    if (rc != DEMC_OK) return rc;
+    migration_enqueue(h, iter, nullptr, h->mig_rows, false, true);
+    return DEMC_OK;
+}
+
+static int step_body(demc_handle* h, int64_t iter0, int32_t n_iters, bool with_migration);
+
+// update! + store_samples! of iterations [iter0, iter0 + n_iters) for a SUBSET of the handle's groups (local indices),
+// enqueued only.  The list travels through a ring of pinned host / device copies: the device copy is refilled by a copy ON
+// THE HANDLE'S STREAM, i.e. behind every kernel that still reads its previous content.
+static int update_subset(demc_handle* h, int64_t iter0, int32_t n_iters, const int32_t* groups, int32_t n) {
+    if (n == 0) return DEMC_OK;
+    if (h->family == FAM_USER) return fail(h, DEMC_EUNSUPPORTED, "subset updates are not available for source plug-in models");
+    if (h->rp_active && h->rp_n_mig > 0)
+        return fail(h, DEMC_EINVAL, "subset updates follow demc_migration_groups, which does not see a replayed migration sub-group");
+    const int G = h->c.n_groups;
+    for (int i = 0; i < n; ++i)
+        if (groups[i] < 0 || groups[i] >= G) return fail(h, DEMC_EINVAL, "group index outside this handle");
+    const int slot = h->glist_next;
+    h->glist_next = (slot + 1) % demc_handle::kGlistRing;
+    int* dev = h->glist_buf[slot];
+    if (hipEventSynchronize(h->glist_ev[slot]) != hipSuccess) return fail(h, DEMC_EHIP, "group-list ring");
+    std::memcpy(h->glist_pin[slot], groups, (size_t)n * sizeof(int));
+    if (hipMemcpyAsync(dev, h->glist_pin[slot], (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipEventRecord(h->glist_ev[slot], h->stream) != hipSuccess)
+        return fail(h, DEMC_EHIP, "copying the group list");
+    h->cur_glist = dev;
+    h->cur_ng = n;
+    const int rc = step_body(h, iter0, n_iters, false);
+    h->cur_glist = nullptr;
+    h->cur_ng = 0;
+    return rc;
+}
+
+// Per-group-asynchronous migration behind the boundary: migration of iteration `iter` + the update of
+// iterations [iter, iter + run).  The sub-group of an exchange is a pure function of (seed, iter), so the groups it did NOT
+// select start their update while the all-gather is in flight on the side stream; only the selected groups wait for it.
+static int exchange_overlapped(demc_handle* h, int64_t iter, int run) {
     const demc_config& c = h->c;
-    if (c.partner_kind == DEMC_PARTNER_HISTORY && iter0 < 2)
-        return fail(h, DEMC_EINVAL, "history partners need at least one stored row (n_initial > 0)");
+    std::vector<int32_t> sel((size_t)c.n_groups_total), mine, rest;
+    int32_t n_sel = 0;
+    demc_migration_groups(&c, iter, sel.data(), &n_sel);
+    std::vector<char> picked((size_t)c.n_groups, 0);
+    for (int i = 0; i < n_sel; ++i) {
+        const int gl = sel[(size_t)i] - c.group_offset;
+        if (gl >= 0 && gl < c.n_groups) picked[(size_t)gl] = 1;
+    }
+    for (int g = 0; g < c.n_groups; ++g) (picked[(size_t)g] ? mine : rest).push_back(g);
+    migration_enqueue(h, iter, own_rows(h), nullptr, true, false);
+    HIPCHK(hipEventRecord(h->ev_pack, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->side, h->ev_pack, 0));
+    int rc = gather_enqueue(h, h->side);  // the one collective, off the main stream
+    if (rc != DEMC_OK) return rc;
+    HIPCHK(hipEventRecord(h->ev_gath, h->side));
+    rc = update_subset(h, iter, run, rest.data(), (int32_t)rest.size());  // overlaps the gather
+    if (rc != DEMC_OK) return rc;
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_gath, 0));
+    migration_enqueue(h, iter, nullptr, h->mig_rows, false, true);
+    return update_subset(h, iter, run, mine.data(), (int32_t)mine.size());
+}
+
+// iterations [iter0, iter0 + n_iters) enqueued on the handle's stream; nothing is drained
+static int step_body(demc_handle* h, int64_t iter0, int32_t n_iters, bool with_migration) {
+    const demc_config& c = h->c;
     const int n_sweeps = c.n_blocks > 0 ? c.n_blocks : 1;  // block_update! main.jl:174-179
     for (int64_t iter = iter0; iter < iter0 + n_iters; ++iter) {
         if (with_migration && migration_due_h(h, iter)) {  // main.jl:85
-            if (c.n_groups_total != c.n_groups)
-                return fail(h, DEMC_EINVAL, "sharded handle: drive the exchange with demc_migration_pack/apply + demc_update");
-            migration_enqueue(h, iter, h->mig_rows, h->mig_rows, true, true);
+            if (c.n_groups_total != c.n_groups || (h->comm && h->own_comm)) {  // (a communicator of one rank takes the same path)
+                if (h->multi) return fail(h, DEMC_EINVAL, "shard of a multi-GPU set: step the set with demc_multi_step");
+                if (!h->comm)
+                    return fail(h, DEMC_EINVAL, "sharded handle without a communicator: demc_comm_init, or drive the exchange with "
+                                                "demc_migration_pack/apply + demc_update");
+                if (h->comm_overlap && !h->rp_active && h->family != FAM_USER) {
+                    int run = 1;
+                    while (iter + run < iter0 + n_iters && !migration_due_h(h, iter + run)) ++run;
+                    int rc = exchange_overlapped(h, iter, run);
+                    if (rc != DEMC_OK) return rc;
+                    iter += run - 1;
+                    continue;
+                }
+                int rc = exchange_enqueue(h, iter);
+                if (rc != DEMC_OK) return rc;
+            } else
+                migration_enqueue(h, iter, h->mig_rows, h->mig_rows, true, true);
         }
         const bool st_ok = h->st_ok && !h->cur_glist;  // (a subset update never uses the form whose workgroups wait on each other)
         if ((h->res_ok || st_ok) && !h->rp_active) {  // every iteration up to the next migration in one launch
@@ -1494,45 +1609,64 @@ static int32_t step_impl(demc_handle* h, int64_t iter0, int32_t n_iters, bool wi
             if (rc != DEMC_OK) return rc;
         }
     }
-    if (!drain) {
-        HIPCHK(hipGetLastError());
-        return DEMC_OK;
-    }
+    HIPCHK(hipGetLastError());
+    return DEMC_OK;
+}
+
+static int step_checks(demc_handle* h, int64_t iter0, int32_t n_iters) {
+    if (h->family < 0) return fail(h, DEMC_EINVAL, "demc_set_model has not been called");
+    if (iter0 < 1 || n_iters < 0) return fail(h, DEMC_EINVAL, "iter0 is 1-based (de.iter, main.jl:34)");
+    if (h->c.partner_kind == DEMC_PARTNER_HISTORY && iter0 < 2)
+        return fail(h, DEMC_EINVAL, "history partners need at least one stored row (n_initial > 0)");
+    return DEMC_OK;
+}
+
+static int drain(demc_handle* h) {
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
     if (h->st_err && *h->st_err) {
         *h->st_err = 0u;
         return fail(h, DEMC_EHIP, "streaming-resident kernel: a hand-over between the workgroups of a group timed out");
     }
+    if (h->comm) {  // a collective that failed after it was enqueued shows up here
+        ncclResult_t ar = ncclSuccess;
+        if (ncclCommGetAsyncError(h->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress)
+            return fail(h, DEMC_ERCCL, std::string("communicator: ") + ncclGetErrorString(ar));
+    }
     return DEMC_OK;
+}
+
+static int32_t step_impl(demc_handle* h, int64_t iter0, int32_t n_iters, bool with_migration, bool do_drain = true) {
+    return guarded(h, [&]() -> int32_t {
+    if (!h) return DEMC_EINVAL;
+    USE_DEVICE(h);
+    int rc = step_checks(h, iter0, n_iters);
+    if (rc != DEMC_OK) return rc;
+    rc = step_body(h, iter0, n_iters, with_migration);
+    if (rc != DEMC_OK || !do_drain) return rc;
+    return drain(h);
     });
 }
 
 int32_t demc_step(demc_handle* h, int64_t iter0, int32_t n_iters) { return step_impl(h, iter0, n_iters, true); }
 int32_t demc_update(demc_handle* h, int64_t iter0, int32_t n_iters) { return step_impl(h, iter0, n_iters, false); }
+int32_t demc_step_async(demc_handle* h, int64_t iter0, int32_t n_iters) { return step_impl(h, iter0, n_iters, true, false); }
+int32_t demc_synchronize(demc_handle* h) {
+    return guarded(h, [&]() -> int32_t {
+    if (!h) return DEMC_EINVAL;
+    USE_DEVICE(h);
+    return drain(h);
+    });
+}
 
 int32_t demc_update_groups_async(demc_handle* h, int64_t iter0, int32_t n_iters, const int32_t* groups, int32_t n) {
+    return guarded(h, [&]() -> int32_t {
     if (!h || n < 0 || (n > 0 && !groups)) return DEMC_EINVAL;
-    if (n == 0) return DEMC_OK;
-    if (h->family == FAM_USER) return fail(h, DEMC_EUNSUPPORTED, "subset updates are not available for source plug-in models");
-    const int G = h->c.n_groups;
-    for (int i = 0; i < n; ++i)
-        if (groups[i] < 0 || groups[i] >= G) return fail(h, DEMC_EINVAL, "group index outside this handle");
-    if (hipSetDevice(h->c.device_id) != hipSuccess) return fail(h, DEMC_EHIP, "hipSetDevice");
-    const int slot = h->glist_next;
-    h->glist_next = (slot + 1) % demc_handle::kGlistRing;
-    int* dev = h->glist_buf[slot];
-    if (hipEventSynchronize(h->glist_ev[slot]) != hipSuccess) return fail(h, DEMC_EHIP, "group-list ring");
-    std::memcpy(h->glist_pin[slot], groups, (size_t)n * sizeof(int));
-    if (hipMemcpyAsync(dev, h->glist_pin[slot], (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
-        hipEventRecord(h->glist_ev[slot], h->stream) != hipSuccess)
-        return fail(h, DEMC_EHIP, "copying the group list");
-    h->cur_glist = dev;
-    h->cur_ng = n;
-    const int32_t rc = step_impl(h, iter0, n_iters, false, false);
-    h->cur_glist = nullptr;
-    h->cur_ng = 0;
-    return rc;
+    USE_DEVICE(h);
+    int rc = step_checks(h, iter0, n_iters);
+    if (rc != DEMC_OK) return rc;
+    return update_subset(h, iter0, n_iters, groups, n);
+    });
 }
 
 int32_t demc_migration_groups(const demc_config* cfg, int64_t iter, int32_t* sel, int32_t* n_sel) {
@@ -1610,6 +1744,305 @@ int32_t demc_migration_apply_async(demc_handle* h, int64_t iter, const double* d
     USE_DEVICE(h);
     migration_enqueue(h, iter, nullptr, dev_all_rows, false, true);
     HIPCHK(hipGetLastError());
+    return DEMC_OK;
+    });
+}
+
+// ---- the communicator behind the boundary (SURVEY 8b "demc_create_multi / DEMC_ERCCL", 8e) ----
+int32_t demc_comm_unique_id(void* id_out, int32_t nbytes) {
+    return guarded(nullptr, [&]() -> int32_t {
+    if (!id_out || nbytes < (int32_t)sizeof(ncclUniqueId)) return DEMC_EINVAL;
+    static_assert(sizeof(ncclUniqueId) == DEMC_COMM_ID_BYTES, "DEMC_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return DEMC_ERCCL;
+    std::memcpy(id_out, &id, sizeof id);
+    return DEMC_OK;
+    });
+}
+
+static int comm_side_objects(demc_handle* h) {
+    if (!h->side) HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    if (!h->ev_pack) HIPCHK(hipEventCreateWithFlags(&h->ev_pack, hipEventDisableTiming));
+    if (!h->ev_gath) HIPCHK(hipEventCreateWithFlags(&h->ev_gath, hipEventDisableTiming));
+    return DEMC_OK;
+}
+
+static int comm_shape_check(demc_handle* h, int rank, int world) {
+    const demc_config& c = h->c;
+    if (world < 1 || rank < 0 || rank >= world) return fail(h, DEMC_EINVAL, "need 0 <= rank < world");
+    // equal shards in rank order: what the in-place all-gather (and select_groups over GLOBAL group indices) assume
+    if ((long long)c.n_groups * world != c.n_groups_total || c.group_offset != rank * c.n_groups)
+        return fail(h, DEMC_EINVAL, "communicator shape: n_groups_total must be world * n_groups and group_offset rank * n_groups");
+    return DEMC_OK;
+}
+
+int32_t demc_comm_init(demc_handle* h, const void* unique_id, int32_t rank, int32_t world) {
+    return guarded(h, [&]() -> int32_t {
+    if (!h || !unique_id) return DEMC_EINVAL;
+    USE_DEVICE(h);
+    if (h->comm || h->multi) return fail(h, DEMC_EINVAL, "the handle already has a communicator");
+    int rc = comm_shape_check(h, rank, world);
+    if (rc != DEMC_OK) return rc;
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof id);
+    NCCLCHK(ncclCommInitRank(&h->comm, world, id, rank));
+    h->own_comm = true; h->comm_rank = rank; h->comm_world = world;
+    return comm_side_objects(h);
+    });
+}
+
+int32_t demc_comm_destroy(demc_handle* h) {
+    return guarded(h, [&]() -> int32_t {
+    if (!h) return DEMC_EINVAL;
+    USE_DEVICE(h);
+    if (h->stream) HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->side) HIPCHK(hipStreamSynchronize(h->side));
+    if (h->comm && h->own_comm) NCCLCHK(ncclCommDestroy(h->comm));
+    h->comm = nullptr; h->own_comm = false; h->comm_rank = 0; h->comm_world = 1; h->comm_overlap = false;
+    return DEMC_OK;
+    });
+}
+
+int32_t demc_comm_set_overlap(demc_handle* h, int32_t on) {
+    return guarded(h, [&]() -> int32_t {
+    if (!h) return DEMC_EINVAL;
+    if (on && (!h->comm || h->multi)) return fail(h, DEMC_EINVAL, "needs a communicator of the handle's own (demc_comm_init)");
+    h->comm_overlap = on != 0;
+    return DEMC_OK;
+    });
+}
+
+static int32_t exchange_impl(demc_handle* h, int64_t iter, bool do_drain) {
+    return guarded(h, [&]() -> int32_t {
+    if (!h) return DEMC_EINVAL;
+    USE_DEVICE(h);
+    if (!h->comm) return fail(h, DEMC_EINVAL, "the handle has no communicator (demc_comm_init)");
+    int rc = exchange_enqueue(h, iter);
+    if (rc != DEMC_OK || !do_drain) return rc;
+    return drain(h);
+    });
+}
+int32_t demc_migration_exchange(demc_handle* h, int64_t iter) { return exchange_impl(h, iter, true); }
+int32_t demc_migration_exchange_async(demc_handle* h, int64_t iter) { return exchange_impl(h, iter, false); }
+
+int32_t demc_comm_allreduce(demc_handle* h, double* host_inout, int32_t n, int32_t op) {
+    return guarded(h, [&]() -> int32_t {
+    if (!h || n < 0 || (n > 0 && !host_inout) || op < 0 || op > 2) return DEMC_EINVAL;
+    USE_DEVICE(h);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (!h->comm || h->comm_world == 1) return DEMC_OK;  // one rank: the values are the result
+    const size_t m = n > 0 ? (size_t)n : 1;              // n == 0: a barrier (one dummy element goes round)
+    if (h->red_cap < m) {
+        if (h->red_dev) { hipFree(h->red_dev); h->red_dev = nullptr; h->red_cap = 0; }
+        ALLOC(h->red_dev, m);
+        h->red_cap = m;
+    }
+    double dummy = 0.0;
+    HIPCHK(hipMemcpyAsync(h->red_dev, n > 0 ? host_inout : &dummy, m * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const ncclRedOp_t rop = op == 0 ? ncclSum : op == 1 ? ncclMax : ncclMin;
+    NCCLCHK(ncclAllReduce(h->red_dev, h->red_dev, m, ncclDouble, rop, h->comm, h->stream));
+    HIPCHK(hipMemcpyAsync(n > 0 ? host_inout : &dummy, h->red_dev, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return drain(h);
+    });
+}
+
+int32_t demc_comm_stats(demc_handle* h, int64_t* out3) {
+    if (!h || !out3) return DEMC_EINVAL;
+    out3[0] = h->comm ? h->comm_world : 1;
+    out3[1] = h->comm ? h->comm_rank : 0;
+    out3[2] = h->n_exchanges;
+    return DEMC_OK;
+}
+
+// ---- single-process multi-GPU set: one host thread (a Julia task) drives every shard ----
+}  // extern "C"  (the struct below is C++)
+
+struct demc_multi {
+    std::vector<demc_handle*> shard;
+    bool rccl = false;              // distinct devices: one communicator per shard from ncclCommInitAll
+    std::vector<hipEvent_t> packed, copied;  // shared-device transport: rows packed / peers' rows copied
+    bool copied_valid = false;
+    std::string err;
+};
+
+namespace {
+int mfail(demc_multi* m, int code, const std::string& msg) noexcept {
+    if (m) {
+        try { m->err = msg; } catch (...) {}
+    }
+    return code;
+}
+// first failing shard's message becomes the set's
+int mshard_fail(demc_multi* m, int r, int code) {
+    return mfail(m, code, "shard " + std::to_string(r) + ": " + m->shard[(size_t)r]->err);
+}
+}  // namespace
+
+extern "C" {
+
+const char* demc_multi_last_error(demc_multi* m) { return m ? m->err.c_str() : "null set"; }
+
+int32_t demc_destroy_multi(demc_multi* m) {
+    return guarded(nullptr, [&]() -> int32_t {
+    if (!m) return DEMC_OK;
+    for (demc_handle* h : m->shard) {
+        if (!h) continue;
+        hipSetDevice(h->c.device_id);
+        if (h->stream) hipStreamSynchronize(h->stream);
+        if (h->comm) { ncclCommDestroy(h->comm); h->comm = nullptr; }
+        h->multi = nullptr;
+    }
+    for (size_t r = 0; r < m->shard.size(); ++r) {
+        if (m->shard[r]) hipSetDevice(m->shard[r]->c.device_id);
+        if (r < m->packed.size() && m->packed[r]) hipEventDestroy(m->packed[r]);
+        if (r < m->copied.size() && m->copied[r]) hipEventDestroy(m->copied[r]);
+        if (m->shard[r]) demc_destroy(m->shard[r]);
+    }
+    delete m;
+    return DEMC_OK;
+    });
+}
+
+int32_t demc_create_multi(const demc_config* cfg, int32_t n_shards, const int32_t* device_ids, demc_multi** out) {
+    if (!cfg || !out || n_shards < 1) return DEMC_EINVAL;
+    *out = nullptr;
+    demc_multi* m = new (std::nothrow) demc_multi();
+    if (!m) return DEMC_ENOMEM;
+    *out = m;  // returned even on failure so that demc_multi_last_error() can be read; the caller destroys it
+    return guarded(nullptr, [&]() -> int32_t {
+    if (cfg->n_groups % n_shards != 0) return mfail(m, DEMC_EINVAL, "n_groups (of the whole population) must divide by n_shards");
+    if (cfg->group_offset != 0 || (cfg->n_groups_total != 0 && cfg->n_groups_total != cfg->n_groups))
+        return mfail(m, DEMC_EINVAL, "demc_create_multi takes the configuration of the WHOLE population (group_offset 0)");
+    const int G = cfg->n_groups / n_shards;
+    std::vector<int> devs((size_t)n_shards);
+    bool distinct = true;
+    for (int r = 0; r < n_shards; ++r) {
+        devs[(size_t)r] = device_ids ? device_ids[r] : r;
+        for (int q = 0; q < r; ++q) distinct = distinct && devs[(size_t)q] != devs[(size_t)r];
+    }
+    m->shard.assign((size_t)n_shards, nullptr);
+    for (int r = 0; r < n_shards; ++r) {
+        demc_config c = *cfg;
+        c.n_groups = G; c.group_offset = r * G; c.n_groups_total = cfg->n_groups; c.device_id = devs[(size_t)r];
+        // one population on several GPUs: every shard takes the lane geometry of the unsharded run, so that the set
+        // reproduces a single handle bit for bit (demc_config.geometry_groups)
+        if (c.geometry_groups == 0) c.geometry_groups = cfg->n_groups;
+        const int rc = demc_create(&c, &m->shard[(size_t)r]);
+        if (rc != DEMC_OK) return mfail(m, rc, "shard " + std::to_string(r) + ": " + (m->shard[(size_t)r] ? m->shard[(size_t)r]->err : "demc_create"));
+        m->shard[(size_t)r]->multi = m;
+    }
+    if (n_shards > 1 && distinct) {
+        std::vector<ncclComm_t> comms((size_t)n_shards);
+        const ncclResult_t nr = ncclCommInitAll(comms.data(), n_shards, devs.data());
+        if (nr != ncclSuccess) return mfail(m, DEMC_ERCCL, std::string("ncclCommInitAll: ") + ncclGetErrorString(nr));
+        for (int r = 0; r < n_shards; ++r) {
+            demc_handle* h = m->shard[(size_t)r];
+            h->comm = comms[(size_t)r]; h->own_comm = false; h->comm_rank = r; h->comm_world = n_shards;
+        }
+        m->rccl = true;
+    } else if (n_shards > 1) {
+        // shards that share a device (several shards per GPU): the rows change hands by device-to-device copies ordered by
+        // events -- RCCL refuses two ranks on one device
+        m->packed.assign((size_t)n_shards, nullptr);
+        m->copied.assign((size_t)n_shards, nullptr);
+        for (int r = 0; r < n_shards; ++r) {
+            if (hipSetDevice(devs[(size_t)r]) != hipSuccess ||
+                hipEventCreateWithFlags(&m->packed[(size_t)r], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&m->copied[(size_t)r], hipEventDisableTiming) != hipSuccess)
+                return mfail(m, DEMC_EHIP, "creating the exchange events");
+        }
+    }
+    return DEMC_OK;
+    });
+}
+
+int32_t demc_multi_size(demc_multi* m) { return m ? (int32_t)m->shard.size() : 0; }
+demc_handle* demc_multi_shard(demc_multi* m, int32_t r) {
+    return (m && r >= 0 && (size_t)r < m->shard.size()) ? m->shard[(size_t)r] : nullptr;
+}
+
+// migration! of iteration `iter` over the whole set, enqueued on every shard's stream
+static int multi_exchange(demc_multi* m, int64_t iter) {
+    const int n = (int)m->shard.size();
+    for (int r = 0; r < n; ++r) {
+        demc_handle* h = m->shard[(size_t)r];
+        if (hipSetDevice(h->c.device_id) != hipSuccess) return mfail(m, DEMC_EHIP, "hipSetDevice");
+        if (!m->rccl && m->copied_valid)  // nobody may still be copying the rows this shard is about to overwrite
+            for (int q = 0; q < n; ++q)
+                if (q != r && hipStreamWaitEvent(h->stream, m->copied[(size_t)q], 0) != hipSuccess) return mfail(m, DEMC_EHIP, "hipStreamWaitEvent");
+        migration_enqueue(h, iter, own_rows(h), nullptr, true, false);
+        if (!m->rccl && hipEventRecord(m->packed[(size_t)r], h->stream) != hipSuccess) return mfail(m, DEMC_EHIP, "hipEventRecord");
+    }
+    if (m->rccl) {
+        // one host thread, several devices: the collective calls of all ranks go out as one group
+        ncclResult_t nr = ncclGroupStart();
+        for (int r = 0; r < n && nr == ncclSuccess; ++r) {
+            demc_handle* h = m->shard[(size_t)r];
+            const size_t cnt = (size_t)h->c.n_groups * ((size_t)h->c.D + 3);
+            nr = ncclAllGather(own_rows(h), h->mig_rows, cnt, ncclDouble, h->comm, h->stream);
+            h->n_exchanges += 1;
+        }
+        const ncclResult_t ne = ncclGroupEnd();
+        if (nr == ncclSuccess) nr = ne;
+        if (nr != ncclSuccess) return mfail(m, DEMC_ERCCL, std::string("ncclAllGather: ") + ncclGetErrorString(nr));
+    } else {
+        for (int r = 0; r < n; ++r) {
+            demc_handle* h = m->shard[(size_t)r];
+            if (hipSetDevice(h->c.device_id) != hipSuccess) return mfail(m, DEMC_EHIP, "hipSetDevice");
+            const size_t W = (size_t)h->c.D + 3, bytes = (size_t)h->c.n_groups * W * sizeof(double);
+            for (int q = 0; q < n; ++q) {
+                if (q == r) continue;
+                demc_handle* src = m->shard[(size_t)q];
+                if (hipStreamWaitEvent(h->stream, m->packed[(size_t)q], 0) != hipSuccess ||
+                    hipMemcpyAsync(h->mig_rows + (size_t)src->c.group_offset * W, own_rows(src), bytes, hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
+                    return mfail(m, DEMC_EHIP, "copying a peer's migration rows");
+            }
+            if (hipEventRecord(m->copied[(size_t)r], h->stream) != hipSuccess) return mfail(m, DEMC_EHIP, "hipEventRecord");
+            h->n_exchanges += 1;
+        }
+        m->copied_valid = true;
+    }
+    for (int r = 0; r < n; ++r) {
+        demc_handle* h = m->shard[(size_t)r];
+        if (hipSetDevice(h->c.device_id) != hipSuccess) return mfail(m, DEMC_EHIP, "hipSetDevice");
+        migration_enqueue(h, iter, nullptr, h->mig_rows, false, true);
+    }
+    return DEMC_OK;
+}
+
+int32_t demc_multi_step(demc_multi* m, int64_t iter0, int32_t n_iters) {
+    return guarded(nullptr, [&]() -> int32_t {
+    if (!m || m->shard.empty()) return DEMC_EINVAL;
+    const int n = (int)m->shard.size();
+    for (int r = 0; r < n; ++r) {
+        const int rc = step_checks(m->shard[(size_t)r], iter0, n_iters);
+        if (rc != DEMC_OK) return mshard_fail(m, r, rc);
+    }
+    demc_handle* h0 = m->shard[0];
+    for (int64_t it = iter0; it < iter0 + n_iters;) {
+        // the alpha coin is a pure function of (seed, iteration): every shard sees the same runs (main.jl:85)
+        const bool due = n > 1 && migration_due_h(h0, it);
+        int run = 1;
+        while (it + run < iter0 + n_iters && !(n > 1 && migration_due_h(h0, it + run))) ++run;
+        if (due) {
+            const int rc = multi_exchange(m, it);
+            if (rc != DEMC_OK) return rc;
+        }
+        for (int r = 0; r < n; ++r) {  // every shard's update enqueued before any is waited for: the GPUs run side by side
+            demc_handle* h = m->shard[(size_t)r];
+            if (hipSetDevice(h->c.device_id) != hipSuccess) return mfail(m, DEMC_EHIP, "hipSetDevice");
+            // (a single shard keeps its on-device migration inside the update)
+            const int rc = step_body(h, it, run, n == 1);
+            if (rc != DEMC_OK) return mshard_fail(m, r, rc);
+        }
+        it += run;
+    }
+    for (int r = 0; r < n; ++r) {
+        demc_handle* h = m->shard[(size_t)r];
+        if (hipSetDevice(h->c.device_id) != hipSuccess) return mfail(m, DEMC_EHIP, "hipSetDevice");
+        const int rc = drain(h);
+        if (rc != DEMC_OK) return mshard_fail(m, r, rc);
+    }
     return DEMC_OK;
     });
 }

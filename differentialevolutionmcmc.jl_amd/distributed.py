@@ -9,6 +9,13 @@ is split around the exchange:
     apply  : every rank derives the same group subset and circular shift from the shared Philox STEP stream
              (select_groups + shift_particles!, migration.jl:31-35, 84-91) and overwrites its own selected slots.
 All randomness is keyed by GLOBAL group / slot indices, so an N-rank run reproduces the 1-rank run bit for bit.
+
+Two homes for the collective:
+    collective="library" : the engine's own RCCL communicator behind the C-ABI (demc_comm_init, include/demc.h) -- what a
+                           Julia or C host uses; torch.distributed (any backend, gloo will do) only carries the 128-byte
+                           communicator id from rank 0 to the others, then demc_step does the whole sharded iteration;
+    collective="torch"   : torch.distributed.all_gather_into_tensor between demc_migration_pack / _apply (the exchange
+                           halves of the C-ABI) -- the form the CPU tests drive over gloo with the oracle as the engine.
 """
 import numpy as np
 
@@ -17,7 +24,7 @@ class ShardedDriver:
     """Drives one engine shard.  `engine` follows the engine interface (HipEngine, or the CPU oracle when a TEST
     injects it); `dist` is torch.distributed (or None for a single shard)."""
 
-    def __init__(self, engine, dist=None, device=None, stream_ordered=False, async_migration=False):
+    def __init__(self, engine, dist=None, device=None, stream_ordered=False, async_migration=False, collective="torch"):
         import torch
         self.torch = torch
         self.eng = engine
@@ -28,6 +35,21 @@ class ShardedDriver:
         Gt = engine.cfg.n_groups_total
         if G * self.world != Gt:
             raise ValueError(f"n_groups_total={Gt} must equal world_size*n_groups={self.world}*{G}")
+        if collective not in ("torch", "library"):
+            raise ValueError("collective is 'torch' or 'library'")
+        self.library = collective == "library"
+        if self.library:
+            # the host's control plane carries the communicator id; the data path never leaves the library
+            rank = self.dist.get_rank() if self.dist else 0
+            box = [engine.comm_unique_id() if rank == 0 else None]
+            if self.dist:
+                self.dist.broadcast_object_list(box, src=0)
+            engine.comm_init(box[0], rank, self.world)
+            engine.comm_set_overlap(bool(async_migration))
+            self.async_migration = bool(async_migration)
+            self.stream_ordered, self.stream, self.side, self.on_device = False, None, None, True
+            self._n_exchanges = 0
+            return
         self.rows = torch.zeros((G, D + 3), dtype=torch.float64, device=self.device)
         self.all_rows = torch.zeros((Gt, D + 3), dtype=torch.float64, device=self.device)
         self.on_device = self.device.type == "cuda"
@@ -40,7 +62,7 @@ class ShardedDriver:
         if self.stream_ordered:
             self.stream = torch.cuda.Stream(device=self.device)
             engine.set_stream(self.stream.cuda_stream)
-        self.n_exchanges = 0
+        self._n_exchanges = 0
         # per-group-asynchronous migration: the groups an exchange does not select start their update while the
         # all-gather is still in flight (on a side stream); only the selected groups wait for it
         self.async_migration = bool(async_migration)
@@ -73,12 +95,15 @@ class ShardedDriver:
             else:
                 self.all_rows.copy_(self.rows)
             self.eng.migration_apply(it, self.all_rows.numpy())
-        self.n_exchanges += 1
+        self._n_exchanges += 1
 
     def _exchange_async(self, it, run):
         """migration of iteration `it` + the update of iterations [it, it + run), with the groups the exchange did not select
-        updating while the collective is in flight.  Groups never interact inside update! (main.jl:135-167), so the result is
-        the one _exchange + update give, bit for bit."""
+        updating while the collective is in flight.  Groups never interact inside update! (main.jl:135-167), so draws and
+        decisions are the ones _exchange + update give -- bit for bit whenever the subset update runs the same kernel form
+        as the full update; where it does not (MvNormal STREAMING on small populations: the full update takes the
+        streaming-resident form, a subset update the K1 -> K2 -> K3 chain) the log-densities agree to rounding.  The engine
+        refuses subset updates while a migration sub-group is replayed (migration_groups does not see the replay)."""
         t = self.torch
         G, off = self.eng.cfg.n_groups, self.eng.cfg.group_offset
         sel = self.eng.migration_groups(it)
@@ -108,11 +133,17 @@ class ShardedDriver:
                 work.wait()
             self.eng.migration_apply(it, self.all_rows.numpy())
             self.eng.update_groups_enqueue(it, run, mine)
-        self.n_exchanges += 1
+        self._n_exchanges += 1
+
+    @property
+    def n_exchanges(self):
+        return self.eng.comm_stats()["exchanges"] if self.library else self._n_exchanges
 
     def step(self, iter0, n_iters):
         """n_iters of step!/pstep! (main.jl:84-107); runs of iterations without a migration event go to the engine
         as one call."""
+        if self.library:  # demc_step on a handle with a communicator IS the sharded iteration
+            return self.eng.step_enqueue(iter0, n_iters)
         if self.stream is not None:
             with self.torch.cuda.stream(self.stream):
                 return self._step(iter0, n_iters)
@@ -135,7 +166,9 @@ class ShardedDriver:
 
     def synchronize(self):
         """drain the engine's stream (the asynchronous form only enqueues)"""
-        if self.stream is not None:
+        if self.library:
+            self.eng.synchronize()
+        elif self.stream is not None:
             self.stream.synchronize()
         elif self.on_device:
             self.torch.cuda.current_stream().synchronize()

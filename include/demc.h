@@ -32,14 +32,14 @@
 extern "C" {
 #endif
 
-#define DEMC_VERSION 110 /* 0.1.1 */
+#define DEMC_VERSION 120 /* 0.1.2 */
 
 enum {
     DEMC_OK = 0,
     DEMC_EINVAL = 1,       /* bad argument / inconsistent configuration */
     DEMC_EHIP = 2,         /* HIP runtime error (message has hipGetErrorString) */
     DEMC_ENOMEM = 3,
-    DEMC_ERCCL = 4,        /* reserved for a library-owned communicator */
+    DEMC_ERCCL = 4,        /* RCCL error on the handle's communicator (message has ncclGetErrorString) */
     DEMC_EUNSUPPORTED = 5  /* hook / model outside the registered family: no CPU fallback */
 };
 
@@ -185,8 +185,14 @@ int32_t demc_get_history(demc_handle* h, int64_t row0, int64_t row1, double* the
 int32_t demc_export_chains(demc_handle* h, int64_t row0, int64_t row1, int32_t layout, double* host_out);
 
 /* n_iters of step!/pstep! (main.jl:84-107) starting at de.iter == iter0 (1-based, n_initial included):
- * migration coin + exchange (single shard only), update of every group, store. */
+ * migration coin + exchange, update of every group, store.  On a sharded handle (n_groups_total > n_groups) the exchange is
+ * the one collective of the path and needs the handle's communicator (demc_comm_init below); without one the call fails
+ * at the first migration. */
 int32_t demc_step(demc_handle* h, int64_t iter0, int32_t n_iters);
+/* the same, ENQUEUED ONLY on the handle's stream; demc_synchronize drains it and reports what went wrong meanwhile (for a
+ * host that drives several handles from one thread, like one task per group in p_update!, main.jl:135-148) */
+int32_t demc_step_async(demc_handle* h, int64_t iter0, int32_t n_iters);
+int32_t demc_synchronize(demc_handle* h);
 /* update! + store_samples! only (main.jl:86-87): for drivers that run the migration exchange themselves */
 int32_t demc_update(demc_handle* h, int64_t iter0, int32_t n_iters);
 
@@ -209,11 +215,62 @@ int32_t demc_migration_apply_async(demc_handle* h, int64_t iter, const double* d
  *   demc_migration_groups     : select_groups' ordered sub-group of iteration `iter` (GLOBAL group indices, sel has room for
  *                               n_groups_total entries) -- a pure function of (seed, iter), what k_mig_apply derives on the device.
  *   demc_update_groups_async  : update! + store_samples! (like demc_update) for a SUBSET of this handle's groups (local indices),
- *                               enqueued on the handle's stream WITHOUT draining it.
+ *                               enqueued on the handle's stream WITHOUT draining it.  Refused while a migration sub-group is
+ *                               replayed (demc_migration_groups does not see the replay).
  * A sharded driver enqueues  pack -> [all-gather on a side stream] ; update(groups not selected) ; wait for the gather ;
  * apply ; update(selected groups)  -- the collective overlaps the update of the unselected groups (distributed.py). */
 int32_t demc_migration_groups(const demc_config* cfg, int64_t iter, int32_t* sel, int32_t* n_sel);
 int32_t demc_update_groups_async(demc_handle* h, int64_t iter0, int32_t n_iters, const int32_t* local_groups, int32_t n);
+/* ---- The one collective behind the boundary: an RCCL communicator owned by the handle. ----
+ * migration! (migration.jl:11-19, called from step!/pstep!, main.jl:85,103) exchanges one candidate particle per group
+ * between groups; with groups sharded over GPUs that is ONE all-gather of [n_groups][D+3] doubles per rank and migration
+ * event (xGMI, RCCL), everything else of the iteration is shard-local (groups never interact inside update!/p_update!,
+ * main.jl:135-167).  One process per GPU:
+ *   rank 0:      demc_comm_unique_id(id)            -- ncclGetUniqueId; the host carries the 128 bytes to the other ranks by
+ *                                                      whatever it has (MPI.bcast, Distributed.jl, a file, a pipe)
+ *   every rank:  demc_create(cfg with n_groups = G, group_offset = rank*G, n_groups_total = world*G, device_id = local GPU)
+ *                demc_comm_init(h, id, rank, world) -- ncclCommInitRank on the handle's device (collective: all ranks call it)
+ *   then         demc_step(h, iter0, n)             -- the whole sharded iteration: alpha coin (same on every rank), pack ->
+ *                                                      ncclAllGather on the handle's stream -> apply, update, store; an
+ *                                                      N-rank run makes the draws and decisions of the 1-rank run
+ * demc_comm_set_overlap(h, 1): per-group-asynchronous migration -- the all-gather runs on a side stream while
+ *   the groups the exchange did not select are updated; the selected groups wait for it.  Same draws and decisions; a
+ *   log-density can differ in its last bits where the subset update takes another kernel form (MvNormal STREAMING on small
+ *   populations: the subset update does not use the streaming-resident form).  Ignored while a replay is set.
+ * demc_migration_exchange[_async]: pack -> all-gather -> apply of iteration `iter` alone, for a host that calls demc_update
+ *   itself (the `_async` form only enqueues).
+ * demc_comm_allreduce: host doubles reduced over the ranks (op 0 sum, 1 max, 2 min; n = 0: a barrier) -- what a host without
+ *   MPI needs for the reference's own reductions at the end (timing, posterior means); one rank: no-op.
+ * demc_comm_stats: out3 = (world, rank, all-gathers issued so far).
+ * Failures of RCCL come back as DEMC_ERCCL with ncclGetErrorString in demc_last_error. */
+#define DEMC_COMM_ID_BYTES 128
+int32_t demc_comm_unique_id(void* id_out, int32_t nbytes);
+int32_t demc_comm_init(demc_handle* h, const void* unique_id, int32_t rank, int32_t world);
+int32_t demc_comm_destroy(demc_handle* h);
+int32_t demc_comm_set_overlap(demc_handle* h, int32_t on);
+int32_t demc_migration_exchange(demc_handle* h, int64_t iter);
+int32_t demc_migration_exchange_async(demc_handle* h, int64_t iter);
+int32_t demc_comm_allreduce(demc_handle* h, double* host_inout, int32_t n, int32_t op);
+int32_t demc_comm_stats(demc_handle* h, int64_t* out3);
+
+/* ---- The same for a SINGLE-PROCESS host (one Julia task driving all GPUs of the node; SURVEY 8b "demc_create_multi"). ----
+ * cfg describes the WHOLE population (n_groups = all groups, group_offset = 0); shard r owns groups [r*G, (r+1)*G),
+ * G = n_groups / n_shards, on device device_ids[r] (NULL: 0..n_shards-1).  Distinct devices get one RCCL communicator each
+ * (ncclCommInitAll) and the exchange is one grouped ncclAllGather; shards that share a device (several shards per GPU)
+ * hand their rows over by device-to-device copies.  Every shard is sized with the lane geometry of the whole population
+ * (demc_config.geometry_groups), so the set reproduces a single handle of n_groups groups bit for bit.
+ *   demc_multi_shard(m, r) : the shard's handle, for the per-shard calls -- demc_set_model / _priors / _bounds / _blocks (the
+ *                            same on every shard), demc_set_state / demc_get_state / demc_get_history with the shard's own
+ *                            P/n_shards particles.  Shards are destroyed with the set.
+ *   demc_multi_step        : n_iters of step! over the set: every shard's work is enqueued before any shard is waited for. */
+typedef struct demc_multi demc_multi;
+int32_t demc_create_multi(const demc_config* cfg, int32_t n_shards, const int32_t* device_ids, demc_multi** out);
+int32_t demc_destroy_multi(demc_multi* m);
+const char* demc_multi_last_error(demc_multi* m);
+int32_t demc_multi_size(demc_multi* m);
+demc_handle* demc_multi_shard(demc_multi* m, int32_t r);
+int32_t demc_multi_step(demc_multi* m, int64_t iter0, int32_t n_iters);
+
 /* shift_particles! (migration.jl:84-91) with a HOST-drawn plan: for every k, slot dst_slot[k] receives the row
  * (theta, weight, id) that slot src_slot[k] held BEFORE the call -- all reads precede all writes, so a cycle is a
  * rotation.  For a caller that keeps migration!'s own random choices (select_groups / select_particles,

@@ -1,0 +1,167 @@
+"""The one collective behind the C-ABI (include/demc.h "The one collective"): migration! (migration.jl:11-19,
+called from step!/pstep!, main.jl:85,103) with groups sharded over GPUs, reachable by a host that has neither Python nor
+torch -- demc_comm_init / demc_step for one process per GPU, demc_create_multi / demc_multi_step for one host thread.
+
+A 1-GPU box can run RCCL at world size 1 only (two ranks on one device are refused), so the communicator path is checked at
+world 1 against demc_step's own on-device migration, and the rank logic (offsets, who receives whose candidate) through a
+two-shard set whose shards share the device."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import make_problem, setup_engine
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def D():
+    import demc_amd
+    return demc_amd
+
+
+def _run_single(D, prob, G, Np, n_it, th0, **kw):
+    e = D.HipEngine(n_groups=G, Np=Np, D=prob["D"], n_rows=n_it, schedule=2, **kw)
+    setup_engine(e, prob)
+    e.set_state(th0)
+    e.step(1, n_it)
+    out = e.get_history(0, n_it) + e.get_state()
+    e.close()
+    return out
+
+
+@pytest.mark.parametrize("family,kw", [("mvn_full", dict(loglike_mode=1)), ("gaussian", dict()), ("hier_binomial", dict())])
+def test_library_communicator_at_world_one_equals_demc_step(D, family, kw):
+    """demc_comm_unique_id -> demc_comm_init -> demc_step: pack -> ncclAllGather on the handle's stream -> apply, through
+    the C-ABI alone (no torch.distributed anywhere), reproduces demc_step's on-device migration bit for bit; so does the
+    overlapped form (all-gather on the side stream, unselected groups updating meanwhile), and demc_migration_exchange +
+    demc_update driven from the host."""
+    prob = make_problem(family, np.random.default_rng(71), N=300, d=6, S=300)
+    G, Np, n_it = 10, 8, 40
+    th0 = prob["init"](G * Np)
+    cfg = dict(seed=29, alpha=0.5, burnin=10, trace=0, **kw)
+    ref = _run_single(D, prob, G, Np, n_it, th0, **cfg)
+    for form in ("step", "overlap", "host_loop"):
+        e = D.HipEngine(n_groups=G, Np=Np, D=prob["D"], n_rows=n_it, schedule=2, **cfg)
+        setup_engine(e, prob)
+        e.set_state(th0)
+        e.comm_init(D.HipEngine.comm_unique_id(), 0, 1)
+        if form == "overlap":
+            e.comm_set_overlap(True)
+        if form == "host_loop":
+            for it in range(1, n_it + 1):
+                if e.migration_due(it):
+                    e.migration_exchange_enqueue(it)
+                e.update(it, 1)
+        else:
+            e.step(1, n_it)
+        st = e.comm_stats()
+        assert st["world"] == 1 and st["rank"] == 0 and st["exchanges"] >= 10
+        out = e.get_history(0, n_it) + e.get_state()
+        e.comm_destroy()
+        e.close()
+        for i, (x, y) in enumerate(zip(ref, out)):
+            assert np.array_equal(x, y), f"{form}: array {i}"
+
+
+def test_communicator_shape_is_checked_and_a_sharded_step_needs_one(D):
+    prob = make_problem("gaussian", np.random.default_rng(72))
+    e = D.HipEngine(n_groups=4, Np=6, D=2, n_rows=8, schedule=2, seed=3, alpha=1.0, group_offset=4, n_groups_total=8)
+    setup_engine(e, prob)
+    e.set_state(prob["init"](24))
+    with pytest.raises(D.DemcError) as err:  # migration due at once (alpha = 1) and nobody to exchange with
+        e.step(1, 2)
+    assert err.value.code == D._ffi.EINVAL and "communicator" in str(err.value)
+    uid = D.HipEngine.comm_unique_id()
+    assert len(uid) == 128 and uid != D.HipEngine.comm_unique_id()
+    for rank, world in ((0, 2), (1, 3), (2, 2), (0, 1)):  # offset 4 of 8 groups is rank 1 of 2, nothing else
+        with pytest.raises(D.DemcError) as err:
+            e.comm_init(uid, rank, world)
+        assert err.value.code == D._ffi.EINVAL
+    with pytest.raises(D.DemcError):
+        e.comm_set_overlap(True)  # no communicator yet
+    with pytest.raises(D.DemcError):
+        e.migration_exchange(1)
+    np.testing.assert_array_equal(e.comm_allreduce([1.5, -2.0], "max"), [1.5, -2.0])  # one rank: the values stand
+    e.close()
+
+
+@pytest.mark.parametrize("n_shards", [1, 2, 4])
+def test_multi_set_equals_one_handle(D, n_shards):
+    """demc_create_multi / demc_multi_step: one host thread, n shards (here sharing the one device: rows change hands by
+    event-ordered device-to-device copies), every shard sized with the geometry of the whole population: history and
+    state of the set == the single handle of all groups, bit for bit -- offsets, the circular shift across shard borders
+    and the stream ordering of pack / exchange / apply / update included."""
+    prob = make_problem("mvn_full", np.random.default_rng(73), N=400, d=8)
+    G, Np, n_it = 16, 16, 50
+    th0 = prob["init"](G * Np)
+    cfg = dict(seed=31, alpha=0.4, burnin=12, trace=0, loglike_mode=1, theta_snooker=0.1)
+    ref = _run_single(D, prob, G, Np, n_it, th0, geometry_groups=G, **cfg)
+    m = D.MultiEngine(n_shards, device_ids=[0] * n_shards, n_groups=G, Np=Np, D=prob["D"], n_rows=n_it, schedule=2, **cfg)
+    m.each(lambda e: setup_engine(e, prob))
+    m.set_state(th0)
+    m.step(1, 20)
+    m.step(21, n_it - 20)
+    out = m.get_history(0, n_it) + m.get_state()
+    if n_shards > 1:
+        assert all(e.comm_stats()["exchanges"] >= 10 for e in m.shards)
+        with pytest.raises(D.DemcError):
+            m.shards[0].step(1, n_it)  # a shard cannot run a migration on its own
+    m.close()
+    for i, (x, y) in enumerate(zip(ref, out)):
+        assert np.array_equal(x, y), f"array {i}"
+
+
+def test_multi_set_rejects_bad_shapes(D):
+    with pytest.raises(D.DemcError) as err:
+        D.MultiEngine(3, device_ids=[0, 0, 0], n_groups=8, Np=6, D=2)
+    assert err.value.code == D._ffi.EINVAL and "divide" in str(err.value)
+    with pytest.raises(D.DemcError):
+        D.MultiEngine(2, device_ids=[0, 0], n_groups=8, Np=6, D=2, group_offset=2)
+
+
+def test_sharded_driver_with_the_library_collective(D):
+    """ShardedDriver(collective="library"): torch.distributed (gloo: no second RCCL communicator) only carries the id"""
+    import torch
+    import torch.distributed as dist
+    from demc_amd.distributed import ShardedDriver
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        prob = make_problem("mvn_full", np.random.default_rng(74), N=200, d=6)
+        G, Np, n_it = 6, 16, 40
+        th0 = prob["init"](G * Np)
+        cfg = dict(seed=17, alpha=0.4, burnin=10, trace=0, loglike_mode=1)
+        ref = _run_single(D, prob, G, Np, n_it, th0, **cfg)
+        for overlap in (False, True):
+            e = D.HipEngine(n_groups=G, Np=Np, D=prob["D"], n_rows=n_it, schedule=2, **cfg)
+            setup_engine(e, prob)
+            e.set_state(th0)
+            drv = ShardedDriver(e, dist, torch.device("cuda", 0), async_migration=overlap, collective="library")
+            drv.step(1, n_it)
+            drv.synchronize()
+            assert drv.n_exchanges >= 5
+            out = e.get_history(0, n_it) + e.get_state()
+            e.close()
+            for x, y in zip(ref, out):
+                assert np.array_equal(x, y)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_plain_c_multi_rank_driver(tmp_path):
+    """tools/demc_cdriver.c --ranks 1: fork before the GPU is touched, id through a pipe, demc_comm_init, demc_step with
+    the exchange inside, demc_comm_allreduce for the posterior mean -- a host with neither Python nor MPI"""
+    libdir = os.path.join(ROOT, "differentialevolutionmcmc.jl_amd")
+    exe = str(tmp_path / "demc_cdriver")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "demc_cdriver.c"), "-o", exe,
+                           "-L", libdir, "-ldemc_hip", "-lm", "-Wl,-rpath-link,/opt/rocm/lib"])
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    for extra in ([], ["--overlap"]):
+        out = subprocess.run([exe, "--ranks", "1"] + extra, env=env, capture_output=True, text=True, timeout=180)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "C-ABI multi-rank driver OK" in out.stdout and "world 1" in out.stdout

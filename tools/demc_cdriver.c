@@ -1,7 +1,8 @@
 /* demc_cdriver.c -- plain-C caller of the C-ABI (include/demc.h), the way a non-Python host (the Julia @ccall shim of
  * julia/DEMCHIP.jl, or any FFI) drives the library: Examples/Gaussian_Example.jl end to end.
  * Build: gcc -O2 -I include tools/demc_cdriver.c -o tools/demc_cdriver -L differentialevolutionmcmc.jl_amd -ldemc_hip -lm
- * Run  : LD_LIBRARY_PATH=differentialevolutionmcmc.jl_amd ./tools/demc_cdriver      (needs an MI355X) */
+ * Run  : LD_LIBRARY_PATH=differentialevolutionmcmc.jl_amd ./tools/demc_cdriver      (needs an MI355X)
+ *        ... ./tools/demc_cdriver --ranks N [--overlap]   one process per GPU, exchange through the library's communicator */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -111,7 +112,111 @@ static int nested_blocked_sequence(void) {
     return ok ? 0 : 3;
 }
 
-int main(void) {
+/* ---- multi-rank mode: `demc_cdriver --ranks N` ------------------------------------------------------------------------
+ * One process per GPU, the way a Julia host would start its workers (Distributed.jl / MPI.jl): the parent forks N ranks
+ * BEFORE anything has touched the GPU; rank 0 draws the communicator id (demc_comm_unique_id) and hands its 128 bytes to the
+ * other ranks through pipes; every rank creates its shard (4 groups of the 4*N-group population, device = rank), joins
+ * the communicator (demc_comm_init) and calls demc_step -- which does the whole sharded iteration, the migration
+ * all-gather included.  The posterior mean is reduced over the ranks with demc_comm_allreduce (no MPI in sight). */
+#include <sys/types.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+static int run_rank(int rank, int world, int device, const unsigned char* id, int overlap) {
+    enum { N = 50, GL = 4, NP = 6, P = GL * NP, D = 2, N_ITER = 2000, BURN = 1000 };
+    unsigned long long s = 50514; /* the same data on every rank (the dataset is replicated) */
+    double data[N];
+    for (int i = 0; i < N; ++i) data[i] = sqrt(-2.0 * log(1.0 - lcg(&s))) * cos(6.283185307179586 * lcg(&s));
+    demc_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.n_groups = GL; cfg.Np = NP; cfg.D = D; cfg.burnin = BURN; cfg.n_rows = N_ITER;
+    cfg.alpha = 0.1; cfg.beta = 0.1; cfg.eps = 0.001; cfg.sigma = 0.05; cfg.kappa = 1.0;
+    cfg.schedule = DEMC_SCHED_TWO_COLOUR; cfg.store_history = 1; cfg.seed = 20261003;
+    cfg.group_offset = rank * GL; cfg.n_groups_total = world * GL; cfg.device_id = device;
+    cfg.geometry_groups = world * GL; /* every shard sized like the whole population: N ranks == 1 rank, bit for bit */
+    demc_handle* h = NULL;
+    CK(demc_create(&cfg, &h));
+    CK(demc_comm_init(h, id, rank, world));
+    if (overlap) CK(demc_comm_set_overlap(h, 1));
+    const int64_t dims[1] = {N};
+    CK(demc_set_model(h, DEMC_FAM_GAUSSIAN, data, dims, 1, NULL, 0));
+    const int32_t kind[D] = {DEMC_PRIOR_NORMAL, DEMC_PRIOR_HALFCAUCHY};
+    const double a[D] = {0.0, 0.0}, b[D] = {1.0, 1.0};
+    const int32_t ref[D] = {0, 0};
+    CK(demc_set_priors(h, kind, a, b, ref));
+    const double lo[D] = {-INFINITY, 0.0}, hi[D] = {INFINITY, INFINITY};
+    CK(demc_set_bounds(h, lo, hi));
+    unsigned long long sp = 777 + 13 * (unsigned long long)rank; /* prior draws of this rank's particles */
+    double theta[P * D];
+    for (int p = 0; p < P; ++p) {
+        theta[p * D] = 2.0 * lcg(&sp) - 1.0;
+        theta[p * D + 1] = 0.2 + 2.0 * lcg(&sp);
+    }
+    CK(demc_set_state(h, theta, NULL, NULL));
+    CK(demc_step(h, 1, N_ITER)); /* migration exchanges happen inside */
+    const int keep = N_ITER - BURN;
+    double* hist = (double*)malloc(sizeof(double) * (size_t)keep * P * D);
+    CK(demc_get_history(h, BURN, N_ITER, hist, NULL, NULL, NULL));
+    double red[3] = {0, 0, (double)keep * P}; /* sums of mu, sigma and the count, reduced over the ranks */
+    for (long long i = 0; i < (long long)keep * P; ++i) {
+        red[0] += hist[i * D];
+        red[1] += hist[i * D + 1];
+    }
+    free(hist);
+    CK(demc_comm_allreduce(h, red, 3, 0));
+    int64_t st[3];
+    CK(demc_comm_stats(h, st));
+    double xbar = 0;
+    for (int i = 0; i < N; ++i) xbar += data[i] / N;
+    const double mu = red[0] / red[2], sg = red[1] / red[2];
+    const int ok = fabs(mu - xbar) < 0.1 && sg > 0.6 && sg < 1.6 && st[0] == world && st[1] == rank && st[2] > 50;
+    if (rank == 0)
+        printf("multi-rank: world %d%s, %lld all-gathers, posterior mean over all ranks mu=%.4f (data mean %.4f) sigma=%.4f -> %s\n",
+               world, overlap ? " (overlapped exchange)" : "", (long long)st[2], mu, xbar, sg, ok ? "OK" : "FAILED");
+    CK(demc_comm_destroy(h));
+    demc_destroy(h);
+    return ok ? 0 : 4;
+}
+
+static int multi_rank(int world, int overlap, int same_device) {
+    int (*pipes)[2] = malloc(sizeof(int[2]) * (size_t)world);
+    for (int r = 1; r < world; ++r)
+        if (pipe(pipes[r]) != 0) return 5;
+    pid_t* pid = malloc(sizeof(pid_t) * (size_t)world);
+    for (int r = 0; r < world; ++r) {
+        pid[r] = fork(); /* before any HIP / RCCL call in this process */
+        if (pid[r] < 0) return 5;
+        if (pid[r] == 0) {
+            unsigned char id[DEMC_COMM_ID_BYTES];
+            if (r == 0) {
+                if (demc_comm_unique_id(id, sizeof id) != DEMC_OK) _exit(6);
+                for (int q = 1; q < world; ++q)
+                    if (write(pipes[q][1], id, sizeof id) != (ssize_t)sizeof id) _exit(6);
+            } else if (read(pipes[r][0], id, sizeof id) != (ssize_t)sizeof id)
+                _exit(6);
+            const int rc_rank = run_rank(r, world, same_device ? 0 : r, id, overlap);
+            fflush(NULL); /* _exit does not flush stdio */
+            _exit(rc_rank);
+        }
+    }
+    int rc = 0;
+    for (int r = 0; r < world; ++r) {
+        int st = 0;
+        waitpid(pid[r], &st, 0);
+        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = rc ? rc : (WIFEXITED(st) ? WEXITSTATUS(st) : 7);
+    }
+    free(pid);
+    free(pipes);
+    puts(rc == 0 ? "C-ABI multi-rank driver OK" : "C-ABI multi-rank driver FAILED");
+    return rc;
+}
+
+int main(int argc, char** argv) {
+    if (argc >= 3 && strcmp(argv[1], "--ranks") == 0) {
+        int overlap = 0;
+        for (int i = 3; i < argc; ++i) overlap = overlap || strcmp(argv[i], "--overlap") == 0;
+        return multi_rank(atoi(argv[2]), overlap, 0);
+    }
     enum { N = 50, G = 4, NP = 6, P = G * NP, D = 2, N_ITER = 3000, BURN = 1500 };
     unsigned long long s = 50514;
     double data[N];
