@@ -114,6 +114,37 @@ function flat_bounds(de, Θ)
     return lo, hi
 end
 
+"DE keyword constructor (src/structs.jl:80-131) -> demc_config for a handle that owns `n_groups` groups starting at `group_offset`"
+function make_config(de::DE, D::Int, n_iter::Int, b; n_groups = de.n_groups, group_offset = 0, device_id = b.device_id)
+    sched = b.schedule == :two_colour ? 2 : b.schedule == :synchronous ? 1 : 0
+    return DemcConfig(n_groups, de.Np, D, 0, de.burnin, de.n_initial, n_iter + de.n_initial,
+        de.α, de.β, de.ϵ, de.σ, de.κ, de.θsnooker,
+        hook_code(de.generate_proposal, PROPOSALS, "generate_proposal"), hook_code(de.sample, PARTNERS, "sample"),
+        hook_code(de.update_particle!, UPDATES, "update_particle!"), hook_code(de.evaluate_fitness!, FITNESS, "evaluate_fitness!"),
+        sched, 1, group_offset, de.n_groups, b.seed, device_id, b.loglike_mode == :streaming ? 0 : 1, 0, 0, de.n_groups, 0)
+end
+
+"model, priors, bounds, the prior-draw history rows and the particles `ps` (one shard's, in slot order) onto handle `h`"
+function load_handle!(h, m::ModelSpec, de::DE, ps)
+    GC.@preserve m begin
+        check(h, @ccall LIB.demc_set_model(h::Ptr{Cvoid}, m.family::Int32, m.data::Ptr{Float64}, m.dims::Ptr{Int64},
+            Int32(length(m.dims))::Int32, m.hyper::Ptr{Float64}, Int32(length(m.hyper))::Int32)::Int32)
+        check(h, @ccall LIB.demc_set_priors(h::Ptr{Cvoid}, m.prior_kind::Ptr{Int32}, m.prior_a::Ptr{Float64},
+            m.prior_b::Ptr{Float64}, m.prior_ref::Ptr{Int32})::Int32)
+    end
+    lo, hi = flat_bounds(de, ps[1].Θ)
+    check(h, @ccall LIB.demc_set_bounds(h::Ptr{Cvoid}, lo::Ptr{Float64}, hi::Ptr{Float64})::Int32)
+    if de.n_initial > 0   # initialize_samples (utilities.jl:35-39): rows 1:n_initial, [row][particle][D]
+        rows = Float64[x for i = 1:de.n_initial for p in ps for x in Iterators.flatten(de.samples[i, :, p.id])]
+        check(h, @ccall LIB.demc_set_history_rows(h::Ptr{Cvoid}, 0::Int64, Int64(de.n_initial)::Int64, rows::Ptr{Float64})::Int32)
+    end
+    theta = Float64[x for p in ps for x in flatten(p.Θ)]              # D x P column-major == [P][D] row-major
+    weight = Float64[p.weight for p in ps]                            # evaluated by sample_init on the host
+    ids = Int64[p.id - 1 for p in ps]                                 # ids are 0-based across the ABI
+    check(h, @ccall LIB.demc_set_state(h::Ptr{Cvoid}, theta::Ptr{Float64}, weight::Ptr{Float64}, ids::Ptr{Int64})::Int32)
+    return nothing
+end
+
 """
     sample(model::DEModel, de::DE, backend::HIPBackend, n_iter; model_spec, progress=false)
 
@@ -125,37 +156,16 @@ function sample(model::DEModel, de::DE, b::HIPBackend, n_iter::Int; model_spec::
     particles = vcat(groups...)
     P = length(particles); D = length(flatten(particles[1].Θ))
     shapes, lens, offs = layout(particles[1].Θ)
-    sched = b.schedule == :two_colour ? 2 : b.schedule == :synchronous ? 1 : 0
-    cfg = DemcConfig(de.n_groups, de.Np, D, 0, de.burnin, de.n_initial, n_iter + de.n_initial,
-        de.α, de.β, de.ϵ, de.σ, de.κ, de.θsnooker,
-        hook_code(de.generate_proposal, PROPOSALS, "generate_proposal"), hook_code(de.sample, PARTNERS, "sample"),
-        hook_code(de.update_particle!, UPDATES, "update_particle!"), hook_code(de.evaluate_fitness!, FITNESS, "evaluate_fitness!"),
-        sched, 1, 0, de.n_groups, b.seed, b.device_id, b.loglike_mode == :streaming ? 0 : 1, 0, 0, 0, 0)
+    cfg = make_config(de, D, n_iter, b)
     href = Ref{Ptr{Cvoid}}(C_NULL)
     rc = @ccall LIB.demc_create(Ref(cfg)::Ptr{DemcConfig}, href::Ptr{Ptr{Cvoid}})::Int32
     h = href[]
     try
         check(h, rc)
-        m = model_spec
-        GC.@preserve m begin
-            check(h, @ccall LIB.demc_set_model(h::Ptr{Cvoid}, m.family::Int32, m.data::Ptr{Float64}, m.dims::Ptr{Int64},
-                Int32(length(m.dims))::Int32, m.hyper::Ptr{Float64}, Int32(length(m.hyper))::Int32)::Int32)
-            check(h, @ccall LIB.demc_set_priors(h::Ptr{Cvoid}, m.prior_kind::Ptr{Int32}, m.prior_a::Ptr{Float64},
-                m.prior_b::Ptr{Float64}, m.prior_ref::Ptr{Int32})::Int32)
-        end
-        lo, hi = flat_bounds(de, particles[1].Θ)
-        check(h, @ccall LIB.demc_set_bounds(h::Ptr{Cvoid}, lo::Ptr{Float64}, hi::Ptr{Float64})::Int32)
+        load_handle!(h, model_spec, de, particles)
         # de.blocks: one nested Bool array per block (src/structs.jl:45), flattened like Θ -> nblocks x D bytes, row-major
         has_blocks = !isempty(de.blocks) && !(de.blocks[1] isa Bool)               # default is the placeholder [false]
         masks = has_blocks ? UInt8[x for blk in de.blocks for x in Iterators.flatten(blk)] : UInt8[]
-        if de.n_initial > 0   # initialize_samples (utilities.jl:35-39): rows 1:n_initial, [row][particle][D]
-            rows = Float64[x for i = 1:de.n_initial for p = 1:P for x in Iterators.flatten(de.samples[i, :, p])]
-            check(h, @ccall LIB.demc_set_history_rows(h::Ptr{Cvoid}, 0::Int64, Int64(de.n_initial)::Int64, rows::Ptr{Float64})::Int32)
-        end
-        theta = Float64[x for p in particles for x in flatten(p.Θ)]        # D x P column-major == [P][D] row-major
-        weight = Float64[p.weight for p in particles]                      # evaluated by sample_init on the host
-        ids = Int64[p.id - 1 for p in particles]                           # ids are 0-based across the ABI
-        check(h, @ccall LIB.demc_set_state(h::Ptr{Cvoid}, theta::Ptr{Float64}, weight::Ptr{Float64}, ids::Ptr{Int64})::Int32)
         # for iter in 1:n_iter: de.iter = iter + n_initial; groups = stepfun(model, de, groups)   (src/main.jl:33-38).
         # Whether a step is a block update is asked per iteration (main.jl:137,162): consecutive iterations with the same
         # answer go to the device as one demc_step call, with the block masks switched on or off in between.
@@ -180,20 +190,132 @@ function sample(model::DEModel, de::DE, b::HIPBackend, n_iter::Int; model_spec::
             particles[id].accept .= v[:, D + 1, id] .!= 0
             particles[id].lp .= v[:, D + 2, id]
         end
-        # final state of the particle objects (bundle_samples reads accept/lp from them; Θ for completeness)
-        th = Vector{Float64}(undef, P * D); wt = Vector{Float64}(undef, P); idv = Vector{Int64}(undef, P)
-        check(h, @ccall LIB.demc_get_state(h::Ptr{Cvoid}, th::Ptr{Float64}, wt::Ptr{Float64}, idv::Ptr{Int64})::Int32)
-        for s = 1:P
-            p = particles[idv[s] + 1]
-            p.Θ = [unflatten(view(th, (s - 1) * D + offs[k] + 1:(s - 1) * D + offs[k] + lens[k]), shapes[k]) for k in eachindex(shapes)]
-            p.weight = wt[s]
-        end
+        pull_state!(h, particles, P, D, shapes, lens, offs)
     finally
         h != C_NULL && @ccall LIB.demc_destroy(h::Ptr{Cvoid})::Int32
     end
     # particles are now ordered by id, so Θ columns and accept/lp agree (fixes the pairing quirk of main.jl:232-239)
     return bundle_samples(model, de, [particles], n_iter)                   # src/main.jl:222-250, unchanged
 end
+
+"final state of the particle objects behind handle `h` (bundle_samples reads accept/lp from them; Θ for completeness)"
+function pull_state!(h, particles, Pl, D, shapes, lens, offs)
+    th = Vector{Float64}(undef, Pl * D); wt = Vector{Float64}(undef, Pl); idv = Vector{Int64}(undef, Pl)
+    check(h, @ccall LIB.demc_get_state(h::Ptr{Cvoid}, th::Ptr{Float64}, wt::Ptr{Float64}, idv::Ptr{Int64})::Int32)
+    for s = 1:Pl
+        p = particles[idv[s] + 1]
+        p.Θ = [unflatten(view(th, (s - 1) * D + offs[k] + 1:(s - 1) * D + offs[k] + lens[k]), shapes[k]) for k in eachindex(shapes)]
+        p.weight = wt[s]
+    end
+    return nothing
+end
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Multi-GPU (SURVEY 8e).  Groups are sharded over the GPUs of the node; groups never interact inside update!/p_update!
+# (src/main.jl:135-167), and migration! (src/migration.jl:11-19, called from src/main.jl:85,103) becomes ONE RCCL all-gather
+# per migration event -- which lives BEHIND the C-ABI, so this host needs no collective library of its own.
+# ----------------------------------------------------------------------------------------------------------------------
+"One Julia task drives every GPU of the node (demc_create_multi): `devices` are HIP device ids, de.n_groups must divide by their number"
+struct HIPMultiBackend
+    devices::Vector{Int32}
+    schedule::Symbol
+    loglike_mode::Symbol
+    seed::UInt64
+    device_id::Int           # (unused: every shard takes its own device)
+end
+HIPMultiBackend(devices; schedule = :two_colour, loglike_mode = :streaming, seed = rand(UInt64)) =
+    HIPMultiBackend(Int32.(collect(devices)), schedule, loglike_mode, seed, 0)
+
+function mcheck(m, rc)
+    rc == 0 && return nothing
+    msg = unsafe_string(@ccall LIB.demc_multi_last_error(m::Ptr{Cvoid})::Cstring)
+    error("libdemc_hip (multi): status $rc: $msg")
+end
+
+"""
+    sample(model::DEModel, de::DE, backend::HIPMultiBackend, n_iter; model_spec)
+
+The threaded method's contract (src/main.jl:62-71) on several GPUs from ONE process: shard r owns groups
+`r*G+1:(r+1)*G` with their particles and history; `demc_multi_step` enqueues every shard's iterations and the one
+all-gather per migration (grouped ncclAllGather over xGMI) before it waits for any of them.
+"""
+function sample(model::DEModel, de::DE, b::HIPMultiBackend, n_iter::Int; model_spec::ModelSpec, progress = false, kwargs...)
+    groups = sample_init(model, de, n_iter)
+    particles = vcat(groups...)
+    P = length(particles); D = length(flatten(particles[1].Θ))
+    shapes, lens, offs = layout(particles[1].Θ)
+    R = length(b.devices)
+    de.n_groups % R == 0 || error("n_groups = $(de.n_groups) must divide by the number of devices ($R)")
+    Pl = P ÷ R
+    cfg = make_config(de, D, n_iter, b)          # the configuration of the WHOLE population
+    mref = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = @ccall LIB.demc_create_multi(Ref(cfg)::Ptr{DemcConfig}, Int32(R)::Int32, b.devices::Ptr{Int32}, mref::Ptr{Ptr{Cvoid}})::Int32
+    m = mref[]
+    try
+        mcheck(m, rc)
+        hs = [@ccall LIB.demc_multi_shard(m::Ptr{Cvoid}, Int32(r - 1)::Int32)::Ptr{Cvoid} for r = 1:R]
+        for r = 1:R
+            load_handle!(hs[r], model_spec, de, particles[(r - 1) * Pl + 1:r * Pl])   # ids 1..P in group-major order (main.jl:265-268)
+        end
+        mcheck(m, @ccall LIB.demc_multi_step(m::Ptr{Cvoid}, Int64(1 + de.n_initial)::Int64, Int32(n_iter)::Int32)::Int32)
+        de.iter = n_iter + de.n_initial
+        n_rows = n_iter + de.n_initial
+        for r = 1:R
+            # raw history of the shard, keyed by slot, + the (global, 0-based) id that sat in the slot: [row][slot][D] row-major
+            th = Array{Float64,3}(undef, D, Pl, n_rows); acc = Array{UInt8,2}(undef, Pl, n_rows)
+            lp = Array{Float64,2}(undef, Pl, n_rows); idh = Array{Int64,2}(undef, Pl, n_rows)
+            check(hs[r], @ccall LIB.demc_get_history(hs[r]::Ptr{Cvoid}, 0::Int64, Int64(n_rows)::Int64, th::Ptr{Float64},
+                acc::Ptr{UInt8}, lp::Ptr{Float64}, idh::Ptr{Int64})::Int32)
+            for row = 1:n_rows, s = 1:Pl
+                id = idh[s, row] + 1                                       # samples[iter, :, p.id] (utilities.jl:170-180)
+                for k in eachindex(shapes)
+                    de.samples[row, k, id] = unflatten(view(th, offs[k]+1:offs[k]+lens[k], s, row), shapes[k])
+                end
+                particles[id].accept[row] = acc[s, row] != 0
+                particles[id].lp[row] = lp[s, row]
+            end
+            pull_state!(hs[r], particles, Pl, D, shapes, lens, offs)
+        end
+    finally
+        m != C_NULL && @ccall LIB.demc_destroy_multi(m::Ptr{Cvoid})::Int32
+    end
+    return bundle_samples(model, de, [particles], n_iter)
+end
+
+# One PROCESS per GPU (Distributed.jl workers, MPI.jl ranks): every worker creates its shard with
+# make_config(de, D, n_iter, b; n_groups = G, group_offset = rank*G, device_id = local_gpu), joins the communicator and calls
+# demc_step -- the exchange happens inside.  The host only carries the 128-byte id from rank 0 to the others.
+const COMM_ID_BYTES = 128
+function comm_unique_id()
+    id = Vector{UInt8}(undef, COMM_ID_BYTES)
+    rc = @ccall LIB.demc_comm_unique_id(id::Ptr{Cvoid}, Int32(COMM_ID_BYTES)::Int32)::Int32
+    rc == 0 || error("libdemc_hip: demc_comm_unique_id: status $rc")
+    return id
+end
+"collective: every rank calls it with the same id; `overlap`: unselected groups update while the all-gather is in flight"
+function comm_init!(h, id::Vector{UInt8}, rank::Int, world::Int; overlap = false)
+    length(id) == COMM_ID_BYTES || error("communicator id must be $COMM_ID_BYTES bytes")
+    check(h, @ccall LIB.demc_comm_init(h::Ptr{Cvoid}, id::Ptr{Cvoid}, Int32(rank)::Int32, Int32(world)::Int32)::Int32)
+    check(h, @ccall LIB.demc_comm_set_overlap(h::Ptr{Cvoid}, Int32(overlap)::Int32)::Int32)
+    return nothing
+end
+comm_destroy!(h) = check(h, @ccall LIB.demc_comm_destroy(h::Ptr{Cvoid})::Int32)
+"reduce host doubles over the ranks in place (op: 0 sum, 1 max, 2 min); an empty vector is a barrier"
+function comm_allreduce!(h, x::Vector{Float64}, op::Int = 0)
+    check(h, @ccall LIB.demc_comm_allreduce(h::Ptr{Cvoid}, x::Ptr{Float64}, Int32(length(x))::Int32, Int32(op)::Int32)::Int32)
+    return x
+end
+"(world, rank, all-gathers issued so far)"
+function comm_stats(h)
+    out = Vector{Int64}(undef, 3)
+    check(h, @ccall LIB.demc_comm_stats(h::Ptr{Cvoid}, out::Ptr{Int64})::Int32)
+    return (world = out[1], rank = out[2], exchanges = out[3])
+end
+"migration! of iteration `iter` alone (pack -> all-gather -> apply) for a host loop that calls demc_update itself"
+migration_exchange!(h, iter::Int) = check(h, @ccall LIB.demc_migration_exchange(h::Ptr{Cvoid}, Int64(iter)::Int64)::Int32)
+"enqueue only / wait: for a task that drives several handles (one per device) without demc_create_multi"
+step_async!(h, iter0::Int, n::Int) = check(h, @ccall LIB.demc_step_async(h::Ptr{Cvoid}, Int64(iter0)::Int64, Int32(n)::Int32)::Int32)
+synchronize!(h) = check(h, @ccall LIB.demc_synchronize(h::Ptr{Cvoid})::Int32)
 
 """
     host_migration!(h, de, P)

@@ -1,0 +1,156 @@
+"""Static conformance of julia/DEMCHIP.jl -- the reference-side binding (the analogue of src/main.jl:62-71) -- with
+include/demc.h.  There is no Julia runtime here, so nothing in this repository executes the shim: a field added
+to demc_config, or a changed signature, would silently break it.  This test parses both files and compares
+
+  * struct DemcConfig / DemcReplay: field names, order and C types;
+  * the positional constructor calls `DemcConfig(...)` / `DemcReplay(...)`: arity = number of fields;
+  * every `@ccall LIB.demc_*(args...)::ret`: the symbol exists in the header, argument count and every argument / return
+    type agree with the C prototype."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "demc.h")).read(), flags=re.S)
+JULIA = open(os.path.join(ROOT, "julia", "DEMCHIP.jl")).read()
+
+SCALAR = {"int32_t": "Int32", "int64_t": "Int64", "uint64_t": "UInt64", "uint8_t": "UInt8", "double": "Float64"}
+OPAQUE = {"demc_handle", "demc_multi", "void"}
+STRUCTS = {"demc_config": "DemcConfig", "demc_replay": "DemcReplay"}
+
+
+def julia_type(ctype):
+    """C type of include/demc.h -> the Julia type an @ccall must name for it"""
+    t = ctype.replace("const", "").strip()
+    stars = t.count("*")
+    base = t.replace("*", "").strip()
+    if stars == 0:
+        return SCALAR[base]
+    if base == "char":
+        return "Cstring"
+    inner = "Cvoid" if base in OPAQUE else STRUCTS.get(base) or SCALAR[base]
+    for _ in range(stars):
+        inner = f"Ptr{{{inner}}}"
+    return inner
+
+
+def c_prototypes():
+    protos = {}
+    for ret, name, args in re.findall(r"((?:const\s+)?[a-z_0-9]+\s*\**)\s*\b(demc_[a-z_0-9]+)\s*\(([^;{}]*?)\)\s*;", HEADER):
+        args = args.strip()
+        types = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                m = re.match(r"(.*?[\s\*])([A-Za-z_0-9]+)$", a)  # type, then the parameter name
+                types.append(m.group(1).strip())
+        protos[name] = (ret.strip(), types)
+    return protos
+
+
+def split_top(text):
+    out, depth, cur = [], 0, ""
+    for ch in text:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def balanced(text, start):
+    """text[start] is '(' -> index just past the matching ')'"""
+    depth = 0
+    for i in range(start, len(text)):
+        if text[i] == "(":
+            depth += 1
+        elif text[i] == ")":
+            depth -= 1
+            if depth == 0:
+                return i + 1
+    raise ValueError("unbalanced")
+
+
+def ccalls():
+    calls = []
+    for m in re.finditer(r"@ccall LIB\.(demc_[a-z_0-9]+)\(", JULIA):
+        end = balanced(JULIA, m.end() - 1)
+        args = split_top(JULIA[m.end():end - 1])
+        ret = re.match(r"::([A-Za-z0-9{}]+)", JULIA[end:]).group(1)
+        types = []
+        for a in args:
+            depth, cut = 0, None
+            for i, ch in enumerate(a):  # the type follows the LAST top-level '::'
+                if ch in "([{":
+                    depth += 1
+                elif ch in ")]}":
+                    depth -= 1
+                elif ch == ":" and depth == 0 and a[i:i + 2] == "::":
+                    cut = i
+            types.append(a[cut + 2:].strip())
+        calls.append((m.group(1), types, ret, JULIA.count("\n", 0, m.start()) + 1))
+    return calls
+
+
+def c_struct_fields(name):
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), HEADER, re.S).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        m = re.match(r"((?:const\s+)?[a-z_0-9]+\s*\**)\s*(.*)$", decl, re.S)
+        ctype = m.group(1)
+        for nm in m.group(2).split(","):
+            stars = nm.count("*")
+            fields.append((nm.replace("*", "").strip(), julia_type(ctype + "*" * stars)))
+    return fields
+
+
+def julia_struct_fields(name):
+    body = re.search(r"^struct %s\n(.*?)^end" % name, JULIA, re.S | re.M).group(1)
+    body = re.sub(r"#.*", "", body)
+    return [tuple(x.strip() for x in f.split("::")) for f in re.split(r"[;\n]", body) if "::" in f]
+
+
+def test_structs_mirror_the_header_field_by_field():
+    for cname, jname in STRUCTS.items():
+        assert julia_struct_fields(jname) == c_struct_fields(cname), jname
+
+
+def test_positional_constructors_have_one_argument_per_field():
+    for jname in STRUCTS.values():
+        n_fields = len(julia_struct_fields(jname))
+        calls = [m for m in re.finditer(r"(?<![A-Za-z_{])%s\(" % jname, JULIA)]
+        assert calls, f"{jname} is never constructed"
+        for m in calls:
+            args = split_top(JULIA[m.end():balanced(JULIA, m.end() - 1) - 1])
+            assert len(args) == n_fields, f"{jname}(...) at line {JULIA.count(chr(10), 0, m.start()) + 1}: {len(args)} arguments for {n_fields} fields"
+
+
+def test_every_ccall_matches_its_c_prototype():
+    protos = c_prototypes()
+    calls = ccalls()
+    assert len(calls) >= 25
+    for name, jtypes, jret, line in calls:
+        assert name in protos, f"line {line}: {name} is not declared in include/demc.h"
+        cret, ctypes_ = protos[name]
+        assert len(jtypes) == len(ctypes_), f"line {line}: {name} takes {len(ctypes_)} arguments, the shim passes {len(jtypes)}"
+        for i, (jt, ct) in enumerate(zip(jtypes, ctypes_)):
+            assert jt == julia_type(ct), f"line {line}: {name} argument {i + 1}: {jt} for `{ct}`"
+        assert jret == julia_type(cret), f"line {line}: {name} returns `{cret}`, the shim says {jret}"
+
+
+def test_the_shim_binds_the_whole_multi_gpu_surface():
+    """the communicator and the single-process set are reachable from the Julia side"""
+    bound = {c[0] for c in ccalls()}
+    for name in ("demc_comm_unique_id", "demc_comm_init", "demc_comm_destroy", "demc_comm_set_overlap", "demc_comm_allreduce",
+                 "demc_migration_exchange", "demc_create_multi", "demc_multi_shard", "demc_multi_step", "demc_destroy_multi",
+                 "demc_multi_last_error", "demc_step", "demc_set_replay", "demc_export_chains", "demc_apply_migration"):
+        assert name in bound, name
