@@ -21,7 +21,7 @@ EXPORTS = [
     "demc_migration_pack", "demc_migration_apply", "demc_migration_pack_async", "demc_migration_apply_async", "demc_migration_groups",
     "demc_update_groups_async", "demc_apply_migration", "demc_get_weights", "demc_logpost",
     "demc_get_trace", "demc_set_replay", "demc_timing_enable", "demc_timing_read",
-    "demc_step_async", "demc_synchronize",
+    "demc_step_async", "demc_synchronize", "demc_last_kernels",
     "demc_comm_unique_id", "demc_comm_init", "demc_comm_destroy", "demc_comm_set_overlap", "demc_migration_exchange",
     "demc_migration_exchange_async", "demc_comm_allreduce", "demc_comm_stats",
     "demc_create_multi", "demc_destroy_multi", "demc_multi_last_error", "demc_multi_size", "demc_multi_shard", "demc_multi_step",
@@ -154,6 +154,7 @@ def load():
     L.demc_timing_read.argtypes = [H, _dp, C.c_int32]
     L.demc_step_async.argtypes = [H, C.c_int64, C.c_int32]
     L.demc_synchronize.argtypes = [H]
+    L.demc_last_kernels.argtypes = [H, C.c_char_p, C.c_int32]
     L.demc_comm_unique_id.argtypes = [C.c_void_p, C.c_int32]
     L.demc_comm_init.argtypes = [H, C.c_void_p, C.c_int32, C.c_int32]
     L.demc_comm_destroy.argtypes = [H]
@@ -178,7 +179,7 @@ def make_config(**kw):
     d = dict(n_groups=4, Np=4, D=1, n_blocks=0, burnin=1000, n_initial=0, n_rows=0, alpha=0.1, beta=0.1, eps=0.001,
              sigma=0.05, kappa=1.0, theta_snooker=0.0, proposal_kind=0, partner_kind=0, update_kind=0,
              fitness_kind=0, schedule=2, store_history=1, group_offset=0, n_groups_total=0, seed=1, device_id=0,
-             loglike_mode=0, trace=1, fuse=0, geometry_groups=0, reserved0=0)
+             loglike_mode=0, trace=0, fuse=0, geometry_groups=0, reserved0=0)
     for k, v in kw.items():
         if k in d:
             d[k] = v
@@ -380,6 +381,12 @@ class HipEngine:
         self._ck(self.L.demc_get_trace(self.h, _d(prop), _d(w), _d(adj), idx.ctypes.data_as(_ip),
                                        acc.ctypes.data_as(_bp)))
         return dict(proposal=prop, w_prop=w, log_adj=adj, idx=idx, accepted=acc)
+
+    def last_kernels(self):
+        """the kernel instances the last update launched (diagnostic, demc_last_kernels)"""
+        buf = C.create_string_buffer(512)
+        self._ck(self.L.demc_last_kernels(self.h, buf, 512))
+        return buf.value.decode()
 
     def set_replay(self, **draws):
         """test mode: caller-supplied draws (see fill_replay / demc_replay); no arguments -> back to Philox"""

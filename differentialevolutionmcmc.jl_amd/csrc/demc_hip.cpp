@@ -134,6 +134,13 @@ struct demc_handle {
     size_t red_cap = 0;
     long long n_exchanges = 0;        // all-gathers issued (diagnostic, demc_comm_stats)
     struct demc_multi* multi = nullptr;
+    // which kernel instances the last update launched (demc_last_kernels: lets a test name the instance it compared)
+    struct LastPlan {
+        int k1 = -1;  // 0 k_propose per phase, 1 k_longrow, 2 k_propose resident, 3 k_propose streaming-resident, 4 k_res_mvn
+        int wg = 0, tile = 0, tail = 0, plain = 0, dt = 0, stream = 0;
+        int k2 = 0;   // 0 none (fused into K1), 1 k_cross_mfma, 2 k_obs_loglike, 3 k_hier_loglike, 4 user plug-in
+        int ks = 0, k3 = 0;
+    } last;
     // timing
     bool timing = false;
     std::vector<Timed> events;
@@ -356,6 +363,7 @@ int launch_loglike(demc_handle* h, KParams& k) {
             const bool suff = h->c.loglike_mode == DEMC_LOGLIKE_SUFFSTAT;  // then K1 already formed S
             k.n_partials = 1;
             if (!suff) {
+                h->last.k2 = 1; h->last.ks = h->ks_t <= 1 ? 1 : h->ks_t <= 2 ? 2 : h->ks_t <= 4 ? 4 : h->ks_t <= 8 ? 8 : 16;
                 tick(h, 2, true);
                 // particle tiles of 256 (4 waves x MT=4 x 16) x observation chunks; chunks in multiples of 8 so that
                 // blockIdx % 8 (the XCD a block lands on) selects the chunk it streams
@@ -392,6 +400,7 @@ int launch_loglike(demc_handle* h, KParams& k) {
             if (want > h->partial_cap) want = h->partial_cap;
             if (want < 1 || h->family == FAM_RASTRIGIN) want = 1;
             const int n_chunks = (int)want;
+            h->last.k2 = 2;
             tick(h, 2, true);
             LAUNCH_T(h, k_obs_loglike, dim3((unsigned)((n_prop + 255) / 256), (unsigned)n_chunks), dim3(256), 0,
                                k, n_chunks);
@@ -410,6 +419,7 @@ int launch_loglike(demc_handle* h, KParams& k) {
             u.data = h->data; u.hyper = h->user_hyper;
             size_t sz = sizeof u;
             void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &u, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+            h->last.k2 = 4;
             tick(h, 2, true, true);
             hipError_t e = hipModuleLaunchKernel(h->user_kernel, (unsigned)((n_prop + 255) / 256), (unsigned)want, 1, 256, 1, 1, 0,
                                                  h->stream, nullptr, cfg);
@@ -419,6 +429,7 @@ int launch_loglike(demc_handle* h, KParams& k) {
         } break;
         case FAM_HIER_BINOMIAL:
         case FAM_HIER_GAUSSIAN: {
+            h->last.k2 = 3;
             tick(h, 2, true);
             LAUNCH_T(h, k_hier_loglike, dim3((unsigned)n_prop), dim3(256), 0, k);
             tick(h, 2, false);
@@ -520,6 +531,8 @@ int launch_phase(demc_handle* h, KParams& k) {
             const bool two_per_cu = (long long)h->geo_groups * k.n_act >= 2LL * h->n_cus && h->lr_two_fit;
             int wg_lr = two_per_cu ? 256 : 512;
             if (const char* e = experiment("DEMC_LR_WG")) wg_lr = std::atoi(e);  // A/B experiments
+            h->last = demc_handle::LastPlan();
+            h->last.k1 = 1; h->last.wg = wg_lr;
             tick(h, 0, true);
             if (wg_lr == 256)
                 LAUNCH_T(h, k_longrow<256>, dim3((unsigned)n_prop), dim3(256), lr_lds, k);
@@ -532,11 +545,15 @@ int launch_phase(demc_handle* h, KParams& k) {
     tick(h, 0, true);
     const int tail = tail_of(k);
     const size_t lds = tile ? lds_tile + (k.plan ? plan_bytes : 0) : h->k1_lds - h->k1_tile_bytes;
-    LAUNCH_T(h, k1_instance(tile, tail, is_plain(h, k), wg), dim3(k.n_groups * n_split), dim3(wg), lds, k);
+    const bool plain = is_plain(h, k);
+    h->last = demc_handle::LastPlan();
+    h->last.k1 = 0; h->last.wg = wg; h->last.tile = tile; h->last.tail = tail; h->last.plain = plain && tile && wg == 256;
+    LAUNCH_T(h, k1_instance(tile, tail, plain, wg), dim3(k.n_groups * n_split), dim3(wg), lds, k);
     tick(h, 0, false);
     if (k.fuse_accept) return DEMC_OK;
     int rc = launch_loglike(h, k);
     if (rc != DEMC_OK) return rc;
+    h->last.k3 = 1;
     tick(h, 3, true);
     LAUNCH_T(h, k_accept_store, dim3((unsigned)((n_prop + ppp3 - 1) / ppp3)), dim3(256), 0, k);
     tick(h, 3, false);
@@ -606,6 +623,8 @@ int launch_resident(demc_handle* h, long long iter0, int n_iters) {
     k.scr_doubles = h->res_scr_doubles;
     k.plan = (k.lpp >= 4) ? 1 : 0;
     if (const char* e = experiment("DEMC_K1_PLAN")) k.plan = k.plan && e[0] == '1';  // A/B experiments
+    h->last = demc_handle::LastPlan();
+    h->last.k1 = 2; h->last.wg = h->res_wg; h->last.tile = 1; h->last.tail = tail_of(k); h->last.plain = is_plain(h, k);
     tick(h, 0, true);
     LAUNCH_T(h, k1_resident_instance(h->res_wg, tail_of(k), is_plain(h, k)), dim3(k.n_groups), dim3(h->res_wg), h->res_lds,
                        k);
@@ -667,6 +686,8 @@ int launch_lean(demc_handle* h, long long iter0, int n_iters, bool stream) {
     const size_t lds = stream ? h->lean_stream_lds : h->lean_lds;
     // instances with the row length folded in (cfg3: 32, cfg2: 8) when the prior table is one segment
     const int dt = (h->n_seg == 1 && (c.D == 32 || c.D == 8)) ? c.D : 0;
+    h->last = demc_handle::LastPlan();
+    h->last.k1 = 4; h->last.wg = h->lean_wg; h->last.stream = stream; h->last.dt = dt;
     void (*fn)(KParams) = nullptr;
     if (stream) fn = dt == 8 ? k_res_mvn<256, true, 8> : dt == 32 ? k_res_mvn<256, true, 32> : k_res_mvn<256, true, 0>;
     else if (h->lean_wg == 512) fn = dt == 8 ? k_res_mvn<512, false, 8> : dt == 32 ? k_res_mvn<512, false, 32> : k_res_mvn<512, false, 0>;
@@ -760,6 +781,8 @@ int launch_stream(demc_handle* h, long long iter0, int n_iters) {
     // grid is sized for that by construction -- at most one workgroup per CU (plan_stream: n_groups * C <= CUs, and each
     // takes most of a CU's LDS) -- so a plain launch has the same residency as a cooperative one, without its launch-time
     // cost (+15-19 us, MI355X_MICROARCH.md "coop-launch"); every spin in the kernel is bounded regardless.
+    h->last = demc_handle::LastPlan();
+    h->last.k1 = 3; h->last.wg = h->st_wg; h->last.tile = 1; h->last.tail = tail_of(k); h->last.plain = is_plain(h, k); h->last.stream = 1;
     LAUNCH_T(h, k1_stream_instance(h->st_wg, tail_of(k), is_plain(h, k)), dim3(c.n_groups * h->st_C), dim3(h->st_wg), h->st_lds,
                        k);
     const hipError_t e = hipGetLastError();
@@ -2179,6 +2202,39 @@ int32_t demc_get_trace(demc_handle* h, double* proposal, double* w_prop, double*
     if (log_adj) HIPCHK(hipMemcpy(log_adj, h->prop_adj, P * sizeof(double), hipMemcpyDeviceToHost));
     if (idx) HIPCHK(hipMemcpy(idx, h->tr_idx, P * 4 * sizeof(int), hipMemcpyDeviceToHost));
     if (accepted) HIPCHK(hipMemcpy(accepted, h->tr_acc, P, hipMemcpyDeviceToHost));
+    return DEMC_OK;
+    });
+}
+
+int32_t demc_last_kernels(demc_handle* h, char* out, int32_t nbytes) {
+    return guarded(h, [&]() -> int32_t {
+    if (!h || !out || nbytes < 1) return DEMC_EINVAL;
+    const demc_handle::LastPlan& L = h->last;
+    static const char* const tails[4] = {"TAIL_NONE", "TAIL_PREP", "TAIL_PREP_MFMA", "TAIL_OBS"};
+    char buf[256];
+    buf[0] = '\0';
+    const char* tf[2] = {"false", "true"};
+    switch (L.k1) {
+        case 0:
+            std::snprintf(buf, sizeof buf, "k_propose<%d,%s,%s,false,%s>", L.wg, tf[L.tile != 0], tails[L.tail & 3], tf[L.plain != 0]);
+            break;
+        case 1: std::snprintf(buf, sizeof buf, "k_longrow<%d>", L.wg); break;
+        case 2:
+            std::snprintf(buf, sizeof buf, "k_propose<%d,true,%s,true,%s>", L.wg, tails[L.tail & 3], tf[L.plain != 0]);
+            break;
+        case 3:
+            std::snprintf(buf, sizeof buf, "k_propose<%d,true,%s,true,%s,true>", L.wg, tails[L.tail & 3], tf[L.plain != 0]);
+            break;
+        case 4: std::snprintf(buf, sizeof buf, "k_res_mvn<%d,%s,%d>", L.wg, tf[L.stream != 0], L.dt); break;
+        default: break;
+    }
+    std::string s = buf;
+    if (L.k2 == 1) s += " + k_cross_mfma<" + std::to_string(L.ks) + ",4>";
+    else if (L.k2 == 2) s += " + k_obs_loglike";
+    else if (L.k2 == 3) s += " + k_hier_loglike";
+    else if (L.k2 == 4) s += " + k_user_loglike";
+    if (L.k3) s += " + k_accept_store";
+    std::snprintf(out, (size_t)nbytes, "%s", s.c_str());
     return DEMC_OK;
     });
 }

@@ -288,6 +288,12 @@ int32_t demc_logpost(demc_handle* h, const double* theta, int64_t n, double* out
 int32_t demc_get_trace(demc_handle* h, double* proposal, double* w_prop, double* log_adj, int32_t* idx,
                        uint8_t* accepted);
 
+/* Diagnostic: the kernel instances the last update launched on this handle, e.g. "k_res_mvn<512,false,32>" or
+ * "k_propose<256,true,TAIL_PREP_MFMA,false,true> + k_cross_mfma<8,4> + k_accept_store" (template arguments as in csrc/:
+ * workgroup, LDS tile, fused tail, resident, plain[, streaming]) -- so that a parity test can say which instance it
+ * compared with the oracle.  Empty before the first update. */
+int32_t demc_last_kernels(demc_handle* h, char* out, int32_t nbytes);
+
 /* Test mode: caller-supplied random numbers in place of the library's addressed Philox draws, so that a
  * host that owns the reference's RNG (Julia's task-local stream) can feed ITS draws -- in the order of SURVEY Appendix A
  * -- and compare index bookkeeping and proposals bit for bit.  All pointers are HOST arrays, copied at the call; a NULL

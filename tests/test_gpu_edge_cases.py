@@ -78,7 +78,7 @@ def test_snooker_drawing_itself_gives_nan_proposal_and_is_rejected(demc, orc):
     weight -Inf -> rejected.  Np = 4 and theta_snooker = 1 makes it frequent."""
     prob = make_problem("gaussian", np.random.default_rng(12))
     rng = np.random.default_rng(99)
-    eng = demc.HipEngine(n_groups=8, Np=4, D=2, n_rows=6, schedule=1, theta_snooker=1.0, seed=5)
+    eng = demc.HipEngine(n_groups=8, Np=4, D=2, n_rows=6, schedule=1, theta_snooker=1.0, seed=5, trace=1)
     o = orc.Oracle(n_groups=8, Np=4, D=2, n_rows=6, schedule=1, theta_snooker=1.0, seed=5)
     setup_engine(eng, prob)
     setup_engine(o, prob)
@@ -109,7 +109,7 @@ def test_out_of_bounds_particles_and_all_minus_inf_group(demc, orc):
     th0[:Np, 1] = -1.0          # whole group 0 out of bounds (sigma < 0)
     th0[Np + 1, 1] = -2.0       # one particle of group 1
     cfg = dict(n_groups=G, Np=Np, D=2, n_rows=8, schedule=2, burnin=8, alpha=1.0, seed=3)
-    eng, o = demc.HipEngine(**cfg), orc.Oracle(**cfg)
+    eng, o = demc.HipEngine(trace=1, **cfg), orc.Oracle(**cfg)
     setup_engine(eng, prob)
     setup_engine(o, prob)
     eng.set_state(th0)

@@ -24,7 +24,7 @@ def _rtol(prob):
 
 
 def _pair(demc, orc, prob, **cfg):
-    base = dict(D=prob["D"], seed=cfg.pop("seed", 1234))
+    base = dict(D=prob["D"], seed=cfg.pop("seed", 1234), trace=1)  # (these tests read the per-slot trace: they opt in)
     base.update(cfg)
     eng = demc.HipEngine(**base)
     o = orc.Oracle(**{k: v for k, v in base.items() if k in orc.CFG_KEYS})

@@ -1,0 +1,140 @@
+"""The kernel instances that SHIP -- the ones `sample()`, bench.py and the Julia shim run (trace = 0) -- against the CPU
+oracle DIRECTLY, free-running: both engines start from the same rows, evaluate their own weights and run the iterations on
+their own (no teacher forcing, no trace); afterwards the whole history is compared -- the id in every slot and every accept
+flag bit for bit, theta bit for bit where the run holds crossover moves only (the proposal is a fixed +,-,* sequence,
+crossover.jl:154-172) and to 1e-10 where mutation's device log/sincos enter (mutation.jl:13-25), log-posteriors to 1e-9
+(north-star bar 1e-6; utilities.jl:201-210).  Every test asserts, through demc_last_kernels, WHICH instance it compared.
+
+The teacher-forced tests of test_gpu_parity.py read the per-slot trace and therefore run the general k_propose instance;
+these are the production twins: PLAIN K1 + k_cross_mfma + K3, k_res_mvn in its three shapes, the long-row span loops, the
+thread-per-proposal LBA kernel."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def free_run(demc, orc, w, n_it, kernels, G, Np, theta_exact, lp_rtol=1e-9, theta_rtol=1e-10, **cfg):
+    from demc_amd import workloads as W
+    P = G * Np
+    base = dict(n_groups=G, Np=Np, D=w["D"], n_rows=n_it, schedule=2, seed=4242, burnin=n_it // 2, trace=0)
+    base.update(w["engine"])
+    base.update(cfg)
+    eng = demc.HipEngine(**base)
+    o = orc.Oracle(n_threads=8, **{k: v for k, v in base.items() if k in orc.CFG_KEYS})
+    for e in (eng, o):
+        W.configure(e, w)
+    th0 = w["init"](P, np.random.default_rng(5))
+    eng.set_state(th0)   # each engine evaluates its own starting weights
+    o.set_state(th0)
+    np.testing.assert_allclose(eng.get_state()[1], o.get_state()[1], rtol=lp_rtol)
+    eng.step(1, n_it)
+    o.step(1, n_it)
+    ran = eng.last_kernels()
+    for name in kernels:
+        assert name in ran, f"expected {name}, the engine ran {ran}"
+    hg, ho = eng.get_history(0, n_it), o.get_history(0, n_it)
+    assert np.array_equal(hg[3], ho[3]), "particle ids per slot differ (migration bookkeeping)"
+    n_flip = int((hg[1] != ho[1]).sum())
+    assert n_flip == 0, f"{n_flip} accept decisions differ"
+    assert hg[1].mean() > 0.02, "nothing was accepted: the comparison would be vacuous"
+    if theta_exact:
+        assert np.array_equal(hg[0], ho[0]), "theta history is not bit-exact"
+    else:
+        np.testing.assert_allclose(hg[0], ho[0], rtol=theta_rtol, atol=1e-13)
+    np.testing.assert_allclose(hg[2], ho[2], rtol=lp_rtol)
+    sg, so = eng.get_state(), o.get_state()
+    assert np.array_equal(sg[2], so[2])
+    np.testing.assert_allclose(sg[1], so[1], rtol=lp_rtol)
+    eng.close()
+    o.close()
+    return ran
+
+
+@pytest.mark.parametrize("beta", [0.0, 0.1])
+def test_cfg2_shape_streaming_lean_kernel(demc, orc, beta):
+    """BASELINE cfg2 as it is benchmarked: 32 x 64, D = 8, N = 1e4, STREAMING -> k_res_mvn<256,true,8> (the observation
+    stream inside the resident kernel, 8 workgroups per group handing their cross terms over)"""
+    from demc_amd import workloads as W
+    w = W.cfg2()
+    free_run(demc, orc, w, 10, ["k_res_mvn<256,true,8>"], w["G"], w["Np"], theta_exact=beta == 0.0, beta=beta, loglike_mode=0)
+
+
+@pytest.mark.parametrize("beta", [0.0, 0.1])
+def test_cfg3_geometry_suffstat_lean_kernel(demc, orc, beta):
+    """cfg3's group shape (Np = 256, D = 32) in SUFFSTAT mode -> k_res_mvn<512,false,32>, on 8 groups and N = 2000 so that
+    the oracle (which visits every observation) finishes in seconds"""
+    from demc_amd import workloads as W
+    w = W.cfg3(N=2000, G=8)
+    free_run(demc, orc, w, 10, ["k_res_mvn<512,false,32>"], 8, 256, theta_exact=beta == 0.0, beta=beta, loglike_mode=1)
+
+
+@pytest.mark.parametrize("beta", [0.0, 0.1])
+def test_cfg3_geometry_streaming_chain(demc, orc, beta):
+    """the headline's three kernels: PLAIN K1 (LDS tile, MvNormal preparation on the matrix cores) -> k_cross_mfma<8,4> ->
+    k_accept_store, with cfg3's lane geometry (geometry_groups = 256 -> 4 lanes per particle) on 16 groups; fuse = 2 keeps
+    the per-phase chain that the full-size population takes by itself"""
+    from demc_amd import workloads as W
+    w = W.cfg3(N=2000, G=16)
+    free_run(demc, orc, w, 8, ["k_propose<256,true,TAIL_PREP_MFMA,false,true>", "k_cross_mfma<8,4>", "k_accept_store"], 16, 256,
+             theta_exact=beta == 0.0, beta=beta, loglike_mode=0, fuse=2, geometry_groups=256)
+
+
+@pytest.mark.parametrize("wg,G,Np", [(512, 4, 8), (256, 40, 32)])
+def test_cfg4_shape_long_row_span_loops(demc, orc, wg, G, Np):
+    """hierarchical Binomial with the two blocks [hyper; subject] of Examples/Hierarchical_Example.jl:88-92 at S = 2100
+    (rows long enough for a workgroup per particle): k_longrow<512>, and k_longrow<256> (two workgroups per CU) once the
+    moving particles outnumber twice the CUs.  Mutation sweeps (beta = 0.1) included: theta to 1e-10."""
+    from demc_amd import workloads as W
+    w = W.cfg4(S=2100, G=G, Np=Np)
+    free_run(demc, orc, w, 6, [f"k_longrow<{wg}>"], G, Np, theta_exact=False)
+
+
+def test_cfg5_shape_lba_thread_per_proposal(demc, orc):
+    """LBA, 3 accumulators, snooker 0.1 (Examples/Run_LBA.jl), N = 500 simulated trials: K1 -> k_obs_loglike (Phi / phi
+    tables in LDS) -> k_accept_store.  LBA log-densities at 1e-5 (survival factors formed by cancellation, see
+    test_gpu_parity._rtol), snooker projections to 1e-10."""
+    from demc_amd import workloads as W
+    w = W.cfg5(N=500, G=8, Np=16)
+    free_run(demc, orc, w, 10, ["k_obs_loglike", "k_accept_store"], 8, 16, theta_exact=False, lp_rtol=1e-5)
+
+
+def test_sample_runs_the_production_instances(demc):
+    """the public sample() no longer asks for the diagnostic trace: the default sampler on the Gaussian example runs the
+    PLAIN resident instance"""
+    import demc_amd as D
+    from demc_amd import sampler as S
+    seen = []
+    real = D.HipEngine
+
+    def factory(**cfg):
+        e = real(**cfg)
+        seen.append(e)
+        return e
+    rng = np.random.default_rng(3)
+    data = rng.normal(0.0, 1.0, 50)
+    sp = lambda: [rng.normal(0, 1), abs(rng.standard_cauchy()) + 0.1]
+    model = D.DEModel(sample_prior=sp, prior_loglike=D.Priors(mu=D.Normal(0, 1), sigma=D.TruncatedCauchy(0, 1)),
+                      loglike=D.GaussianLikelihood(), data=data, names=("mu", "sigma"))
+    de = D.DE(sample_prior=sp, bounds=((-np.inf, np.inf), (0.0, np.inf)), burnin=200, Np=6)
+    S.sample(model, de, D.HIPBackend(seed=3), 400, engine_factory=factory)
+    assert seen and seen[0].cfg.trace == 0
+    # (the engine is closed by sample(); its configuration is what this test is about)
+
+
+@pytest.mark.parametrize("n_distinct,kernel", [(32, "k_propose<512,true,TAIL_PREP_MFMA,true,true>"), (8, "k_res_mvn<512,false,0>"),
+                                               (1, "k_res_mvn<512,false,32>")])
+def test_lean_kernel_plan_follows_the_prior_table(demc, orc, n_distinct, kernel):
+    """priors and bounds arrive AFTER demc_set_model in every host (workloads.configure, DEMCHIP.jl, the C driver): the lean
+    kernel's plan must be taken again then.  32 distinct per-dimension priors / bounds do not fit the run-length table
+    (16 segments): the general resident instance has to run (round 2 launched the lean kernel on an empty segment table);
+    8 distinct ones take the lean kernel's general-row instance; one segment the D = 32 instance.  All three == oracle."""
+    from demc_amd import workloads as W
+    w = W.cfg3(N=500, G=4)
+    d = w["D"]
+    seg = np.arange(d) // (d // n_distinct)
+    w["pa"] = list(0.05 * seg)                 # Normal(0.05 k, 1 + 0.01 k) on the dimensions of segment k
+    w["pb"] = list(1.0 + 0.01 * seg)
+    w["lo"] = list(-50.0 - seg)
+    w["hi"] = list(60.0 + seg)
+    free_run(demc, orc, w, 8, [kernel], 4, 256, theta_exact=True, beta=0.0, loglike_mode=1)

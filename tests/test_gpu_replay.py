@@ -70,7 +70,7 @@ def test_random_replayed_draws_give_identical_choices(demc, orc, family, schedul
     G, Np, D = 3, 8, prob["D"]
     cfg = dict(n_groups=G, Np=Np, D=D, n_rows=8, schedule=schedule, burnin=4, theta_snooker=0.3, kappa=0.8, beta=0.3,
                alpha=0.0, seed=21)
-    eng = demc.HipEngine(**cfg)
+    eng = demc.HipEngine(trace=1, **cfg)
     o = orc.Oracle(**{k: v for k, v in cfg.items() if k in orc.CFG_KEYS})
     setup_engine(eng, prob)
     setup_engine(o, prob)
