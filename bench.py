@@ -39,7 +39,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
-    ap.add_argument("--mode", default="streaming", choices=["streaming", "suffstat"])
+    ap.add_argument("--mode", default="streaming", choices=["streaming", "suffstat", "direct"],
+                    help="MvNormal likelihood: streaming = expanded quadratic form on the FP64 matrix cores (headline); suffstat = "
+                         "O(D^2) per proposal; direct = the residual form sum_i |L^-1(x_i - mu)|^2 term by term on the FP64 vector pipe")
     ap.add_argument("--schedule", default="two_colour", choices=["two_colour", "synchronous"])
     ap.add_argument("--n-groups", type=int, default=None, help="groups per GPU (default: the config's)")
     ap.add_argument("--np", type=int, default=None, dest="Np")
@@ -160,11 +162,28 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
             alg_bytes = (8.0 * N * d * phases + P * 8.0 * d) * k_iters / n_launch
             rf = dict(bound="mfma", kernel=kern, achieved=ach, peak=PEAK_FP64_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP64_TFLOPS,
                       flop_counted="executed 2*N*D per particle-update (every proposal x observation pair on the matrix cores)",
+                      what_is_streamed="the cross term sum_i y.x~_i of the EXPANDED quadratic form, y = Sigma^-1 (theta' - xbar), x~_i = x_i - xbar. "
+                                       "After centring it equals y.(sum_i x~_i), i.e. rounding noise around zero: STREAMING = SUFFSTAT + this "
+                                       "[proposals x D].[D x N] product; the data dependence of the result sits in the data-only constant "
+                                       "sum_i x~_i' Sigma^-1 x~_i and in N mu~' Sigma^-1 mu~.  The per-pair work that does not collapse is "
+                                       "`--mode direct` (3*N*D per particle-update on the FP64 vector pipe)",
                       survey_equivalent_tflops=survey / t_s / 1e12,
                       survey_note="SURVEY 8d counts the whitened form 3ND+2D^2; the expanded form executes 2/3 of it for the same result",
                       launch_ms=t_s / n_launch * 1e3, launches=n_launch, updates_per_launch=P * k_iters / n_launch,
                       traffic=traffic, traffic_source=src,
                       wasted_traffic_ratio=None if traffic is None else traffic / alg_bytes)
+        elif a.mode == "direct":
+            t_s = tm["loglike"]["ms"] * 1e-3
+            n_launch = max(1, tm["loglike"]["launches"])
+            dp = 8 if d <= 8 else 16 if d <= 16 else 32 if d <= 32 else 64
+            executed = 3.0 * N * dp * P * k_iters   # per (proposal, observation, padded dimension): one add, one fma
+            ach = executed / t_s / 1e12
+            rf = dict(bound="valu", kernel=f"k_direct_mvn<{dp}> (thread per proposal, m = L^-1 mu~ in registers, wave-uniform z rows)",
+                      achieved=ach, peak=PEAK_FP64_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP64_TFLOPS,
+                      flop_counted="3*N*D per particle-update (SURVEY 8d's whitened residual form: v_add_f64 + v_fma_f64 per dimension; "
+                                   "an add counts one flop, so 0.75 of the FMA peak is this form's ceiling)",
+                      launch_ms=t_s / n_launch * 1e3, launches=n_launch, updates_per_launch=P * k_iters / n_launch,
+                      traffic=None, traffic_source=None, wasted_traffic_ratio=None)
         else:
             t_s = fused_ms * 1e-3
             n_launch = max(1, tm["propose"]["launches"])
@@ -245,6 +264,7 @@ def accuracy_leg(a, w, demc_amd, local, rng):
     t0 = time.perf_counter()
     n_snap = 10
     eng.step(1, n_it - n_snap * 10)
+    kern = eng.last_kernels()
     snaps = []
     it = 1 + n_it - n_snap * 10
     for _ in range(n_snap):
@@ -259,8 +279,10 @@ def accuracy_leg(a, w, demc_amd, local, rng):
     return dict(posterior_mean_l1_rel=float(np.abs(th.mean(0) - m).sum() / np.abs(m).sum()),
                 max_abs_err_in_posterior_sd=float(np.max(np.abs(th.mean(0) - m) / sd)),
                 ensemble_sd_over_posterior_sd=float(np.median(th.std(0) / sd)),
-                leg=f"untimed run of {n_it} iterations (burn-in {a.burnin}) of the same sampler on this GPU, SUFFSTAT likelihood "
-                    f"(accept decisions identical to STREAMING); all {P} particles at {n_snap} snapshots 10 iterations apart",
+                leg=f"untimed run of {n_it} iterations (burn-in {a.burnin}) of the same sampler on this GPU, SUFFSTAT likelihood: "
+                    f"DIFFERENT KERNELS than the timed ones ({kern}), same proposals and accept decisions "
+                    f"(tests/test_gpu_production.py::test_the_three_likelihood_modes_make_the_same_decisions); all {P} particles at "
+                    f"{n_snap} snapshots 10 iterations apart",
                 seconds=dt, reference="closed-form Gaussian posterior (conjugate: prior N(0,I), known Sigma)")
 
 
@@ -379,7 +401,7 @@ def main():
     n_rows = a.warmup + a.steps
     eng = demc_amd.HipEngine(n_groups=G, Np=Np, D=D, n_rows=n_rows, schedule=2 if a.schedule == "two_colour" else 1,
                              group_offset=rank * G, n_groups_total=G * world, seed=20260001, device_id=local, burnin=a.burnin,
-                             loglike_mode=0 if a.mode == "streaming" else 1, trace=0, fuse=a.fuse, **w["engine"])
+                             loglike_mode={"streaming": 0, "suffstat": 1, "direct": 2}[a.mode], trace=0, fuse=a.fuse, **w["engine"])
     W.configure(eng, w)
     eng.set_state(w["init"](P, np.random.default_rng(20260003 + rank)))
     if library:

@@ -21,7 +21,7 @@ EXPORTS = [
     "demc_migration_pack", "demc_migration_apply", "demc_migration_pack_async", "demc_migration_apply_async", "demc_migration_groups",
     "demc_update_groups_async", "demc_apply_migration", "demc_get_weights", "demc_logpost",
     "demc_get_trace", "demc_set_replay", "demc_timing_enable", "demc_timing_read",
-    "demc_step_async", "demc_synchronize", "demc_last_kernels",
+    "demc_step_async", "demc_synchronize", "demc_last_kernels", "demc_set_model_source_row",
     "demc_comm_unique_id", "demc_comm_init", "demc_comm_destroy", "demc_comm_set_overlap", "demc_migration_exchange",
     "demc_migration_exchange_async", "demc_comm_allreduce", "demc_comm_stats",
     "demc_create_multi", "demc_destroy_multi", "demc_multi_last_error", "demc_multi_size", "demc_multi_shard", "demc_multi_step",
@@ -130,6 +130,7 @@ def load():
     L.demc_set_stream.argtypes = [H, C.c_void_p]
     L.demc_set_model.argtypes = [H, C.c_int32, _dp, _lp, C.c_int32, _dp, C.c_int32]
     L.demc_set_model_source.argtypes = [H, C.c_char_p, _dp, _lp, C.c_int32, _dp, C.c_int32]
+    L.demc_set_model_source_row.argtypes = [H, C.c_char_p, _dp, _lp, C.c_int32, _dp, C.c_int32, C.c_int32]
     L.demc_set_priors.argtypes = [H, _ip, _dp, _dp, _ip]
     L.demc_set_bounds.argtypes = [H, _dp, _dp]
     L.demc_set_blocks.argtypes = [H, _bp, C.c_int32]
@@ -250,6 +251,14 @@ class HipEngine:
         hyper = None if hyper is None else np.ascontiguousarray(np.asarray(hyper, dtype=np.float64).ravel())
         self._ck(self.L.demc_set_model_source(self.h, source.encode(), _d(data), dims.ctypes.data_as(_lp), dims.size,
                                               _d(hyper), 0 if hyper is None else hyper.size))
+
+    def set_model_source_row(self, source, data, dims, hyper=None, has_prior=False):
+        """whole-row plug-in: HIP source defining demc_user_loglike_row(...) [and demc_user_prior_row(...)] (include/demc.h)"""
+        data = np.ascontiguousarray(np.asarray(data, dtype=np.float64).ravel())
+        dims = np.ascontiguousarray(np.asarray(dims, dtype=np.int64).ravel())
+        hyper = None if hyper is None else np.ascontiguousarray(np.asarray(hyper, dtype=np.float64).ravel())
+        self._ck(self.L.demc_set_model_source_row(self.h, source.encode(), _d(data), dims.ctypes.data_as(_lp), dims.size,
+                                                  _d(hyper), 0 if hyper is None else hyper.size, 1 if has_prior else 0))
 
     def set_priors(self, kind, a, b, ref=None):
         kind = np.ascontiguousarray(kind, dtype=np.int32)

@@ -71,6 +71,8 @@ struct demc_handle {
     int d = 0, n_acc = 0, dpad = 0;
     int n_tiles = 0;
     int ks_t = 0, n_kpass = 0;  // MFMA k-steps per pass (template) and passes over the dimensions
+    int dp_direct = 0;          // DIRECT mode: padded length of a whitened observation row (8 / 16 / 32 / 64)
+    int direct_wgs_per_cu = 0;  // ... resident workgroups of its kernel per CU (asked once)
     double *data = nullptr, *Ainv = nullptr, *Ypad = nullptr, *Xf = nullptr, *sx = nullptr, *xbar = nullptr;
     size_t data2_off = 0;
     // user plug-in (demc_set_model_source): JIT-compiled module, kernel and its hyper-parameters
@@ -78,6 +80,10 @@ struct demc_handle {
     hipFunction_t user_kernel = nullptr;
     double* user_hyper = nullptr;
     int user_nhyper = 0;
+    bool user_row = false;        // whole-row plug-in (demc_set_model_source_row): one workgroup per proposal
+    bool user_has_prior = false;  // ... whose source also defines demc_user_prior_row
+    long long* user_dims = nullptr;
+    int user_ndims = 0;
     double c0 = 0, c1 = 0, c2 = 0;
     int partial_cap = 64;
     int lpp = 1;
@@ -270,6 +276,8 @@ void drain_events(demc_handle* h) {
     h->events.clear();
 }
 
+bool is_mvn(int fam);
+
 int pow2_ceil(int x) {
     int p = 1;
     while (p < x) p <<= 1;
@@ -299,6 +307,7 @@ KParams base_params(demc_handle* h) {
     k.family = h->family; k.N = h->N; k.d = h->d; k.n_acc = h->n_acc; k.n_partials = 1;
     k.partial = h->partial; k.aux = h->aux; k.data = h->data; k.data2 = h->data ? h->data + h->data2_off : nullptr;
     k.c0 = h->c0; k.c1 = h->c1; k.c2 = h->c2;
+    k.direct = (is_mvn(h->family) && c.loglike_mode == DEMC_LOGLIKE_DIRECT) ? 1 : 0;
     k.n_split = 1; k.fuse_prep = 0; k.prep_mfma = 0; k.fuse_obs = 0; k.fuse_accept = 0; k.plan = 0;
     k.scr_doubles = (int)(h->k1_scr_bytes / sizeof(double)); k.write_prop = 1; k.trace = c.trace;
     k.Ainv = h->Ainv; k.sx = nullptr; k.xbar = h->xbar; k.Ypad = h->Ypad; k.dpad = h->dpad;
@@ -317,24 +326,65 @@ void launch_cross(demc_handle* h, const KParams& k, int grid, int k0, int n_chun
 
 // Kernarg of the JIT-compiled user-likelihood kernel; the same text is prepended to the user's source.
 struct UserKParams {
-    int n_groups, Np, D, a_lo, n_act, n_chunks, nhyper, pad;
+    int n_groups, Np, D, a_lo, n_act, n_chunks, nhyper, with_prior;
     long long N, P;
     const double* prop;
     double* partial;
     const double* data;
     const double* hyper;
+    const long long* dims;
+    const int* glist;
+    int ndims, pad;
 };
-const char* kUserPrologue = R"SRC(
+const char* kUserStruct = R"SRC(
+#ifndef INFINITY
+#define INFINITY __builtin_huge_val()
+#endif
+#ifndef NAN
+#define NAN __builtin_nan("")
+#endif
 struct UserKParams {
-    int n_groups, Np, D, a_lo, n_act, n_chunks, nhyper, pad;
+    int n_groups, Np, D, a_lo, n_act, n_chunks, nhyper, with_prior;
     long long N, P;
     const double* prop;
     double* partial;
     const double* data;
     const double* hyper;
+    const long long* dims;
+    const int* glist;
+    int ndims, pad;
 };
+)SRC";
+const char* kUserPrologue = R"SRC(
 __device__ double demc_user_obs(const double* theta, int D, const double* data, long long N, long long i,
                                 const double* hyper, int nhyper);
+)SRC";
+// whole-row plug-in: the user's functions return the share of lane `lane` of `n_lanes` cooperating lanes
+const char* kUserRowPrologue = R"SRC(
+__device__ double demc_user_loglike_row(const double* theta, int D, const double* data, const long long* dims, int ndims,
+                                        const double* hyper, int nhyper, int lane, int n_lanes);
+#ifdef DEMC_USER_HAS_PRIOR
+__device__ double demc_user_prior_row(const double* theta, int D, const double* hyper, int nhyper, int lane, int n_lanes);
+#endif
+)SRC";
+// one workgroup of 256 lanes per proposal; the lanes' shares are summed in a fixed order (wave butterfly, then the four
+// waves left to right), so the result does not depend on scheduling
+const char* kUserRowKernel = R"SRC(
+extern "C" __global__ __launch_bounds__(256) void k_user_row(UserKParams p) {
+    __shared__ double s_part[4];
+    const int q = blockIdx.x;
+    const int g = q / p.n_act;
+    const size_t slot = (size_t)(p.glist ? p.glist[g] : g) * p.Np + p.a_lo + (q - g * p.n_act);
+    const double* th = p.prop + slot * p.D;
+    double acc = demc_user_loglike_row(th, p.D, p.data, p.dims, p.ndims, p.hyper, p.nhyper, (int)threadIdx.x, 256);
+#ifdef DEMC_USER_HAS_PRIOR
+    if (p.with_prior) acc += demc_user_prior_row(th, p.D, p.hyper, p.nhyper, (int)threadIdx.x, 256);
+#endif
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) p.partial[slot] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
 )SRC";
 // thread per proposal x observation chunks: same mapping as k_obs_loglike
 const char* kUserKernel = R"SRC(
@@ -343,7 +393,7 @@ extern "C" __global__ __launch_bounds__(256) void k_user_loglike(UserKParams p) 
     const int chunk = blockIdx.y;
     if (q >= p.n_groups * p.n_act) return;
     const int g = q / p.n_act;
-    const size_t slot = (size_t)g * p.Np + p.a_lo + (q - g * p.n_act);
+    const size_t slot = (size_t)(p.glist ? p.glist[g] : g) * p.Np + p.a_lo + (q - g * p.n_act);
     const double* th = p.prop + slot * p.D;
     const long long per = (p.N + p.n_chunks - 1) / p.n_chunks;
     const long long i0 = chunk * per, i1 = (i0 + per < p.N) ? i0 + per : p.N;
@@ -362,7 +412,44 @@ int launch_loglike(demc_handle* h, KParams& k) {
         case FAM_MVN_ISO: {
             const bool suff = h->c.loglike_mode == DEMC_LOGLIKE_SUFFSTAT;  // then K1 already formed S
             k.n_partials = 1;
-            if (!suff) {
+            if (k.direct) {
+                // proposal blocks of 256 x observation chunks: enough workgroups for 8 waves per SIMD, chunks no shorter
+                // than 64 observations, at most the partial-sum workspace
+                const long long blocks = (n_prop + 255) / 256;
+                long long cap = h->N / 64;
+                if (cap > h->partial_cap) cap = h->partial_cap;
+                if (cap < 1) cap = 1;
+                // The kernel is one long uniform loop per workgroup: the launch takes ceil(workgroups / resident workgroups)
+                // rounds of equal length, so the chunk count is chosen to fill the last round (cfg3: 128 blocks x 48 chunks =
+                // 4 full rounds of 1536 resident workgroups; 32 chunks would leave a third of the chip idle in round 3).
+                if (h->direct_wgs_per_cu == 0) {
+                    int nb = 0;
+                    const void* fn = h->dp_direct == 8 ? (const void*)k_direct_mvn<8> : h->dp_direct == 16 ? (const void*)k_direct_mvn<16>
+                                     : h->dp_direct == 32 ? (const void*)k_direct_mvn<32> : (const void*)k_direct_mvn<64>;
+                    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0));
+                    h->direct_wgs_per_cu = nb > 0 ? nb : 1;
+                }
+                const double resident = (double)h->direct_wgs_per_cu * h->n_cus;
+                long long best = 1;
+                double best_fill = 0.0;
+                for (long long nc = 1; nc <= cap; ++nc) {
+                    const double wgs = (double)blocks * (double)nc;
+                    const double fill = wgs / (std::ceil(wgs / resident) * resident);
+                    if (fill > best_fill + 1e-9 || (fill > best_fill - 1e-9 && wgs <= 4.0 * resident)) { best = nc; best_fill = fill; }
+                }
+                const int n_chunks = (int)best;
+                h->last.k2 = 5; h->last.ks = h->dp_direct;
+                tick(h, 2, true);
+                const dim3 grid((unsigned)blocks, (unsigned)n_chunks);
+                switch (h->dp_direct) {
+                    case 8: LAUNCH_T(h, k_direct_mvn<8>, grid, dim3(256), 0, k, n_chunks); break;
+                    case 16: LAUNCH_T(h, k_direct_mvn<16>, grid, dim3(256), 0, k, n_chunks); break;
+                    case 32: LAUNCH_T(h, k_direct_mvn<32>, grid, dim3(256), 0, k, n_chunks); break;
+                    default: LAUNCH_T(h, k_direct_mvn<64>, grid, dim3(256), 0, k, n_chunks); break;
+                }
+                tick(h, 2, false);
+                k.n_partials = n_chunks;
+            } else if (!suff) {
                 h->last.k2 = 1; h->last.ks = h->ks_t <= 1 ? 1 : h->ks_t <= 2 ? 2 : h->ks_t <= 4 ? 4 : h->ks_t <= 8 ? 8 : 16;
                 tick(h, 2, true);
                 // particle tiles of 256 (4 waves x MT=4 x 16) x observation chunks; chunks in multiples of 8 so that
@@ -413,16 +500,20 @@ int launch_loglike(demc_handle* h, KParams& k) {
             if (cap < 1) cap = 1;
             if (want > cap) want = cap;
             if (want > h->partial_cap) want = h->partial_cap;
+            if (h->user_row) want = 1;
             UserKParams u;
             u.n_groups = k.n_groups; u.Np = k.Np; u.D = k.D; u.a_lo = k.a_lo; u.n_act = k.n_act; u.n_chunks = (int)want;
-            u.nhyper = h->user_nhyper; u.pad = 0; u.N = h->N; u.P = h->P; u.prop = k.prop; u.partial = k.partial;
-            u.data = h->data; u.hyper = h->user_hyper;
+            u.nhyper = h->user_nhyper; u.with_prior = h->c.fitness_kind == DEMC_FITNESS_POSTERIOR ? 1 : 0;
+            u.N = h->N; u.P = h->P; u.prop = k.prop; u.partial = k.partial;
+            u.data = h->data; u.hyper = h->user_hyper; u.dims = h->user_dims; u.glist = k.glist; u.ndims = h->user_ndims; u.pad = 0;
             size_t sz = sizeof u;
             void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &u, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-            h->last.k2 = 4;
+            h->last.k2 = h->user_row ? 6 : 4;
             tick(h, 2, true, true);
-            hipError_t e = hipModuleLaunchKernel(h->user_kernel, (unsigned)((n_prop + 255) / 256), (unsigned)want, 1, 256, 1, 1, 0,
-                                                 h->stream, nullptr, cfg);
+            hipError_t e = h->user_row
+                ? hipModuleLaunchKernel(h->user_kernel, (unsigned)n_prop, 1, 1, 256, 1, 1, 0, h->stream, nullptr, cfg)
+                : hipModuleLaunchKernel(h->user_kernel, (unsigned)((n_prop + 255) / 256), (unsigned)want, 1, 256, 1, 1, 0,
+                                        h->stream, nullptr, cfg);
             tick(h, 2, false, true);
             if (e != hipSuccess) return fail(h, DEMC_EHIP, std::string("hipModuleLaunchKernel: ") + hipGetErrorString(e));
             k.n_partials = (int)want;
@@ -913,7 +1004,7 @@ void free_replay(demc_handle* h) {
     h->rp_active = h->rp_has_step = false;
 }
 
-bool chol_inv(const double* S, int d, std::vector<double>& Ainv, double& logdet) {
+bool chol_inv(const double* S, int d, std::vector<double>& Ainv, double& logdet, std::vector<double>* Linv = nullptr) {
     std::vector<double> L((size_t)d * d, 0.0), Li((size_t)d * d, 0.0);
     for (int i = 0; i < d; ++i)
         for (int j = 0; j <= i; ++j) {
@@ -940,6 +1031,7 @@ bool chol_inv(const double* S, int d, std::vector<double>& Ainv, double& logdet)
             for (int k = 0; k < d; ++k) s += Li[k * d + i] * Li[k * d + j];
             Ainv[i * d + j] = s;
         }
+    if (Linv) *Linv = Li;
     return true;
 }
 
@@ -969,6 +1061,7 @@ int32_t demc_create(const demc_config* cfg, demc_handle** out) {
     if (c.schedule != DEMC_SCHED_SEQUENTIAL && c.schedule != DEMC_SCHED_SYNCHRONOUS && c.schedule != DEMC_SCHED_TWO_COLOUR)
         return fail(h, DEMC_EINVAL, "unknown schedule");
     if (c.geometry_groups < 0) return fail(h, DEMC_EINVAL, "geometry_groups < 0");
+    if (c.loglike_mode < DEMC_LOGLIKE_STREAMING || c.loglike_mode > DEMC_LOGLIKE_DIRECT) return fail(h, DEMC_EINVAL, "unknown loglike_mode");
     h->geo_groups = c.geometry_groups > 0 ? c.geometry_groups : c.n_groups;
     if (c.schedule == DEMC_SCHED_TWO_COLOUR && c.partner_kind == DEMC_PARTNER_CURRENT) {
         const int need = c.theta_snooker > 0.0 ? 6 : 4;
@@ -1068,6 +1161,7 @@ int32_t demc_destroy(demc_handle* h) {
         if (p) hipFree(p);
     if (h->user_module) hipModuleUnload(h->user_module);
     if (h->user_hyper) hipFree(h->user_hyper);
+    if (h->user_dims) hipFree(h->user_dims);
     free_replay(h);
     for (int i = 0; i < demc_handle::kGlistRing; ++i) {
         if (h->glist_buf[i]) hipFree(h->glist_buf[i]);
@@ -1117,6 +1211,7 @@ int32_t demc_set_model(demc_handle* h, int32_t family, const double* data, const
     for (double** p : {&h->data, &h->Ainv, &h->Ypad, &h->Xf, &h->sx, &h->xbar})
         if (*p) { hipFree(*p); *p = nullptr; }
     h->family = -1; h->N = 0; h->d = 0; h->n_acc = 0; h->dpad = 0; h->n_tiles = 0; h->c0 = h->c1 = h->c2 = 0; h->data2_off = 0;
+    h->dp_direct = 0; h->direct_wgs_per_cu = 0;
     std::vector<double> dev;  // what goes to h->data
     switch (family) {
         case DEMC_FAM_GAUSSIAN:
@@ -1186,13 +1281,21 @@ int32_t demc_set_model(demc_handle* h, int32_t family, const double* data, const
             h->dpad = 4 * h->ks_t * h->n_kpass;
             if ((N + 15) / 16 > 0x3fffffff) return fail(h, DEMC_EINVAL, "too many observations");
             h->n_tiles = (int)((N + 15) / 16);
-            std::vector<double> Ainv;
+            const bool direct = h->c.loglike_mode == DEMC_LOGLIKE_DIRECT;
+            if (direct && d > 64) return fail(h, DEMC_EUNSUPPORTED, "DIRECT likelihood: data dimension d <= 64 (the whitened proposal lives in registers)");
+            std::vector<double> Ainv, Linv;
             double logdet = 0.0;
             if (family == DEMC_FAM_MVN_FULL) {
-                if (!chol_inv(hyper, d, Ainv, logdet)) return fail(h, DEMC_EINVAL, "Sigma is not positive definite");
+                if (!chol_inv(hyper, d, Ainv, logdet, &Linv)) return fail(h, DEMC_EINVAL, "Sigma is not positive definite");
                 h->c0 = -0.5 * (double)N * (d * kLog2Pi + logdet);
                 ALLOC(h->Ainv, (size_t)d * d);
-                HIPCHK(hipMemcpy(h->Ainv, Ainv.data(), sizeof(double) * d * d, hipMemcpyHostToDevice));
+                // K1's preparation forms y_c = sum_k M[k][c] (theta' - xbar)_k.  M = Sigma^-1 (symmetric) gives y = Sigma^-1 mu~;
+                // in DIRECT mode M = (L^-1)' gives the whitened proposal m = L^-1 mu~ instead.
+                std::vector<double> M = Ainv;
+                if (direct)
+                    for (int r = 0; r < d; ++r)
+                        for (int cc = 0; cc < d; ++cc) M[(size_t)r * d + cc] = Linv[(size_t)cc * d + r];
+                HIPCHK(hipMemcpy(h->Ainv, M.data(), sizeof(double) * d * d, hipMemcpyHostToDevice));
             }
             // The data are CENTRED once (x~_i = x_i - xbar) and proposals are shifted the same way in K1
             // (mu~ = theta' - xbar): (x_i - mu) = (x~_i - mu~), but every term of the expanded quadratic form
@@ -1242,6 +1345,24 @@ int32_t demc_set_model(demc_handle* h, int32_t family, const double* data, const
                     }
             ALLOC(h->Xf, xf.size());
             HIPCHK(hipMemcpy(h->Xf, xf.data(), sizeof(double) * xf.size(), hipMemcpyHostToDevice));
+            if (direct) {
+                // whitened, centred observations z_i = L^-1 x~_i (ISO: x~_i), rows padded with zeros to DP scalars
+                h->dp_direct = d <= 8 ? 8 : d <= 16 ? 16 : d <= 32 ? 32 : 64;
+                const int DP = h->dp_direct;
+                dev.assign((size_t)N * DP, 0.0);
+                for (long long i = 0; i < N; ++i) {
+                    const double* x = data + i * d;
+                    double* zr = dev.data() + (size_t)i * DP;
+                    if (family == DEMC_FAM_MVN_FULL) {
+                        for (int r = 0; r < d; ++r) {
+                            double sr = 0.0;
+                            for (int k = 0; k <= r; ++k) sr += Linv[(size_t)r * d + k] * x[k];
+                            zr[r] = sr;
+                        }
+                    } else
+                        for (int k = 0; k < d; ++k) zr[k] = x[k];
+                }
+            }
         } break;
         default:
             return fail(h, DEMC_EUNSUPPORTED, "model family is not registered; arbitrary closures cannot run on the device");
@@ -1255,21 +1376,25 @@ int32_t demc_set_model(demc_handle* h, int32_t family, const double* data, const
     });
 }
 
-int32_t demc_set_model_source(demc_handle* h, const char* hip_source, const double* data, const int64_t* dims, int32_t ndims,
-                              const double* hyper, int32_t nhyper) {
+static int32_t set_model_source_impl(demc_handle* h, const char* hip_source, const double* data, const int64_t* dims, int32_t ndims,
+                                     const double* hyper, int32_t nhyper, bool row, bool has_prior) {
     return guarded(h, [&]() -> int32_t {
     if (!h || !hip_source) return DEMC_EINVAL;
     USE_DEVICE(h);
-    if (ndims < 1 || !dims || dims[0] < 1 || !data) return fail(h, DEMC_EINVAL, "user model: dims[0] = number of observations, data required");
+    if (ndims < 1 || ndims > 8 || !dims || dims[0] < 1 || !data) return fail(h, DEMC_EINVAL, "user model: dims[0] = number of observations, data required");
     long long n_data = 1;
     for (int i = 0; i < ndims; ++i) n_data *= dims[i];
+    if (n_data < 1) return fail(h, DEMC_EINVAL, "user model: empty data");
     HIPCHK(hipStreamSynchronize(h->stream));
     for (double** p : {&h->data, &h->Ainv, &h->Ypad, &h->Xf, &h->sx, &h->xbar, &h->user_hyper})
         if (*p) { hipFree(*p); *p = nullptr; }
+    if (h->user_dims) { hipFree(h->user_dims); h->user_dims = nullptr; }
     if (h->user_module) { hipModuleUnload(h->user_module); h->user_module = nullptr; h->user_kernel = nullptr; }
     h->family = -1; h->d = 0; h->n_acc = 0; h->dpad = 0; h->n_tiles = 0; h->c0 = h->c1 = h->c2 = 0; h->data2_off = 0;
-    // compile prologue + user source + kernel for gfx950
-    const std::string src = std::string(kUserPrologue) + hip_source + kUserKernel;
+    h->user_row = row; h->user_has_prior = row && has_prior; h->user_ndims = ndims;
+    // compile: kernarg struct + declarations + user source + kernel, for gfx950
+    const std::string src = std::string(row && has_prior ? "#define DEMC_USER_HAS_PRIOR 1\n" : "") + kUserStruct +
+                            (row ? kUserRowPrologue : kUserPrologue) + hip_source + (row ? kUserRowKernel : kUserKernel);
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "demc_user_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         return fail(h, DEMC_EHIP, "hiprtcCreateProgram failed");
@@ -1289,18 +1414,36 @@ int32_t demc_set_model_source(demc_handle* h, const char* hip_source, const doub
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
     HIPCHK(hipModuleLoadData(&h->user_module, code.data()));
-    HIPCHK(hipModuleGetFunction(&h->user_kernel, h->user_module, "k_user_loglike"));
+    HIPCHK(hipModuleGetFunction(&h->user_kernel, h->user_module, row ? "k_user_row" : "k_user_loglike"));
     h->N = dims[0];
     ALLOC(h->data, (size_t)n_data);
     HIPCHK(hipMemcpy(h->data, data, sizeof(double) * (size_t)n_data, hipMemcpyHostToDevice));
+    {
+        long long dm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < ndims; ++i) dm[i] = dims[i];
+        ALLOC(h->user_dims, (size_t)8);
+        HIPCHK(hipMemcpy(h->user_dims, dm, sizeof dm, hipMemcpyHostToDevice));
+    }
     h->user_nhyper = nhyper > 0 ? nhyper : 0;
     if (h->user_nhyper) {
+        if (!hyper) return fail(h, DEMC_EINVAL, "user model: nhyper > 0 without hyper");
         ALLOC(h->user_hyper, (size_t)h->user_nhyper);
         HIPCHK(hipMemcpy(h->user_hyper, hyper, sizeof(double) * (size_t)h->user_nhyper, hipMemcpyHostToDevice));
     }
     h->family = FAM_USER;
     return size_k1_lds(h);
     });
+}
+
+int32_t demc_set_model_source(demc_handle* h, const char* hip_source, const double* data, const int64_t* dims, int32_t ndims,
+                              const double* hyper, int32_t nhyper) {
+    return set_model_source_impl(h, hip_source, data, dims, ndims, hyper, nhyper, false, false);
+}
+
+int32_t demc_set_model_source_row(demc_handle* h, const char* hip_source, const double* data, const int64_t* dims, int32_t ndims,
+                                  const double* hyper, int32_t nhyper, int32_t flags) {
+    if (flags & ~DEMC_USER_HAS_PRIOR) return h ? fail(h, DEMC_EINVAL, "unknown flag") : DEMC_EINVAL;
+    return set_model_source_impl(h, hip_source, data, dims, ndims, hyper, nhyper, true, (flags & DEMC_USER_HAS_PRIOR) != 0);
 }
 
 static int upload_dimtab(demc_handle* h) {
@@ -1535,7 +1678,6 @@ static int step_body(demc_handle* h, int64_t iter0, int32_t n_iters, bool with_m
 // THE HANDLE'S STREAM, i.e. behind every kernel that still reads its previous content.
 static int update_subset(demc_handle* h, int64_t iter0, int32_t n_iters, const int32_t* groups, int32_t n) {
     if (n == 0) return DEMC_OK;
-    if (h->family == FAM_USER) return fail(h, DEMC_EUNSUPPORTED, "subset updates are not available for source plug-in models");
     if (h->rp_active && h->rp_n_mig > 0)
         return fail(h, DEMC_EINVAL, "subset updates follow demc_migration_groups, which does not see a replayed migration sub-group");
     const int G = h->c.n_groups;
@@ -1595,7 +1737,7 @@ static int step_body(demc_handle* h, int64_t iter0, int32_t n_iters, bool with_m
                 if (!h->comm)
                     return fail(h, DEMC_EINVAL, "sharded handle without a communicator: demc_comm_init, or drive the exchange with "
                                                 "demc_migration_pack/apply + demc_update");
-                if (h->comm_overlap && !h->rp_active && h->family != FAM_USER) {
+                if (h->comm_overlap && !h->rp_active) {
                     int run = 1;
                     while (iter + run < iter0 + n_iters && !migration_due_h(h, iter + run)) ++run;
                     int rc = exchange_overlapped(h, iter, run);
@@ -2233,6 +2375,8 @@ int32_t demc_last_kernels(demc_handle* h, char* out, int32_t nbytes) {
     else if (L.k2 == 2) s += " + k_obs_loglike";
     else if (L.k2 == 3) s += " + k_hier_loglike";
     else if (L.k2 == 4) s += " + k_user_loglike";
+    else if (L.k2 == 5) s += " + k_direct_mvn<" + std::to_string(L.ks) + ">";
+    else if (L.k2 == 6) s += " + k_user_row";
     if (L.k3) s += " + k_accept_store";
     std::snprintf(out, (size_t)nbytes, "%s", s.c_str());
     return DEMC_OK;

@@ -121,6 +121,8 @@ struct KParams {
     const double* data;       // family specific
     const double* data2;
     double c0, c1, c2;        // family constants
+    int direct;               // MvNormal families, DIRECT likelihood: Ypad holds the whitened proposal m = L^-1 (theta' - xbar),
+                              // data the whitened observations z_i, and the summed statistic is sum_i |z_i - m|^2
     // replay (demc_set_replay, test mode): device copies of the caller's draws, null = addressed Philox as usual
     const double* rp_group;         // [n_groups]
     const double* rp_part;          // [P][5] snooker coin, select_base, gamma_1, gamma_2, accept
@@ -231,9 +233,11 @@ __device__ inline uint32_t subgroup_bcast(uint32_t v, int lpp, int sub_base) {
 __device__ inline double loglike_from_stats(const KParams& p, double s, double aux, double sg) {
     switch (p.family) {
         case FAM_MVN_FULL:  // c0 = -N/2 (d log2pi + logdet), c1 = sum_i x_i' A^-1 x_i
+            if (p.direct) return p.c0 - 0.5 * s;  // s = sum_i |L^-1 (x_i - mu)|^2, summed term by term
             return p.c0 - 0.5 * (p.c1 - 2.0 * s + (double)p.N * aux);
         case FAM_MVN_ISO: {  // c1 = sum_i |x_i|^2
             const double nd = (double)p.N * (double)p.d;
+            if (p.direct) return -0.5 * nd * kLog2Pi - nd * log(sg) - 0.5 * s / (sg * sg);
             return -0.5 * nd * kLog2Pi - nd * log(sg) - 0.5 * (p.c1 - 2.0 * s + (double)p.N * aux) / (sg * sg);
         }
         case FAM_GAUSSIAN:
@@ -1777,6 +1781,44 @@ __global__ __launch_bounds__(256, 2) void k_cross_mfma(KParams p, const double* 
             const int q = q0 + mt * 16 + (lane >> 4) + 4 * r;
             if ((lane & 15) == 0 && q < n_prop) p.partial[(size_t)(part0 + chunk) * p.P + slot_of(p, q)] = v;
         }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 (MvNormal, DIRECT mode): the residual form the reference's loglike implies (test/multivariate_normal_tests.jl:31-33:
+// logpdf(MvNormal(mu, Sigma), x_i) summed over i) with the whitening done once:  sum_i |z_i - m|^2,  z_i = L^-1 (x_i - xbar)
+// (demc_set_model),  m = L^-1 (theta' - xbar) (K1's preparation, on the matrix cores).  Unlike the expanded form this one
+// does not separate into data-only and proposal-only factors: every (proposal, observation) pair costs 3 d flop on the
+// FP64 vector pipe (SURVEY 8d's count), nothing collapses.  Thread per proposal with m in registers; all lanes of a wave
+// visit the same observation, so a z row is one wave-uniform (scalar) load and enters the VALU as an SGPR operand; per
+// dimension one v_add_f64 and one v_fma_f64.  DP = padded row length (host pads z rows and m with zeros).
+// grid = (proposal blocks of 256, observation chunks).
+// ------------------------------------------------------------------------------------------------
+template <int DP>
+__global__ __launch_bounds__(256) void k_direct_mvn(KParams p, int n_chunks) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int n_prop = p.n_groups * p.n_act;
+    const int chunk = blockIdx.y;
+    const bool ok = q < n_prop;
+    const size_t slot = ok ? (size_t)slot_of(p, q) : 0;
+    double m[DP];
+    const double* mrow = p.Ypad + slot * p.dpad;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) m[k] = (ok && k < p.d) ? mrow[k] : 0.0;
+    const long long per = (p.N + n_chunks - 1) / n_chunks;
+    const long long i0 = chunk * per, i1 = (i0 + per < p.N) ? i0 + per : p.N;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};  // four independent chains per lane
+    const double* z = p.data + i0 * DP;
+    for (long long i = i0; i < i1; ++i, z += DP) {
+#pragma unroll
+        for (int k = 0; k < DP; k += 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double r = z[k + e] - m[k + e];
+                acc[e] = fma(r, r, acc[e]);
+            }
+        }
+    }
+    if (ok) p.partial[(size_t)chunk * p.P + slot] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
 // ------------------------------------------------------------------------------------------------

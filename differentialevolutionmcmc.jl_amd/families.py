@@ -213,8 +213,12 @@ class SourceLikelihood(Likelihood):
     demc_set_model_source (include/demc.h)."""
     family = FAM_USER
 
-    def __init__(self, source, hyper=None):
-        self.source, self.hyper = source, hyper
+    def __init__(self, source, hyper=None, row=False, has_prior=False):
+        """row=True: the whole-row form (demc_set_model_source_row): `source` defines demc_user_loglike_row(theta, D, data, dims,
+        ndims, hyper, nhyper, lane, n_lanes) -- and demc_user_prior_row(...) with has_prior=True -- evaluated by one workgroup
+        per proposal; for likelihoods that are not a flat sum over observations and priors the per-scalar table cannot
+        express (Examples/Hierarchical_Example.jl:26-44)."""
+        self.source, self.hyper, self.row, self.has_prior = source, hyper, bool(row), bool(has_prior)
 
     def pack(self, data, shapes):
         x = np.ascontiguousarray(np.asarray(data, dtype=np.float64))

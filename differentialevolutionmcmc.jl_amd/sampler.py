@@ -115,7 +115,9 @@ def engine_config(de, lay, n_iter, backend, n_groups_local=None, group_offset=0,
 
 def configure_engine(eng, model, lay):
     data, dims, hyper = model.loglike.pack(model.data, lay["shapes"])
-    if isinstance(model.loglike, SourceLikelihood):
+    if isinstance(model.loglike, SourceLikelihood) and model.loglike.row:
+        eng.set_model_source_row(model.loglike.source, data, dims, hyper, has_prior=model.loglike.has_prior)
+    elif isinstance(model.loglike, SourceLikelihood):
         eng.set_model_source(model.loglike.source, data, dims, hyper)
     else:
         eng.set_model(model.loglike.family, data, dims, hyper)

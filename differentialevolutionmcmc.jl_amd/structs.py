@@ -34,7 +34,7 @@ compute_posterior = _Hook("compute_posterior!", 0)
 evaluate_fun = _Hook("evaluate_fun!", 1)
 
 SCHEDULES = {"synchronous": 1, "two_colour": 2}
-LOGLIKE_MODES = {"streaming": 0, "suffstat": 1}
+LOGLIKE_MODES = {"streaming": 0, "suffstat": 1, "direct": 2}
 
 
 class MCMCThreads:

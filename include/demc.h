@@ -64,10 +64,18 @@ enum { DEMC_FITNESS_POSTERIOR = 0, DEMC_FITNESS_FUN = 1 };
 enum { DEMC_SCHED_SEQUENTIAL = 0, DEMC_SCHED_SYNCHRONOUS = 1, DEMC_SCHED_TWO_COLOUR = 2 };
 /* How Gaussian-family likelihoods are evaluated.
  *   STREAMING : every proposal visits every observation, as model.loglike does
- *               (structs.jl:186; test/multivariate_normal_tests.jl:31-33) -- FP64 MFMA bound;
+ *               (structs.jl:186; test/multivariate_normal_tests.jl:31-33), in the EXPANDED quadratic form
+ *               sum_i x~_i'A x~_i - 2 y.(x~_i summed through the matrix cores) + N mu~'A mu~, y = A mu~, A = Sigma^-1, data centred:
+ *               2 N d flop per proposal on v_mfma_f64 -- FP64 MFMA bound.  (After centring the streamed cross term
+ *               sum_i y.x~_i equals y.(sum_i x~_i), i.e. rounding noise around zero: STREAMING = SUFFSTAT + that product;
+ *               the data dependence of the result sits in the data-only constant and in N mu~'A mu~.)
  *   SUFFSTAT  : one pass over the data at demc_set_model, O(D^2) per proposal -- HBM bound.
- * Reported separately and labelled. */
-enum { DEMC_LOGLIKE_STREAMING = 0, DEMC_LOGLIKE_SUFFSTAT = 1 };
+ *   DIRECT    : the residual form sum_i |L^-1 (x_i - mu)|^2 term by term (whitened once: z_i = L^-1 x~_i at
+ *               demc_set_model, m = L^-1 mu~ per proposal): 3 N d flop per proposal that do NOT separate into data-only
+ *               and proposal-only factors -- FP64 vector bound; MvNormal families with d <= 64.
+ * Same proposals and accept decisions in all three (log-densities agree to rounding); reported separately and labelled
+ * (SURVEY.md 8d). */
+enum { DEMC_LOGLIKE_STREAMING = 0, DEMC_LOGLIKE_SUFFSTAT = 1, DEMC_LOGLIKE_DIRECT = 2 };
 
 /* Registered model family evaluated on device (user closures cannot run on the GPU). */
 enum {
@@ -160,6 +168,22 @@ int32_t demc_set_model(demc_handle* h, int32_t family, const double* host_data, 
  * registered scalar-data families use; compile errors are returned through demc_last_error. */
 int32_t demc_set_model_source(demc_handle* h, const char* hip_source, const double* host_data, const int64_t* dims,
                               int32_t ndims, const double* host_hyper, int32_t nhyper);
+/* Whole-row plug-in: a log-likelihood that is NOT a plain sum of per-observation terms of a flat data array, and / or a
+ * prior the per-scalar table cannot express -- what DEModel's arbitrary prior_loglike / loglike closures (structs.jl:176-189)
+ * look like in the reference's own hierarchical example (Examples/Hierarchical_Example.jl:26-44: the prior of beta_s depends on
+ * another parameter, the likelihood indexes the data by subject).  `hip_source` must define
+ *     __device__ double demc_user_loglike_row(const double* theta, int D, const double* data, const long long* dims, int ndims,
+ *                                             const double* hyper, int nhyper, int lane, int n_lanes);
+ * and, with flags & DEMC_USER_HAS_PRIOR,
+ *     __device__ double demc_user_prior_row(const double* theta, int D, const double* hyper, int nhyper, int lane, int n_lanes);
+ * Each proposal row is evaluated by ONE WORKGROUP of n_lanes = 256 lanes: a function returns the share of lane `lane`
+ * (typically `for (s = lane; s < S; s += n_lanes) acc += term(s);` -- or everything on lane 0 and 0.0 elsewhere); the shares
+ * are summed in a fixed order.  The prior value is added to what the per-scalar table of demc_set_priors gives (flat by
+ * default; bounds still come from demc_set_bounds) and is left out under evaluate_fun! (utilities.jl:113-120).
+ * data = the flat host_data array with shape dims[0..ndims) (ndims <= 8). */
+#define DEMC_USER_HAS_PRIOR 1
+int32_t demc_set_model_source_row(demc_handle* h, const char* hip_source, const double* host_data, const int64_t* dims,
+                                  int32_t ndims, const double* host_hyper, int32_t nhyper, int32_t flags);
 int32_t demc_set_priors(demc_handle* h, const int32_t* kind, const double* a, const double* b, const int32_t* ref);
 /* de.bounds flattened to one (lo,hi) per scalar; +-Inf allowed (utilities.jl:70-78) */
 int32_t demc_set_bounds(demc_handle* h, const double* lo, const double* hi);

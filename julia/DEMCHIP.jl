@@ -50,7 +50,7 @@ end
 
 struct HIPBackend
     schedule::Symbol      # :two_colour (default), :synchronous, or :sequential (the reference's own sweep; slow, for replay runs)
-    loglike_mode::Symbol  # :streaming or :suffstat
+    loglike_mode::Symbol  # :streaming, :suffstat or :direct (include/demc.h DEMC_LOGLIKE_*)
     device_id::Int
     seed::UInt64
 end
@@ -121,7 +121,7 @@ function make_config(de::DE, D::Int, n_iter::Int, b; n_groups = de.n_groups, gro
         de.α, de.β, de.ϵ, de.σ, de.κ, de.θsnooker,
         hook_code(de.generate_proposal, PROPOSALS, "generate_proposal"), hook_code(de.sample, PARTNERS, "sample"),
         hook_code(de.update_particle!, UPDATES, "update_particle!"), hook_code(de.evaluate_fitness!, FITNESS, "evaluate_fitness!"),
-        sched, 1, group_offset, de.n_groups, b.seed, device_id, b.loglike_mode == :streaming ? 0 : 1, 0, 0, de.n_groups, 0)
+        sched, 1, group_offset, de.n_groups, b.seed, device_id, b.loglike_mode == :streaming ? 0 : b.loglike_mode == :suffstat ? 1 : 2, 0, 0, de.n_groups, 0)
 end
 
 "model, priors, bounds, the prior-draw history rows and the particles `ps` (one shard's, in slot order) onto handle `h`"

@@ -731,3 +731,91 @@ def test_cfg5_full_share_properties(orc):
     nu = (3,2,1), A = .8, k = .2, tau = .3, snooker 0.1 (the data bench.py --config cfg5 runs)"""
     gain = _full_share("cfg5", orc, n_iter=4, spot_rows=8, rtol=1e-5)
     assert gain > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Whole-row plug-in (demc_set_model_source_row): user-written prior_loglike / loglike of ANY shape (structs.jl:176-189)
+# ---------------------------------------------------------------------------------------------------------------------
+HIER_ROW_SRC = r"""
+// Examples/Hierarchical_Example.jl:26-44 written by a user: theta = (mu_b0, sd_b0, b0[1:S], sigma), data Y[S][n]
+//   prior_loglike: mu_b0 ~ Normal(1,1), sd_b0 ~ truncated(Cauchy(0,1),0,Inf), b0_s ~ Normal(0, sd_b0), sigma ~ truncated(Cauchy(0,1),0,Inf)
+//   loglike:       y_{s,i} ~ Normal(mu_b0 + b0_s, sigma)
+__device__ double norm_lpdf(double x, double m, double s) { const double z = (x - m) / s; return -(z * z + 1.8378770664093453) / 2.0 - log(s); }
+__device__ double hcauchy_lpdf(double x) { return x < 0.0 ? -INFINITY : 0.6931471805599453 - 1.1447298858494002 - log1p(x * x); }
+__device__ double demc_user_loglike_row(const double* th, int D, const double* Y, const long long* dims, int ndims,
+                                        const double* hyper, int nhyper, int lane, int n_lanes) {
+    const long long S = dims[0], n = dims[1];
+    const double mu0 = th[0], sg = th[2 + S];
+    double acc = 0.0;
+    for (long long s = lane; s < S; s += n_lanes)
+        for (long long i = 0; i < n; ++i) acc += norm_lpdf(Y[s * n + i], mu0 + th[2 + s], sg);
+    return acc;
+}
+__device__ double demc_user_prior_row(const double* th, int D, const double* hyper, int nhyper, int lane, int n_lanes) {
+    const int S = D - 3;
+    double acc = 0.0;
+    if (lane == 0) acc = norm_lpdf(th[0], 1.0, 1.0) + hcauchy_lpdf(th[1]) + hcauchy_lpdf(th[2 + S]);
+    for (int s = lane; s < S; s += n_lanes) acc += norm_lpdf(th[2 + s], 0.0, th[1]);
+    return acc;
+}
+"""
+
+
+def test_user_written_hierarchical_model_equals_the_registered_family():
+    """the reference's hierarchical Gaussian (a prior that depends on another parameter, a likelihood
+    indexed by subject) registered as USER SOURCE, no built-in family involved: log-posteriors equal FAM_HIER_GAUSSIAN's to
+    1e-12, out-of-bounds rows stay -Inf, and a sampling run with block updates makes the same accept decisions."""
+    from conftest import make_problem, setup_engine
+    rng = np.random.default_rng(81)
+    prob = make_problem("hier_gaussian", rng, S=37, n=9)
+    Dd, G, Np = prob["D"], 4, 8
+    th = prob["init"](G * Np)
+    th[3, 1] = -0.5  # sd_b0 < 0: out of bounds -> -Inf, neither function is called (utilities.jl:92-99)
+    a = D.HipEngine(n_groups=G, Np=Np, D=Dd, schedule=2, n_rows=12, seed=4, burnin=6)
+    setup_engine(a, prob)
+    b = D.HipEngine(n_groups=G, Np=Np, D=Dd, schedule=2, n_rows=12, seed=4, burnin=6)
+    b.set_model_source_row(HIER_ROW_SRC, prob["data"], prob["dims"], has_prior=True)
+    b.set_bounds(prob["lo"], prob["hi"])   # priors: the table stays flat, the user's function is the prior
+    la, lb = a.logpost(th), b.logpost(th)
+    assert la[3] == -np.inf and lb[3] == -np.inf
+    fin = np.isfinite(la)
+    assert fin.sum() == G * Np - 1
+    np.testing.assert_allclose(lb[fin], la[fin], rtol=1e-12)
+    masks = np.zeros((2, Dd), np.uint8)   # blocks [hyper ; subject] (Examples/Hierarchical_Example.jl:88-92)
+    masks[0, :2] = 1
+    masks[0, -1] = 1
+    masks[1] = 1 - masks[0]
+    th0 = prob["init"](G * Np)
+    for e in (a, b):
+        e.set_blocks(masks)
+        e.set_state(th0)
+        e.step(1, 12)
+    assert "k_user_row" in b.last_kernels()
+    ha, hb = a.get_history(0, 12), b.get_history(0, 12)
+    assert np.array_equal(ha[1], hb[1]) and np.array_equal(ha[3], hb[3]) and ha[1].mean() > 0.05
+    np.testing.assert_allclose(hb[0], ha[0], rtol=1e-12)
+    np.testing.assert_allclose(hb[2], ha[2], rtol=1e-11)
+    # a source that lacks the entry point fails loudly, with the compiler's message
+    c = D.HipEngine(n_groups=G, Np=Np, D=Dd, schedule=2)
+    with pytest.raises(D.DemcError) as err:
+        c.set_model_source_row("__device__ double something_else() { return 0.0; }", prob["data"], prob["dims"])
+    assert err.value.code in (D._ffi.EINVAL, D._ffi.EHIP)
+    for e in (a, b, c):
+        e.close()
+
+
+def test_user_row_model_through_sample():
+    """the same through DEModel / DE / sample: SourceLikelihood(row=True, has_prior=True)"""
+    rng = np.random.default_rng(82)
+    S, n = 6, 30
+    b0 = rng.normal(0, 0.7, S)
+    Y = 1.0 + b0[:, None] + rng.normal(0, 0.5, (S, n))
+    sp = lambda: [rng.normal(1, 1), abs(rng.standard_cauchy()) + 0.2, rng.normal(0, 1, S), abs(rng.standard_cauchy()) + 0.2]
+    model = D.DEModel(sample_prior=sp, prior_loglike=D.Priors(mu_b0=D.Flat(), sd_b0=D.Flat(), b0=D.Flat(), sigma=D.Flat()),
+                      loglike=D.SourceLikelihood(HIER_ROW_SRC, row=True, has_prior=True), data=Y, names=("mu_b0", "sd_b0", "b0", "sigma"))
+    de = D.DE(sample_prior=sp, bounds=((-np.inf, np.inf), (0.0, np.inf), (-np.inf, np.inf), (0.0, np.inf)), burnin=1500, Np=12, n_groups=4)
+    ch = D.sample(model, de, D.HIPBackend(seed=9), 4000)
+    d = ch.describe()
+    assert abs(d["sigma"]["mean"] - 0.5) < 0.06
+    got = np.array([d[f"b0[{s + 1}]"]["mean"] + d["mu_b0"]["mean"] for s in range(S)])
+    np.testing.assert_allclose(got, Y.mean(1), atol=0.08)   # subject means are well identified (30 observations each)

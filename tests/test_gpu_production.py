@@ -138,3 +138,59 @@ def test_lean_kernel_plan_follows_the_prior_table(demc, orc, n_distinct, kernel)
     w["lo"] = list(-50.0 - seg)
     w["hi"] = list(60.0 + seg)
     free_run(demc, orc, w, 8, [kernel], 4, 256, theta_exact=True, beta=0.0, loglike_mode=1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DIRECT likelihood: the residual form sum_i |L^-1 (x_i - mu)|^2, term by term (what the reference's loglike implies,
+# test/multivariate_normal_tests.jl:31-33; SURVEY 8d's 3ND count) -- the form that does not collapse after centring
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("family,d", [("mvn_full", 5), ("mvn_full", 8), ("mvn_full", 13), ("mvn_full", 32), ("mvn_full", 40),
+                                      ("mvn_iso", 6), ("mvn_iso", 20)])
+def test_direct_mode_log_posteriors_match_the_oracle(demc, orc, family, d):
+    from conftest import make_problem, setup_engine
+    prob = make_problem(family, np.random.default_rng(90 + d), N=700, d=d)
+    th = prob["init"](64)
+    o = orc.Oracle(n_groups=4, Np=16, D=prob["D"], schedule=1)
+    setup_engine(o, prob)
+    want = o.logpost(th)
+    o.close()
+    for mode in (2, 0, 1):
+        e = demc.HipEngine(n_groups=4, Np=16, D=prob["D"], schedule=1, loglike_mode=mode)
+        setup_engine(e, prob)
+        np.testing.assert_allclose(e.logpost(th), want, rtol=1e-9, err_msg=f"loglike_mode {mode}")
+        e.close()
+    with pytest.raises(demc.DemcError):
+        demc.HipEngine(n_groups=4, Np=16, D=2, schedule=1, loglike_mode=3)
+
+
+@pytest.mark.parametrize("beta", [0.0, 0.1])
+def test_cfg3_geometry_direct_chain(demc, orc, beta):
+    """PLAIN K1 (whitened proposal m = L^-1 mu~ on the matrix cores) -> k_direct_mvn<32> -> k_accept_store, free-running
+    against the oracle (whose MvNormal likelihood is the same whitened residual form, oracle/demc_oracle.c:490-505)"""
+    from demc_amd import workloads as W
+    w = W.cfg3(N=2000, G=16)
+    free_run(demc, orc, w, 8, ["k_propose<256,true,TAIL_PREP_MFMA,false,true>", "k_direct_mvn<32>", "k_accept_store"], 16, 256,
+             theta_exact=beta == 0.0, beta=beta, loglike_mode=2, geometry_groups=256)
+
+
+def test_the_three_likelihood_modes_make_the_same_decisions(demc):
+    """STREAMING (expanded form on the matrix cores), SUFFSTAT and DIRECT are three evaluation orders of one log-density:
+    same proposals, same accept decisions, log-posteriors to rounding -- cfg2's shape, 40 iterations"""
+    from demc_amd import workloads as W
+    w = W.cfg2(N=4000)
+    G, Np, n_it = w["G"], w["Np"], 40
+    th0 = w["init"](G * Np, np.random.default_rng(6))
+    outs, names = [], []
+    for mode in (0, 1, 2):
+        e = demc.HipEngine(n_groups=G, Np=Np, D=w["D"], n_rows=n_it, schedule=2, seed=77, burnin=20, loglike_mode=mode)
+        W.configure(e, w)
+        e.set_state(th0)
+        e.step(1, n_it)
+        outs.append(e.get_history(0, n_it))
+        names.append(e.last_kernels())
+        e.close()
+    assert "k_res_mvn<256,true,8>" in names[0] and "k_res_mvn<256,false,8>" in names[1] and "k_direct_mvn<8>" in names[2], names
+    for other in outs[1:]:
+        assert np.array_equal(outs[0][1], other[1]) and np.array_equal(outs[0][3], other[3])
+        assert np.array_equal(outs[0][0], other[0])
+        np.testing.assert_allclose(outs[0][2], other[2], rtol=1e-10)
