@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP64_TFLOPS = 78.6   # MI355X FP64 matrix = vector peak: 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (datasheet)
 PEAK_HBM_GBS = 8000.0     # MI355X HBM3E nominal; /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_ROUND = "r02"     # profiles/<round>/ holds the rocprofv3 PMC passes `traffic` is read from
+PROFILE_ROUND = "r03"     # profiles/<round>/ holds the rocprofv3 PMC passes `traffic` is read from
 
 
 def parse():
@@ -115,6 +115,26 @@ def describe(a, w, world):
             f"n_groups={G}x{world} (BASELINE: 512 groups over 8 GPUs), Np={Np}, snooker 0.1, schedule={a.schedule}")
 
 
+def source_fingerprint():
+    """sha256 over the kernel / runtime sources the library is built from: the committed PMC summaries carry the fingerprint
+    of the sources they were collected on, and are not quoted for any other (they would go stale silently)"""
+    import hashlib
+    hsh = hashlib.sha256()
+    csrc = os.path.join(ROOT, "differentialevolutionmcmc.jl_amd", "csrc")
+    for f in sorted(os.listdir(csrc)) + [os.path.join(ROOT, "include", "demc.h")]:
+        path = f if os.path.isabs(f) else os.path.join(csrc, f)
+        if os.path.isfile(path) and path.endswith((".cpp", ".hpp", ".h")):
+            hsh.update(open(path, "rb").read())
+    return hsh.hexdigest()[:16]
+
+
+def profile_is_current(rec_file):
+    try:
+        return json.load(open(rec_file)).get("source_sha16") == source_fingerprint()
+    except (OSError, ValueError):
+        return False
+
+
 def measured_traffic(a, launches, k_iters):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
     (profiles/<round>/bench_<config>_<mode>_pmc.json, written by tools/collect_profiles.py: FETCH_SIZE and WRITE_SIZE in
@@ -130,6 +150,8 @@ def measured_traffic(a, launches, k_iters):
             rec = json.load(open(path))["dominant"]
         except (OSError, KeyError, ValueError):
             continue
+        if not profile_is_current(path):
+            return None, f"profiles/{rnd}/{os.path.basename(path)} was collected on other kernel sources: not quoted"
         src = f"profiles/{rnd}/{os.path.basename(path)} (rocprofv3 --pmc passes of this command, not this run)"
         if "bytes_per_launch" in rec:
             return float(rec["bytes_per_launch"]), src
@@ -201,38 +223,67 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
         S = w["dims"][0]
         t_s = (fused_ms + tm["loglike"]["ms"]) * 1e-3
         n_launch = max(1, tm["propose"]["launches"])
-        byts = sweeps * (24.0 * D + 17.0 + 16.0 * S) * P * k_iters
-        ach = byts / t_s / 1e9
+        # SURVEY 8d's formula, per particle-update and block sweep: read theta (8D) + write theta' (8D) + history row (8D) + 17
+        # + the subjects' data (16 S).  It overstates what the path needs: the reference stores the history row once per
+        # ITERATION (store_samples!, utilities.jl:161-180), not once per sweep; the hyper-parameter sweep rewrites two scalars,
+        # not a row; and the 16 S bytes of counts are shared by every particle (L2).  What an iteration must move through HBM
+        # per particle: its row in (8D) for each sweep, the accepted row out (<= 8D, subject sweep only) and ONE history
+        # row (8D) -- `necessary_bytes`.  Both are reported; `frac` (the contract's field) is the honest one: counter traffic.
+        survey_bytes = sweeps * (24.0 * D + 17.0 + 16.0 * S) * P * k_iters
+        necessary_bytes = (sweeps * 8.0 * D + 8.0 * D + 8.0 * D + 17.0 * sweeps) * P * k_iters
         traffic, src = measured_traffic(a, n_launch, k_iters)
         inst = "k_longrow<256>, two workgroups per CU" if P // 2 >= 512 else "k_longrow<512>"  # (launch_phase's rule, 256 CUs)
+        ach_survey = survey_bytes / t_s / 1e9
+        ach_traffic = None if traffic is None else traffic * n_launch / t_s / 1e9
         rf = dict(bound="hbm", kernel=inst + " (a workgroup per particle, one pass: proposal, prior, subject terms, accept, store)",
-                  achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
-                  bytes_counted=f"{sweeps} block sweeps x (24*D+17 + 16*S) per particle-update and iteration (SURVEY 8d)",
+                  achieved=ach_traffic if ach_traffic is not None else necessary_bytes / t_s / 1e9,
+                  peak=PEAK_HBM_GBS, unit="GB/s",
+                  frac=(ach_traffic if ach_traffic is not None else necessary_bytes / t_s / 1e9) / PEAK_HBM_GBS,
+                  bytes_counted=("HBM bytes from the FETCH_SIZE / WRITE_SIZE counters of the profiled run / device time of this run"
+                                 if ach_traffic is not None else
+                                 "necessary bytes: row in per sweep + accepted row out + ONE history row per iteration (no profiled traffic for this shape)"),
+                  necessary_gbs=necessary_bytes / t_s / 1e9, necessary_frac=necessary_bytes / t_s / 1e9 / PEAK_HBM_GBS,
+                  survey_formula_gbs=ach_survey, survey_formula_frac=ach_survey / PEAK_HBM_GBS,
+                  survey_formula=f"{sweeps} block sweeps x (24*D+17 + 16*S) per particle-update (SURVEY 8d; counts the history row per sweep and L2-resident data)",
                   launch_ms=t_s / n_launch * 1e3, launches=n_launch, updates_per_launch=sweeps * P * k_iters / n_launch,
                   traffic=traffic, traffic_source=src,
-                  wasted_traffic_ratio=None if traffic is None else traffic / (byts / n_launch))
+                  wasted_traffic_ratio=None if traffic is None else traffic / (necessary_bytes / n_launch))
     else:  # cfg5
         N, na = w["dims"]
         t_s = tm["loglike"]["ms"] * 1e-3
         n_launch = max(1, tm["loglike"]["launches"])
         evals = float(N) * P * k_iters
-        # executed FP64 flop per (trial, proposal): per accumulator 2 x (phi, Phi) pairs = 2 x [two degree-8 polynomials
-        # 2*2*8 + interval look-up 6] + density/cdf algebra 14, plus the product, floor and log ~ 30  (DESIGN section 5).
-        # (Round 2 replaced the exp + erfcx form, 420 flop per evaluation, by the Phi / phi tables: fewer flop AND less time --
-        # the flop fraction fell while the evaluations per second rose; the pipe counters say how busy the VALU is.)
-        flop_per_eval = na * (2 * (2 * 2 * 8 + 6) + 14) + 30
-        ach = evals * flop_per_eval / t_s / 1e12
-        busy, busy_src = None, None
+        # executed FP64 flop per (trial, proposal): counted from the compiler's assembly of the shipped loop (an FMA two flop,
+        # add / mul / max / min / rcp one; tools/count_lba_flop.py -> profiles/<round>/lba_inner_loop.json), not by hand
+        inner, inner_src = {}, None
+        try:
+            pj = os.path.join(ROOT, "profiles", PROFILE_ROUND, "lba_inner_loop.json")
+            inner = json.load(open(pj))
+            inner_src = f"profiles/{PROFILE_ROUND}/lba_inner_loop.json (static count over the batch loop of the shipped kernel)"
+        except (OSError, ValueError):
+            pass
+        flop_per_eval = inner.get("fp64_flop_per_eval")
+        ach = None if flop_per_eval is None else evals * flop_per_eval / t_s / 1e12
+        pipes, pipes_src = {}, None
         try:
             pj = os.path.join(ROOT, "profiles", PROFILE_ROUND, f"bench_{a.config}_{a.mode}_pipe_pmc.json")
-            busy = [v["valu_busy_frac"] for k, v in json.load(open(pj)).items() if "k_obs_loglike" in k][0]
-            busy_src = f"profiles/{PROFILE_ROUND}/{os.path.basename(pj)} (rocprofv3 --pmc pass of this command, not this run)"
+            if profile_is_current(pj):
+                pipes = [v for k, v in json.load(open(pj)).items() if "k_obs_loglike" in k][0]
+                pipes_src = f"profiles/{PROFILE_ROUND}/{os.path.basename(pj)} (rocprofv3 --pmc passes of this command, not this run)"
+            else:
+                pipes_src = f"profiles/{PROFILE_ROUND}/{os.path.basename(pj)} was collected on other kernel sources: not quoted"
         except (OSError, KeyError, ValueError, IndexError):
             pass
-        rf = dict(bound="valu", kernel="k_obs_loglike (LBA: thread per proposal, wave-uniform trial loads, Phi / phi polynomial tables in LDS)",
-                  achieved=ach, peak=PEAK_FP64_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP64_TFLOPS,
-                  flop_counted=f"{flop_per_eval} FP64 flop per (trial, proposal) evaluation x N x proposals",
-                  valu_busy_frac=busy, valu_busy_source=busy_src,
+        rf = dict(bound="valu", kernel="k_obs_loglike (LBA: thread per proposal, wave-uniform trial loads in batches of 8, one degree-9 "
+                                       "Phi polynomial table in LDS whose derivative gives phi, one log per batch)",
+                  achieved=ach, peak=PEAK_FP64_TFLOPS, unit="TFLOP/s", frac=None if ach is None else ach / PEAK_FP64_TFLOPS,
+                  flop_counted=None if flop_per_eval is None else f"{flop_per_eval:.1f} executed FP64 flop per (trial, proposal) evaluation x N x proposals",
+                  flop_source=inner_src, static_valu_insts_per_eval=inner.get("valu_insts_per_eval"),
+                  lds_reads_per_eval=inner.get("lds_reads_per_eval"),
+                  valu_busy_frac=pipes.get("valu_busy_frac"), lds_busy_frac=pipes.get("lds_busy_frac"),
+                  measured_valu_insts_per_eval=(pipes["SQ_INSTS_VALU_mean"] * 64.0 / (float(N) * P * k_iters / n_launch)
+                                                if "SQ_INSTS_VALU_mean" in pipes else None), pipe_source=pipes_src,
+                  limiting_pipe="LDS (table reads: 6 look-ups x 80 B x 64 lanes per wave and trial against 128 B/clk per CU) -- see DESIGN section 6",
                   trial_proposal_evaluations_per_s=evals / t_s, launch_ms=t_s / n_launch * 1e3, launches=n_launch,
                   updates_per_launch=P * k_iters / n_launch, traffic=None, traffic_source=None, wasted_traffic_ratio=None)
     rf["timing"] = "HIP events recorded on the timed iterations, on the stream the kernels run on"
@@ -489,6 +540,7 @@ def main():
                                       else "torch.distributed.all_gather_into_tensor (backend nccl = RCCL)"),
                        "all_gathers_rank0": n_gathers},
             "particle_parameter_updates_per_s": value * D,
+            "particle_iterations_per_s": P * world * a.steps / dt,  # (value counts every block sweep as an update: cfg4 has two)
             "accuracy": accuracy, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -166,26 +166,38 @@ __device__ inline double erfcx_pos(const double* tab, double y) {
     for (int k = kErfcxDeg - 1; k >= 0; --k) r = fma(r, dz, a[k]);
     return r;
 }
-// phi(z) and Phi(z) from the generated piecewise polynomials (tools/gen_phi_table.py: absolute error 1.1e-16, z clamped to
-// [-8.5, 8.5] beyond which both are 0 / 1 in double precision): two degree-8 Horner chains on one interval look-up, no exp.
-// For sums of order one -- the LBA density and distribution function -- where absolute accuracy is what counts; the
-// log-survival of the LNR keeps the exp + erfcx form (relative accuracy in the tail).  tab points at a copy of kPhiTable.
-// A NaN argument gives NaN.
-__device__ inline void phi_Phi_table(const double* tab, double z, double& ph, double& Ph) {
-    double zc = z < -kPhiZmax ? -kPhiZmax : z;
-    zc = zc > kPhiZmax ? kPhiZmax : zc;
-    int idx = (int)((zc + kPhiZmax) * (double)kPhiPerUnit);
-    idx = idx < kPhiIntervals - 1 ? idx : kPhiIntervals - 1;
-    const double dz = zc - fma((double)idx + 0.5, 1.0 / kPhiPerUnit, -kPhiZmax);
-    const double* a = tab + idx * (2 * (kPhiDeg + 1));
-    double P = a[kPhiDeg], q = a[2 * kPhiDeg + 1];
+// Phi(z) and phi(z)/S from the generated piecewise polynomial of Phi (tools/gen_phi_table.py: absolute error 1.1e-16 for Phi
+// and for the phi recovered from it; |z| clamped to 8.5, beyond which they are 0 / 1 in double precision).  S = kPhiPerUnit
+// rows per unit of z.  The argument arrives SCALED, zs = S z: row i = round(zs + 8.5 S) of the table is the polynomial of Phi
+// around z_i = -8.5 + i/S in u = zs + 8.5 S - i in [-1/2, 1/2]; value and derivative (dPhi/du = phi/S) come out of one Horner
+// recurrence (2 deg - 1 FMAs, deg + 1 coefficients), no exp.  Row index and u without a conversion instruction: adding
+// 1.5 * 2^52 + 8.5 S rounds zs + 8.5 S to an integer that sits in the low word of the sum; subtracting the constant again
+// gives i - 8.5 S exactly.  (v_cvt_i32_f64, v_fract_f64, v_mul_lo_u32 and v_ldexp_f64 run at a quarter of the FP64 add rate;
+// the row address is a 24-bit multiply, which runs at full rate.  Rows are NOT padded to a power of two: with a 128-byte
+// stride every row starts on LDS bank 0 and lanes that read different rows serialise -- measured 2.7x slower than the
+// 80-byte stride.)  For sums of order one -- the LBA density and distribution function -- where absolute accuracy is what
+// counts; the log-survival of the LNR keeps the exp + erfcx form (relative accuracy in the tail).  tab points at a copy of
+// kPhiTable.  The clamp is v_max / v_min: a NaN argument is read as -8.5 (callers that must turn a NaN into -Inf test their
+// own inputs, see lba_trial).
+constexpr double kPhiS = (double)kPhiPerUnit;
+constexpr double kPhiHalf = kPhiZmax * kPhiPerUnit;              // 8.5 S: an integer
+constexpr double kPhiMagic = 6755399441055744.0 + kPhiHalf;      // 1.5 * 2^52 + 8.5 S (exactly representable)
+static_assert(kPhiZmax == 8.5 && (kPhiPerUnit & 1) == 0 && kPhiRow >= kPhiDeg + 1 && (kPhiRow & 1) == 0, "table shape");
+__device__ __forceinline__ void phiS_Phi_table(const double* tab, double zs, double& phS, double& Ph) {
+    const double zc = fmin(fmax(zs, -kPhiHalf), kPhiHalf);
+    const double t = zc + kPhiMagic;              // = round(zc + 8.5 S) + 1.5 * 2^52
+    const double u = zc - (t - kPhiMagic);        // t - magic = row - 8.5 S, exactly
+    const int row = __double2loint(t);            // low word of the sum = the row
+    const double* a = tab + __mul24(row, kPhiRow);
+    double P = a[kPhiDeg], dP = a[kPhiDeg];
+    P = fma(P, u, a[kPhiDeg - 1]);
 #pragma unroll
-    for (int k = kPhiDeg - 1; k >= 0; --k) {
-        P = fma(P, dz, a[k]);
-        q = fma(q, dz, a[kPhiDeg + 1 + k]);
+    for (int k = kPhiDeg - 2; k >= 0; --k) {
+        dP = fma(dP, u, P);
+        P = fma(P, u, a[k]);
     }
     Ph = P;
-    ph = q;
+    phS = dP;
 }
 // log Phi(-z) (log-survival of a standard normal), finite far into the tail
 __device__ inline double log_Phi_neg(const double* tab, double z) {
@@ -194,17 +206,46 @@ __device__ inline double log_Phi_neg(const double* tab, double z) {
 }
 
 // LBA (Examples/Run_LBA.jl:33-37; SequentialSamplingModels conventions: b = A + k, sigma = 1,
-// normalised by 1 - P(all drifts <= 0), density floored at 1e-10)
-// density and distribution function of one accumulator at decision time t, sharing the four phi / Phi values
-// (tab: kPhiTable)
-__device__ inline void lba_dens_cdf(const double* tab, double v, double b, double A, double t, double inv_t, double inv_A,
-                                    double& dens, double& cdf) {
-    const double n1 = (b - A) * inv_t - v, n2 = b * inv_t - v;  // (b - A - t v)/t, (b - t v)/t
-    double p1, P1, p2, P2;
-    phi_Phi_table(tab, n1, p1, P1);
-    phi_Phi_table(tab, n2, p2, P2);
-    dens = inv_A * (v * (P2 - P1) + (p1 - p2));
-    cdf = 1.0 + (t * inv_A) * ((n1 * P1 - n2 * P2) + (p1 - p2));
+// normalised by 1 - P(all drifts <= 0), density floored at 1e-10).
+// One accumulator at decision time t, n1 = (b - A - t v)/t, n2 = (b - t v)/t, sharing the four phi / Phi values:
+//   density      f = (1/A) [ v (Phi(n2) - Phi(n1)) + (phi(n1) - phi(n2)) ]                       (the winner's factor)
+//   survival 1-F = (t/A) [ (n2 Phi(n2) - n1 Phi(n1)) - (phi(n1) - phi(n2)) ]                      (a loser's factor)
+// Only ONE of the two is needed per accumulator and trial, and which one is wave-uniform (the lanes of a wave are
+// proposals at the same trial): `win` is a scalar branch.  Everything arrives scaled by S (the table's argument scale):
+// vS = S v, c1 = S k/t, c2 = S b/t, so m1 = S n1, m2 = S n2; the table returns q = phi/S.  With dq = q1 - q2:
+//   f = (1/A) [ v (P2 - P1) + S dq ],      1 - F = (t / S A) [ (m2 P2 - m1 P1) - S^2 dq ].
+__device__ __forceinline__ double lba_factor(const double* tab, bool win, double v, double vS, double c1, double c2, double inv_A,
+                                             double t_inv_SA) {
+    const double m1 = c1 - vS, m2 = c2 - vS;
+    double q1, P1, q2, P2;
+    phiS_Phi_table(tab, m1, q1, P1);
+    phiS_Phi_table(tab, m2, q2, P2);
+    const double dq = q1 - q2;
+    if (win) return inv_A * fma(kPhiS, dq, v * (P2 - P1));
+    return t_inv_SA * fma(-(kPhiS * kPhiS), dq, fma(m2, P2, -(m1 * P1)));
+}
+// 1/x for x > 0 to the last bit or two: hardware reciprocal + two Newton steps (the IEEE division is ~25 instructions)
+__device__ __forceinline__ double recip_pos(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+// the factor a trial contributes to the likelihood PRODUCT: max(density, 1e-10), or 0 where the reference's log-density is
+// -Inf (decision time not after tau, NaN density) -- the caller takes ONE log of the product of several trials.
+// nuS = S nu, kS = S k, bS = S b, inv_SA = 1 / (S A)
+template <int NA>
+__device__ __forceinline__ double lba_trial(const double* tab, int na_rt, const double* nu, const double* nuS, double kS, double bS,
+                                            double tau, double inv_A, double inv_SA, double inv_norm, int c, double rt) {
+    const int na = NA > 0 ? NA : na_rt;
+    const double t = rt - tau;
+    const double inv_t = recip_pos(t), c1 = kS * inv_t, c2 = bS * inv_t, t_inv_SA = t * inv_SA;
+    double den = inv_norm;
+#pragma unroll
+    for (int a = 0; a < (NA > 0 ? NA : 8); ++a)
+        if (a < na) den *= lba_factor(tab, a + 1 == c, nu[a], nuS[a], c1, c2, inv_A, t_inv_SA);
+    const double floored = fmax(den, 1e-10);  // (a NaN density is caught below)
+    return (t > 0.0 && den == den) ? floored : 0.0;
 }
 
 }  // namespace demc

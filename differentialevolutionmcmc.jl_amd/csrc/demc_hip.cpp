@@ -73,6 +73,7 @@ struct demc_handle {
     int ks_t = 0, n_kpass = 0;  // MFMA k-steps per pass (template) and passes over the dimensions
     int dp_direct = 0;          // DIRECT mode: padded length of a whitened observation row (8 / 16 / 32 / 64)
     int direct_wgs_per_cu = 0;  // ... resident workgroups of its kernel per CU (asked once)
+    int obs_wgs_per_cu = 0;     // the same for k_obs_loglike
     double *data = nullptr, *Ainv = nullptr, *Ypad = nullptr, *Xf = nullptr, *sx = nullptr, *xbar = nullptr;
     size_t data2_off = 0;
     // user plug-in (demc_set_model_source): JIT-compiled module, kernel and its hyper-parameters
@@ -403,6 +404,20 @@ extern "C" __global__ __launch_bounds__(256) void k_user_loglike(UserKParams p) 
 }
 )SRC";
 
+// Number of observation chunks for a K2 kernel that is one long uniform loop per workgroup: such a launch takes
+// ceil(workgroups / resident workgroups) rounds of equal length, so among the admissible counts (1..cap) the one that fills
+// the last round best wins; ties go to the larger count while the launch stays within four rounds.
+int chunks_filling_rounds(long long blocks, long long cap, double resident_wgs) {
+    long long best = 1;
+    double best_fill = 0.0;
+    for (long long nc = 1; nc <= cap; ++nc) {
+        const double wgs = (double)blocks * (double)nc;
+        const double fill = wgs / (std::ceil(wgs / resident_wgs) * resident_wgs);
+        if (fill > best_fill + 1e-9 || (fill > best_fill - 1e-9 && wgs <= 4.0 * resident_wgs)) { best = nc; best_fill = fill; }
+    }
+    return (int)best;
+}
+
 // K2 dispatch for the active set described by k.  Sets k.n_partials.
 int launch_loglike(demc_handle* h, KParams& k) {
     const long long n_prop = (long long)k.n_groups * k.n_act;
@@ -429,15 +444,7 @@ int launch_loglike(demc_handle* h, KParams& k) {
                     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0));
                     h->direct_wgs_per_cu = nb > 0 ? nb : 1;
                 }
-                const double resident = (double)h->direct_wgs_per_cu * h->n_cus;
-                long long best = 1;
-                double best_fill = 0.0;
-                for (long long nc = 1; nc <= cap; ++nc) {
-                    const double wgs = (double)blocks * (double)nc;
-                    const double fill = wgs / (std::ceil(wgs / resident) * resident);
-                    if (fill > best_fill + 1e-9 || (fill > best_fill - 1e-9 && wgs <= 4.0 * resident)) { best = nc; best_fill = fill; }
-                }
-                const int n_chunks = (int)best;
+                const int n_chunks = chunks_filling_rounds(blocks, cap, (double)h->direct_wgs_per_cu * h->n_cus);
                 h->last.k2 = 5; h->last.ks = h->dp_direct;
                 tick(h, 2, true);
                 const dim3 grid((unsigned)blocks, (unsigned)n_chunks);
@@ -480,13 +487,19 @@ int launch_loglike(demc_handle* h, KParams& k) {
         case FAM_LBA:
         case FAM_LNR:
         case FAM_RASTRIGIN: {
-            long long want = (262144 + n_prop - 1) / n_prop;
             long long cap = h->N / 32;
-            if (cap < 1) cap = 1;
-            if (want > cap) want = cap;
-            if (want > h->partial_cap) want = h->partial_cap;
-            if (want < 1 || h->family == FAM_RASTRIGIN) want = 1;
-            const int n_chunks = (int)want;
+            if (cap > h->partial_cap) cap = h->partial_cap;
+            if (cap < 1 || h->family == FAM_RASTRIGIN) cap = 1;
+            if (h->obs_wgs_per_cu == 0) {
+                int nb = 0;
+                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_obs_loglike, 256, 0));
+                h->obs_wgs_per_cu = nb > 0 ? nb : 1;
+            }
+            int n_chunks = chunks_filling_rounds((n_prop + 255) / 256, cap, (double)h->obs_wgs_per_cu * h->n_cus);
+            if (const char* e = experiment("DEMC_OBS_CHUNKS")) {  // A/B experiments
+                std::fprintf(stderr, "k_obs_loglike: %d workgroups per CU, %d chunks chosen\n", h->obs_wgs_per_cu, n_chunks);
+                if (std::atoi(e) > 0 && std::atoi(e) <= cap) n_chunks = std::atoi(e);
+            }
             h->last.k2 = 2;
             tick(h, 2, true);
             LAUNCH_T(h, k_obs_loglike, dim3((unsigned)((n_prop + 255) / 256), (unsigned)n_chunks), dim3(256), 0,

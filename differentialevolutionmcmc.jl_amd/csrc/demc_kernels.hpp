@@ -247,11 +247,84 @@ __device__ inline double loglike_from_stats(const KParams& p, double s, double a
     }
 }
 
+// LBA log-likelihood of the trials i0, i0+stride, ... < i1 for one proposal (thread per proposal: every lane of the wave is
+// at the same trial, so choice and decision time arrive by scalar loads).  Trials go in batches of kLbaBatch: their (choice,
+// rt) pairs are loaded together -- scalar loads share the wait counter with the LDS table reads, so a load per trial
+// made every trial wait for both -- and the batch contributes ONE log, of the product of its floored densities (each
+// in [1e-10, ~1e2]: eight of them cannot leave the double range; a -Inf trial contributes a factor 0 and log 0 = -Inf).
+constexpr int kLbaBatch = 8;
+template <int NA>
+__device__ __forceinline__ double lba_range_sum(const KParams& p, const double* th, long long i0, long long i1, int stride, const double* tab) {
+    const int na = NA > 0 ? NA : p.n_acc;
+    double nu[8], nuS[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        nu[a] = a < na ? th[a] : 0.0;
+        nuS[a] = kPhiS * nu[a];
+    }
+    const double A = th[na], kk = th[na + 1], tau = th[na + 2], b = A + kk, inv_A = 1.0 / A;
+    const double kS = kPhiS * kk, bS = kPhiS * b, inv_SA = inv_A * (1.0 / kPhiS);
+    double pneg = 1.0;
+#pragma unroll
+    for (int a = 0; a < (NA > 0 ? NA : 8); ++a)
+        if (a < na) {
+            double q, Ph;
+            phiS_Phi_table(tab, -nuS[a], q, Ph);
+            pneg *= Ph;
+        }
+    const double inv_norm = 1.0 / (1.0 - pneg);
+    double acc = 0.0;
+    long long i = i0;
+    for (; i + (long long)(kLbaBatch - 1) * stride < i1; i += (long long)kLbaBatch * stride) {
+        double cc[kLbaBatch], rr[kLbaBatch];
+#pragma unroll
+        for (int j = 0; j < kLbaBatch; ++j) {
+            cc[j] = p.data[i + (long long)j * stride];
+            rr[j] = p.data2[i + (long long)j * stride];
+        }
+        double prod = 1.0;
+#pragma unroll
+        for (int j = 0; j < kLbaBatch; ++j)
+            prod *= lba_trial<NA>(tab, na, nu, nuS, kS, bS, tau, inv_A, inv_SA, inv_norm, (int)cc[j], rr[j]);
+        acc += log(prod);
+    }
+    double prod = 1.0;
+    for (; i < i1; i += stride)
+        prod *= lba_trial<NA>(tab, na, nu, nuS, kS, bS, tau, inv_A, inv_SA, inv_norm, (int)p.data[i], p.data2[i]);
+    return acc + log(prod);
+}
+
+// LNR log-likelihood of the trials i0, i0+stride, ... < i1 for one proposal (lognormal_race_tests.jl:9-12); tab = kErfcxTable
+__device__ __forceinline__ double lnr_range_sum(const KParams& p, const double* th, long long i0, long long i1, int stride, const double* tab) {
+    const int na = p.n_acc;
+    double nu[8];
+    for (int a = 0; a < 8; ++a) nu[a] = a < na ? th[a] : 0.0;
+    const double tau = th[na], sg = p.c0, lsg = log(sg), isg = 1.0 / sg;
+    double acc = 0.0;
+    for (long long i = i0; i < i1; i += stride) {
+        const int c = (int)p.data[i];
+        const double t = p.data2[i] - tau;
+        double ll = 0.0;
+        if (!(t > 0.0))
+            ll = -INFINITY;
+        else {
+            const double lt = log(t);
+            for (int a = 0; a < na; ++a) {
+                const double z = (lt - nu[a]) * isg;
+                ll += (a + 1 == c) ? (-(z * z + kLog2Pi) / 2.0 - lsg - lt) : log_Phi_neg(tab, z);
+            }
+        }
+        acc += ll;
+    }
+    return acc;
+}
+
 // Sum over observations i = i0, i0+stride, ... < i1 of the per-observation statistic of one proposal `th`
-// (Gaussian: z^2; Binomial / LBA / LNR: the log-density; rastrigin: the objective on i == 0).  tab = the family's table in
-// LDS (LBA: kPhiTable, LNR: kErfcxTable) or nullptr for the families that do not need one.
-__device__ inline double obs_range_sum(const KParams& p, const double* th, long long i0, long long i1, int stride,
-                                       const double* tab) {
+// (Gaussian: z^2; Binomial: the log-density; hierarchical families: one term per subject; rastrigin: the objective on i == 0).
+// The race models (LBA, LNR) are never summed by the proposal kernel's own lanes (thousands of trials, a table in LDS):
+// they live in lba_range_sum / lnr_range_sum, inlined into k_obs_loglike alone -- as cases of this function they made it too
+// large to inline anywhere, and every caller paid a call with its kernarg spilled to scratch.
+__device__ inline double obs_range_sum(const KParams& p, const double* th, long long i0, long long i1, int stride) {
     double acc = 0.0;
     switch (p.family) {
         case FAM_GAUSSIAN: {  // sum_i ((x_i - mu)/sigma)^2   Gaussian_Example.jl:26-28
@@ -270,62 +343,6 @@ __device__ inline double obs_range_sum(const KParams& p, const double* th, long 
                 const double t1 = (k == 0.0) ? 0.0 : k * lp;
                 const double t2 = (n - k == 0.0) ? 0.0 : (n - k) * l1p;
                 acc += lgc[i] + t1 + t2;
-            }
-        } break;
-        case FAM_LBA: {  // Run_LBA.jl:33-37
-            const int na = p.n_acc;
-            double nu[8];
-            for (int a = 0; a < 8; ++a) nu[a] = a < na ? th[a] : 0.0;
-            const double A = th[na], kk = th[na + 1], tau = th[na + 2], b = A + kk, inv_A = 1.0 / A;
-            double pneg = 1.0;
-            for (int a = 0; a < na; ++a) {
-                double ph, Ph;
-                phi_Phi_table(tab, -nu[a], ph, Ph);
-                pneg *= Ph;
-            }
-            const double inv = 1.0 / (1.0 - pneg);
-            for (long long i = i0; i < i1; i += stride) {
-                const int c = (int)p.data[i];
-                const double rt = p.data2[i];
-                double ll;
-                if (rt < tau)
-                    ll = -INFINITY;
-                else {
-                    const double t = rt - tau, inv_t = 1.0 / t;
-                    double den = 1.0;
-                    for (int a = 0; a < na; ++a) {
-                        double dens, cdf;
-                        lba_dens_cdf(tab, nu[a], b, A, t, inv_t, inv_A, dens, cdf);
-                        den *= (a + 1 == c) ? dens : (1.0 - cdf);
-                    }
-                    den *= inv;
-                    if (den != den)
-                        ll = -INFINITY;
-                    else
-                        ll = log(den < 1e-10 ? 1e-10 : den);
-                }
-                acc += ll;
-            }
-        } break;
-        case FAM_LNR: {  // lognormal_race_tests.jl:9-12
-            const int na = p.n_acc;
-            double nu[8];
-            for (int a = 0; a < 8; ++a) nu[a] = a < na ? th[a] : 0.0;
-            const double tau = th[na], sg = p.c0, lsg = log(sg), isg = 1.0 / sg;
-            for (long long i = i0; i < i1; i += stride) {
-                const int c = (int)p.data[i];
-                const double t = p.data2[i] - tau;
-                double ll = 0.0;
-                if (!(t > 0.0))
-                    ll = -INFINITY;
-                else {
-                    const double lt = log(t);
-                    for (int a = 0; a < na; ++a) {
-                        const double z = (lt - nu[a]) * isg;
-                        ll += (a + 1 == c) ? (-(z * z + kLog2Pi) / 2.0 - lsg - lt) : log_Phi_neg(tab, z);
-                    }
-                }
-                acc += ll;
             }
         } break;
         case FAM_HIER_BINOMIAL: {  // k_s ~ Binomial(n, logistic(mu_b0 + b0_s)) (BASELINE cfg4); "observation" = subject
@@ -1574,7 +1591,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (lpp > 64) __syncthreads();  // the row was written by all waves of the workgroup
-            S = group_sum(obs_range_sum(p, scr + srow * scr_stride, sl, p.N, lpp, nullptr), lpp, s_gsum);
+            S = group_sum(obs_range_sum(p, scr + srow * scr_stride, sl, p.N, lpp), lpp, s_gsum);
         }
 
         if (!p.fuse_accept) {
@@ -1827,7 +1844,7 @@ __global__ __launch_bounds__(256) void k_direct_mvn(KParams p, int n_chunks) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_obs_loglike(KParams p, int n_chunks) {
     // LDS copy of the family's table: Phi / phi polynomials (LBA), erfcx polynomials (LNR)
-    constexpr int kTabPhi = kPhiIntervals * 2 * (kPhiDeg + 1), kTabErfcx = kErfcxIntervals * (kErfcxDeg + 1);
+    constexpr int kTabPhi = kPhiIntervals * kPhiRow, kTabErfcx = kErfcxIntervals * (kErfcxDeg + 1);
     __shared__ double s_tab[kTabPhi > kTabErfcx ? kTabPhi : kTabErfcx];
     if (p.family == FAM_LBA) {
         for (int i = threadIdx.x; i < kTabPhi; i += 256) s_tab[i] = kPhiTable[i];
@@ -1844,7 +1861,14 @@ __global__ __launch_bounds__(256) void k_obs_loglike(KParams p, int n_chunks) {
     const double* th = p.prop + slot * p.D;
     const long long per = (p.N + n_chunks - 1) / n_chunks;
     const long long i0 = chunk * per, i1 = (i0 + per < p.N) ? i0 + per : p.N;
-    const double acc = obs_range_sum(p, th, i0, i1, 1, s_tab);
+    double acc;
+    if (p.family == FAM_LBA)  // Run_LBA.jl:33-37
+        acc = p.n_acc == 3 ? lba_range_sum<3>(p, th, i0, i1, 1, s_tab)
+              : p.n_acc == 2 ? lba_range_sum<2>(p, th, i0, i1, 1, s_tab) : lba_range_sum<0>(p, th, i0, i1, 1, s_tab);
+    else if (p.family == FAM_LNR)
+        acc = lnr_range_sum(p, th, i0, i1, 1, s_tab);
+    else
+        acc = obs_range_sum(p, th, i0, i1, 1);
     p.partial[(size_t)chunk * p.P + slot] = acc;
 }
 

@@ -27,10 +27,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STEPS, WARMUP = 20, 5
 # (the default sampler on MvNormal-full runs in the lean resident kernel k_res_mvn; other samplers in k_propose<..., RES>)
 DOMINANT = {("cfg3", "streaming"): "k_cross_mfma", ("cfg3", "suffstat"): "k_res_mvn|k_propose<", ("cfg2", "streaming"): "k_res_mvn|k_propose<",
-            ("cfg4", "streaming"): "k_longrow", ("cfg5", "streaming"): "k_obs_loglike"}
+            ("cfg4", "streaming"): "k_longrow", ("cfg5", "streaming"): "k_obs_loglike", ("cfg3", "direct"): "k_direct_mvn",
+            ("cfg1", "streaming"): "k_propose<"}
 MFMA_CTRS = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_F64", "SQ_INSTS_VALU_MFMA_MOPS_F64", "GRBM_GUI_ACTIVE",
              "SQ_WAVE_CYCLES", "SQ_INSTS_VALU"]
-VALU_CTRS = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS",
+VALU_CTRS = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS",
              "GRBM_GUI_ACTIVE"]
 
 
@@ -89,6 +90,9 @@ def dominant_kernel(names, pat, resident):
 
 
 def main():
+    sys.path.insert(0, ROOT)
+    import bench
+    fingerprint = bench.source_fingerprint()  # bench.py quotes a summary only for the sources it was collected on
     out_dir = os.path.abspath(sys.argv[1])
     os.makedirs(out_dir, exist_ok=True)
     combos = [tuple(c.split(":")) for c in sys.argv[2:]] or list(DOMINANT)
@@ -102,10 +106,6 @@ def main():
         d = run(out_dir, f"{tag}_stats", ["--stats"], args)
         for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
             shutil.copy(f, os.path.join(out_dir, f"bench_{tag}_kernel_stats.csv"))
-        with open(os.path.join(out_dir, f"{tag}_stats.log")) as fh:
-            lines = [ln for ln in fh if ln.startswith("{\"metric\"")]
-        if lines:
-            open(os.path.join(out_dir, f"bench_{tag}_line.json"), "w").write(lines[-1])
         res, totals = {}, defaultdict(float)
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             vals, grid = counters(run(out_dir, f"{tag}_{ctr}", ["--pmc", ctr], args))
@@ -130,6 +130,7 @@ def main():
                 rec["bytes_per_launch"] = (2.0 * e["FETCH_SIZE_KB_mean"] + e["WRITE_SIZE_KB_mean"]) * 1024.0
             rec["launches"] = e["launches_total"]
             res["dominant"] = rec
+        res["source_sha16"] = fingerprint
         json.dump(res, open(os.path.join(out_dir, f"bench_{tag}_pmc.json"), "w"), indent=1)
         # pipe counters of the dominant kernel
         mfma = (cfg in ("cfg2", "cfg3")) and mode == "streaming"
@@ -152,7 +153,26 @@ def main():
                 e["valu_busy_frac"] = 4.0 * e["SQ_ACTIVE_INST_VALU_mean"] / (e["GRBM_GUI_ACTIVE_mean"] / 8.0 * 1024.0)
             if "SQ_INSTS_VALU_mean" in e and e.get("SQ_WAVES_mean", 0) > 0:
                 e["valu_insts_per_wave"] = e["SQ_INSTS_VALU_mean"] / e["SQ_WAVES_mean"]
+            if "SQ_LDS_IDX_ACTIVE_mean" in e and e.get("GRBM_GUI_ACTIVE_mean", 0) > 0:
+                # cycles the LDS pipe of a CU was working, summed over the 256 CUs
+                e["lds_busy_frac"] = e["SQ_LDS_IDX_ACTIVE_mean"] / (e["GRBM_GUI_ACTIVE_mean"] / 8.0 * 256.0)
+        m["source_sha16"] = fingerprint
         json.dump(m, open(os.path.join(out_dir, f"bench_{tag}_pipe_pmc.json"), "w"), indent=1)
+        # The bench line LAST, from an un-profiled run that reads the summaries just written (round 2 wrote the line of the
+        # first pass, whose roofline quoted the PREVIOUS collection's counters): the summaries are installed under
+        # profiles/<round>/ of this tree first (bench.PROFILE_ROUND), then bench.py runs once more.
+        inst = os.path.join(ROOT, "profiles", bench.PROFILE_ROUND)
+        os.makedirs(inst, exist_ok=True)
+        for suffix in ("pmc.json", "pipe_pmc.json", "kernel_stats.csv"):
+            src = os.path.join(out_dir, f"bench_{tag}_{suffix}")
+            if os.path.exists(src):
+                shutil.copy(src, inst)
+        with open(os.path.join(out_dir, f"{tag}_line.log"), "w") as log:
+            out = subprocess.run(["python3", os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, stdout=subprocess.PIPE, stderr=log, text=True, timeout=600)
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{\"metric\"")]
+        if lines:
+            open(os.path.join(out_dir, f"bench_{tag}_line.json"), "w").write(lines[-1] + "\n")
+            shutil.copy(os.path.join(out_dir, f"bench_{tag}_line.json"), inst)
     print("summaries in", out_dir)
 
 

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Counts what ONE (trial, proposal) evaluation of the LBA likelihood executes, from the compiler's own output: the device
+code of k_obs_loglike is compiled to assembly, the batch loop of lba_range_sum<3> (kLbaBatch trials per iteration) is cut
+out, and its FP64 instructions are counted -- an FMA as two flop, add / mul / max / min / rcp as one.  bench.py's cfg5
+roofline uses the result (profiles/<round>/lba_inner_loop.json) instead of a hand count; the PMC pass of the same round gives
+the executed VALU instructions per evaluation to compare with `valu_insts`.
+
+    python3 tools/count_lba_flop.py profiles/r03/lba_inner_loop.json"""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BATCH = int(re.search(r"constexpr int kLbaBatch = (\d+);", open(os.path.join(ROOT, "differentialevolutionmcmc.jl_amd/csrc/demc_kernels.hpp")).read()).group(1))
+src = '#include "%s"\n' % os.path.join(ROOT, "differentialevolutionmcmc.jl_amd/csrc/demc_kernels.hpp")
+with tempfile.TemporaryDirectory() as td:
+    hip, asm = os.path.join(td, "k.hip"), os.path.join(td, "k.s")
+    open(hip, "w").write(src)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                           "--cuda-device-only", "-S", hip, "-o", asm], stderr=subprocess.DEVNULL)
+    text = open(asm).read()
+body = re.search(r"^_ZN4demc13k_obs_loglikeENS_7KParamsEi:(.*?)s_endpgm", text, re.S | re.M).group(1)
+# the batch loop of the 3-accumulator instance: the loop (header label .. last branch back to it) whose body holds exactly
+# 3 accumulators x 2 look-ups x 5 sixteen-byte table reads per trial
+lines = body.splitlines()
+labels = {m.group(1): i for i, ln in enumerate(lines) if (m := re.match(r"^(\.LBB\d+_\d+):", ln))}
+best = None
+for lab, start in labels.items():
+    back = [i for i, ln in enumerate(lines) if i > start and re.search(r"s_c?branch\w* " + re.escape(lab) + r"$", ln.strip())]
+    if not back:
+        continue
+    blk = lines[start:back[-1] + 1]
+    if sum(x.strip().startswith("ds_read_b128") for x in blk) == 30 * BATCH and (best is None or len(blk) < len(best)):
+        best = blk
+assert best, "batch loop not found"
+ins = [x.split()[0] for x in best if x.startswith("\t") and not x.strip().startswith((";", "."))]
+valu = [x for x in ins if x.startswith("v_")]
+fma = sum(x.startswith(("v_fma_f64", "v_fmac_f64")) for x in valu)
+one = sum(x.startswith(("v_add_f64", "v_mul_f64", "v_max_f64", "v_min_f64", "v_rcp_f64")) for x in valu)
+lds = sum(x.startswith("ds_read") for x in ins)
+# the log of the batch product is outside the counted set only if it is a call; here it is inline: count it with the loop
+out = dict(kernel="k_obs_loglike, lba_range_sum<3> batch loop", trials_per_iteration=BATCH,
+           valu_insts_per_eval=len(valu) / BATCH, fp64_fma_per_eval=fma / BATCH, fp64_other_per_eval=one / BATCH,
+           fp64_flop_per_eval=(2 * fma + one) / BATCH, lds_reads_per_eval=lds / BATCH, salu_per_eval=sum(x.startswith("s_") for x in ins) / BATCH,
+           note="static count over one iteration of the batch loop (both sides of the wave-uniform winner / loser branches are in "
+                "the loop body, so the per-evaluation figures are upper bounds by ~2 instructions per accumulator)")
+print(json.dumps(out, indent=1))
+if len(sys.argv) > 1:
+    os.makedirs(os.path.dirname(os.path.abspath(sys.argv[1])), exist_ok=True)
+    json.dump(out, open(sys.argv[1], "w"), indent=1)
