@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
+    ap.add_argument("--config", default="cfg3", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--mode", default="streaming", choices=["streaming", "suffstat", "direct"],
                     help="MvNormal likelihood: streaming = expanded quadratic form on the FP64 matrix cores (headline); suffstat = "
                          "O(D^2) per proposal; direct = the residual form sum_i |L^-1(x_i - mu)|^2 term by term on the FP64 vector pipe")
@@ -105,6 +105,9 @@ def build_workload(a):
 
 def describe(a, w, world):
     G, Np, D = w["G"], w["Np"], w["D"]
+    if a.config == "cfg1":
+        return (f"cfg1: Examples/Gaussian_Example.jl, 1-D Normal(mu, sigma), N={w['dims'][0]} obs, n_groups={G}x{world}, Np={Np}, sampler "
+                f"defaults, schedule={a.schedule} (BASELINE's CPU plumbing config, here on the GPU: 40 particles cannot fill one CU)")
     if a.config in ("cfg2", "cfg3"):
         return (f"{a.config}: MvNormal full-Sigma D={D}, N={w['dims'][0]} obs, n_groups={G}x{world}, Np={Np}, sampler defaults, "
                 f"schedule={a.schedule}, loglike={a.mode}")
@@ -219,6 +222,18 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
                       updates_per_launch=P * k_iters / n_launch,
                       traffic=traffic, traffic_source=src,
                       wasted_traffic_ratio=None if traffic is None else traffic / (byts / n_launch))
+    elif a.config == "cfg1":
+        t_s = fused_ms * 1e-3
+        n_launch = max(1, tm["propose"]["launches"])
+        byts = (24.0 * D + 17.0) * P * k_iters
+        ach = byts / t_s / 1e9
+        rf = dict(bound="hbm", kernel="k_propose<..., TAIL_OBS, RES, PLAIN>: the whole update of a group by one workgroup, resident "
+                                      "over the iterations between two migrations",
+                  achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
+                  bytes_counted="24*D+17 per particle-update (SURVEY 8d); four workgroups on a 256-CU chip: the number says how little "
+                                "of the chip 40 particles can use, not how good the kernel is -- latency per iteration is the figure of merit",
+                  us_per_iteration=t_s / k_iters * 1e6, launch_ms=t_s / n_launch * 1e3, launches=n_launch,
+                  updates_per_launch=P * k_iters / n_launch, traffic=None, traffic_source=None, wasted_traffic_ratio=None)
     elif a.config == "cfg4":
         S = w["dims"][0]
         t_s = (fused_ms + tm["loglike"]["ms"]) * 1e-3
@@ -256,12 +271,17 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
         # executed FP64 flop per (trial, proposal): counted from the compiler's assembly of the shipped loop (an FMA two flop,
         # add / mul / max / min / rcp one; tools/count_lba_flop.py -> profiles/<round>/lba_inner_loop.json), not by hand
         inner, inner_src = {}, None
-        try:
-            pj = os.path.join(ROOT, "profiles", PROFILE_ROUND, "lba_inner_loop.json")
+        pj = os.path.join(ROOT, "profiles", PROFILE_ROUND, "lba_inner_loop.json")
+        if profile_is_current(pj):
             inner = json.load(open(pj))
             inner_src = f"profiles/{PROFILE_ROUND}/lba_inner_loop.json (static count over the batch loop of the shipped kernel)"
-        except (OSError, ValueError):
-            pass
+        else:  # the committed count belongs to other sources: count again (hipcc -S of the kernel header, ~20 s)
+            try:
+                out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "count_lba_flop.py")], capture_output=True, text=True, timeout=300)
+                inner = json.loads(out.stdout)
+                inner_src = "tools/count_lba_flop.py run now (the committed count was taken on other kernel sources)"
+            except (OSError, ValueError, subprocess.SubprocessError):
+                pass
         flop_per_eval = inner.get("fp64_flop_per_eval")
         ach = None if flop_per_eval is None else evals * flop_per_eval / t_s / 1e12
         pipes, pipes_src = {}, None

@@ -46,6 +46,9 @@ __device__ inline uint32_t wave_get(uint32_t v, int src) { return (uint32_t)__bu
 #define DEMC_LR_EXIT(n)
 #endif
 
+#ifndef DEMC_LR_PREFETCH
+#define DEMC_LR_PREFETCH 1  // blocks requested ahead of the one being worked on in the span loops
+#endif
 template <int WG>
 __global__ __launch_bounds__(WG, 512 / WG) void k_longrow(KParams p) {
     extern __shared__ double lds[];  // theta' of the particle [D (+1 if odd)] | cumulative pool weights [pool_n + chunks], the
@@ -574,10 +577,22 @@ __global__ __launch_bounds__(WG, 512 / WG) void k_longrow(KParams p) {
             }
             return r;
         };
+        // (DEMC_LR_PREFETCH = 2 keeps two blocks in flight beside the one being worked on.  Measured on the whole cfg4 and on
+        // its share: no difference to one block ahead -- 168 us per launch either way -- for 22 more VGPRs: the span loops
+        // wait for arithmetic, not for rows.  A round is 351 VALU instructions of which 38 run at a quarter of the FP64
+        // rate (20 v_mad_u64_u32 of the Philox block; rndne, cvt, ldexp and rcp of four softplus), ~1860 cycles per wave.)
         Blk cur = load(tid + i0 * WG);
+#if DEMC_LR_PREFETCH >= 2
+        Blk nx1 = load(tid + (i0 + 1 < i1 ? i0 + 1 : i0) * WG);
+#endif
         for (int i = i0; i < i1; ++i) {
             const int m = tid + i * WG;
+#if DEMC_LR_PREFETCH >= 2
+            const Blk nxt = nx1;
+            nx1 = load(tid + (i + 2 < i1 ? i + 2 : i1 - 1) * WG);
+#else
             const Blk nxt = load(tid + (i + 1 < i1 ? i + 1 : i) * WG);
+#endif
             ++n_fast_blocks__;
             double v0 = cur.t0.x, v1 = cur.t0.y, v2 = cur.t1.x, v3 = cur.t1.y;
             if constexpr (MODE == M_MUT) {  // pt + Normal(0, sigma) on every scalar: mutation.jl:15-18 (a group in ten takes this

@@ -129,6 +129,24 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
 
     const double eps = p.eps, eps2 = p.eps - (-p.eps);
     const long long n_steps = (long long)p.n_iters * 2;
+    // The addressed draws of a colour phase (the particle's PART block, its NOISE blocks) depend on (seed, iteration, slot)
+    // only, not on the state: STREAM draws those of the NEXT phase between storing its hand-over granules and polling for
+    // the others' -- in the shadow of the L2 round trip, off the next phase's chain (and the first poll comes later, when
+    // the peers' granules have had time to arrive).
+    U4 pre_mine = {0, 0, 0, 0}, pre_nzA = pre_mine, pre_nzB = pre_mine;
+    auto draw_phase = [&](long long st, U4& mine_o, U4& nzA_o, U4& nzB_o) {
+        const int ph_ = (int)(st & 1);
+        const long long iter_ = p.iter + (st >> 1);
+        const int a_lo_ = ph_ ? half : 0, n_act_ = ph_ ? Np - half : half;
+        const int q_ = threadIdx.x >> 2, sl_ = threadIdx.x & 3;
+        const int pl_ = a_lo_ + (q_ < n_act_ ? q_ : 0);
+        const uint32_t es = (uint32_t)g_glob * (uint32_t)Np + (uint32_t)pl_;
+        mine_o = draw_block(p.seed, S_PART, 0, (uint64_t)iter_, es, (uint32_t)sl_);
+        nzA_o = draw_block(p.seed, S_NOISE, 0, (uint64_t)iter_, es, (uint32_t)sl_);
+        nzB_o = nzA_o;
+        if (16 + 4 * sl_ < D) nzB_o = draw_block(p.seed, S_NOISE, 0, (uint64_t)iter_, es, (uint32_t)(sl_ + 4));
+    };
+    if (STREAM) draw_phase(0, pre_mine, pre_nzA, pre_nzB);
     for (long long step = 0; step < n_steps; ++step) {
         DEMC_STAMP_RESET();
         const int ph = (int)(step & 1);
@@ -172,7 +190,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
         }
         DEMC_STAMP(0);  // wave 0: cumulative weights in LDS
         // ---- per-particle scalars: lane sl draws PART block sl, the quad shares them (crossover.jl:156-166, utilities.jl:57) ----
-        const U4 mine = draw_block(p.seed, S_PART, 0, (uint64_t)iter, eslot, (uint32_t)sl);
+        const U4 mine = STREAM ? pre_mine : draw_block(p.seed, S_PART, 0, (uint64_t)iter, eslot, (uint32_t)sl);
         const U4 r0 = bcast_u4<0>(mine, 4, 0), ri = bcast_u4<1>(mine, 4, 0), rg = bcast_u4<2>(mine, 4, 0), ra = bcast_u4<3>(mine, 4, 0);
         const double u_base = u53(r0.z, r0.w), u_acc = u53(ra.x, ra.y);
         uint32_t ia, ib;
@@ -180,9 +198,9 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
         const double g1 = 0.5 + (1.0 - 0.5) * u53(rg.x, rg.y);
         const double g2 = use_base ? 0.5 + (1.0 - 0.5) * u53(rg.z, rg.w) : 0.0;
         // noise: block sl (scalars jA..jA+3) and block sl + 4 (scalars jB..jB+3)
-        const U4 nzA = draw_block(p.seed, S_NOISE, 0, (uint64_t)iter, eslot, (uint32_t)sl);
-        U4 nzB = nzA;
-        if (jB < D) nzB = draw_block(p.seed, S_NOISE, 0, (uint64_t)iter, eslot, (uint32_t)(sl + 4));
+        const U4 nzA = STREAM ? pre_nzA : draw_block(p.seed, S_NOISE, 0, (uint64_t)iter, eslot, (uint32_t)sl);
+        U4 nzB = STREAM ? pre_nzB : nzA;
+        if (!STREAM && jB < D) nzB = draw_block(p.seed, S_NOISE, 0, (uint64_t)iter, eslot, (uint32_t)(sl + 4));
         const uint32_t nw[8] = {nzA.x, nzA.y, nzA.z, nzA.w, nzB.x, nzB.y, nzB.z, nzB.w};
 
         DEMC_STAMP(1);  // particle and noise blocks drawn
@@ -363,6 +381,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
                 store_granule(mine_g, epoch, (unsigned)__double2loint(v));
                 store_granule(mine_g + 1, epoch, (unsigned)__double2hiint(v));
             }
+            if (step + 1 < n_steps) draw_phase(step + 1, pre_mine, pre_nzA, pre_nzB);  // while the granules travel
             {
                 const int tot = p.st_C * n_act * 2;
                 unsigned spins = 0;

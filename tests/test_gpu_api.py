@@ -482,7 +482,8 @@ def test_bench_contract_on_a_small_workload(mode):
     assert "timed_chain" in acc and "posterior_mean_l1_rel" in acc and "leg" in acc  # the steps-independent accuracy leg
 
 
-@pytest.mark.parametrize("config,extra", [("cfg2", ["--nobs", "2000"]), ("cfg4", ["--nobs", "600", "--n-groups", "4", "--np", "8"]),
+@pytest.mark.parametrize("config,extra", [("cfg1", []), ("cfg3", ["--mode", "direct", "--n-groups", "16", "--np", "32", "--nobs", "4000", "--dim", "8"]),
+                                          ("cfg2", ["--nobs", "2000"]), ("cfg4", ["--nobs", "600", "--n-groups", "4", "--np", "8"]),
                                           ("cfg5", ["--nobs", "500", "--n-groups", "4", "--np", "16"])])
 def test_bench_lines_of_the_other_configs(config, extra):
     """--config cfg2 / cfg4 / cfg5 print the same contract with their own roofline definition"""
@@ -497,7 +498,7 @@ def test_bench_lines_of_the_other_configs(config, extra):
     r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     rf = r["roofline"]
     assert r["n_gpus"] == 1 and config in r["config"]["workload"] and r["value"] > 0
-    assert rf["bound"] == {"cfg2": "mfma", "cfg4": "hbm", "cfg5": "valu"}[config]
+    assert rf["bound"] == {"cfg1": "hbm", "cfg3": "valu", "cfg2": "mfma", "cfg4": "hbm", "cfg5": "valu"}[config]
     assert 0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert r["cpu_baseline"]["value"] > 0 and r["accuracy"]["timed_chain"]["finite_weights"]
     sweeps = r["config"]["block_sweeps_per_step"]

@@ -47,6 +47,9 @@ out = dict(kernel="k_obs_loglike, lba_range_sum<3> batch loop", trials_per_itera
            fp64_flop_per_eval=(2 * fma + one) / BATCH, lds_reads_per_eval=lds / BATCH, salu_per_eval=sum(x.startswith("s_") for x in ins) / BATCH,
            note="static count over one iteration of the batch loop (both sides of the wave-uniform winner / loser branches are in "
                 "the loop body, so the per-evaluation figures are upper bounds by ~2 instructions per accumulator)")
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+out["source_sha16"] = bench.source_fingerprint()  # bench.py quotes the count only for the sources it was taken on
 print(json.dumps(out, indent=1))
 if len(sys.argv) > 1:
     os.makedirs(os.path.dirname(os.path.abspath(sys.argv[1])), exist_ok=True)
