@@ -49,6 +49,10 @@ __device__ inline uint32_t wave_get(uint32_t v, int src) { return (uint32_t)__bu
 #ifndef DEMC_LR_PREFETCH
 #define DEMC_LR_PREFETCH 1  // blocks requested ahead of the one being worked on in the span loops
 #endif
+// (Tried and dropped, round 3: theta' parked in the handle's proposal buffer instead of LDS, so that the register file and
+// not two 80 KB rows of LDS sets the occupancy -- 'k_longrow<256, GS>'.  Whole cfg4, per launch: LDS form 0.174 ms; global
+// scratch at the same two workgroups per CU 0.191; at three (168 VGPRs, 44 spilled) 0.202; at four (128 VGPRs, 88 spilled)
+// 0.219.  More workgroups in flight make the launch SLOWER: the phase is not waiting for latency that more waves could hide.)
 template <int WG>
 __global__ __launch_bounds__(WG, 512 / WG) void k_longrow(KParams p) {
     extern __shared__ double lds[];  // theta' of the particle [D (+1 if odd)] | cumulative pool weights [pool_n + chunks], the
@@ -860,8 +864,14 @@ __global__ __launch_bounds__(WG, 512 / WG) void k_longrow(KParams p) {
             const int k = pair_at(it);
             const int j0 = 2 * k;
             const bool has1 = j0 + 1 < D;
+            const bool noted = it < 64 && !((lbits >> (it >> 1)) & 1u);  // (wbits covers the rounds this lane went through itself)
+            const bool in_block = noted ? ((wbits >> it) & 1ull) != 0 : (!p.mask || p.mask[j0] || (has1 && p.mask[j0 + 1]));
+            // the pair's accepted value comes from the LDS copy; outside the block of a crossover sweep it is the current row's,
+            // and where neither the state nor the history row wants the pair it is not touched at all
+            const bool parked = acc && (!masked || in_block);
+            if (!parked && !hrow) continue;  // nothing to write for this pair
             double v0, v1;
-            if (acc) {
+            if (parked) {
                 if (even) {
                     const double2 v = *reinterpret_cast<const double2*>(scr + j0);
                     v0 = v.x; v1 = v.y;
@@ -873,8 +883,6 @@ __global__ __launch_bounds__(WG, 512 / WG) void k_longrow(KParams p) {
                 v0 = pt[j0];
                 v1 = has1 ? pt[j0 + 1] : 0.0;
             }
-            const bool noted = it < 64 && !((lbits >> (it >> 1)) & 1u);  // (wbits covers the rounds this lane went through itself)
-            const bool in_block = noted ? ((wbits >> it) & 1ull) != 0 : (!p.mask || p.mask[j0] || (has1 && p.mask[j0 + 1]));
             const bool wr = acc && (!masked || in_block);
             if (even) {
                 if (wr) *reinterpret_cast<double2*>(trow + j0) = make_double2(v0, v1);  // utilities.jl:204

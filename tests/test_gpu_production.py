@@ -90,6 +90,20 @@ def test_cfg4_shape_long_row_span_loops(demc, orc, wg, G, Np):
     free_run(demc, orc, w, 6, [f"k_longrow<{wg}>"], G, Np, theta_exact=False)
 
 
+@pytest.mark.parametrize("extra", [dict(theta_snooker=0.3), dict(kappa=0.8), dict(beta=0.5), dict(theta_snooker=0.3, kappa=0.7, beta=0.3),
+                                   dict(masks=None), dict(S=2101)])
+def test_long_row_kernel_every_sweep_kind_trace_free(demc, orc, extra):
+    """k_longrow<256> WITHOUT the trace (the form that ships) through snooker sweeps (moving and frozen spans), recombination
+    (the general per-pair body), mutation-heavy runs, an unblocked row and an odd row length (no span loops at all) --
+    history against the oracle, free-running"""
+    from demc_amd import workloads as W
+    extra = dict(extra)
+    w = W.cfg4(S=extra.pop("S", 2100), G=40, Np=32)
+    if "masks" in extra:
+        w["masks"] = extra.pop("masks")
+    free_run(demc, orc, w, 5, ["k_longrow<256>"], 40, 32, theta_exact=False, **extra)
+
+
 def test_cfg5_shape_lba_thread_per_proposal(demc, orc):
     """LBA, 3 accumulators, snooker 0.1 (Examples/Run_LBA.jl), N = 500 simulated trials: K1 -> k_obs_loglike (Phi / phi
     tables in LDS) -> k_accept_store.  LBA log-densities at 1e-5 (survival factors formed by cancellation, see

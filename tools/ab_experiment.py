@@ -24,6 +24,9 @@ for v in values:
     env.pop(var, None)
     if v != "" and var != "LIB":
         env[var] = v
+    for kv in os.environ.get("AB_ENV", "").split():  # extra switches for every run, e.g. AB_ENV="DEMC_LR_GS=1"
+        k, _, val = kv.partition("=")
+        env[k] = val
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     note = [ln for ln in out.stderr.splitlines() if "chunks chosen" in ln or "experiment" in ln][:1]
