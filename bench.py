@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--nobs", type=int, default=None, help="observations / subjects / trials (default: the config's)")
     ap.add_argument("--dim", type=int, default=None, help="data dimension of cfg2 / cfg3")
     ap.add_argument("--burnin", type=int, default=1000, help="DE burnin (reference default 1000)")
+    ap.add_argument("--snooker", type=float, default=None, help="override theta_snooker (crossover.jl:31; the reference's multivariate "
+                                                                 "and hierarchical examples use 0.1): runs the snooker instances of the kernels")
     ap.add_argument("--fuse", type=int, default=0, help="demc_config.fuse (0 auto, 1 never, 2 per phase)")
     ap.add_argument("--accuracy-iters", type=int, default=1500, help="length of the untimed accuracy leg (0: skip)")
     ap.add_argument("--async-migration", action="store_true",
@@ -100,7 +102,10 @@ def build_workload(a):
             kw["S"] = a.nobs
     elif a.nobs is not None:
         kw["N"] = a.nobs
-    return W.BUILDERS[a.config](**kw)
+    w = W.BUILDERS[a.config](**kw)
+    if a.snooker is not None:
+        w["engine"] = dict(w["engine"], theta_snooker=a.snooker)
+    return w
 
 
 def describe(a, w, world):
@@ -110,7 +115,7 @@ def describe(a, w, world):
                 f"defaults, schedule={a.schedule} (BASELINE's CPU plumbing config, here on the GPU: 40 particles cannot fill one CU)")
     if a.config in ("cfg2", "cfg3"):
         return (f"{a.config}: MvNormal full-Sigma D={D}, N={w['dims'][0]} obs, n_groups={G}x{world}, Np={Np}, sampler defaults, "
-                f"schedule={a.schedule}, loglike={a.mode}")
+                f"schedule={a.schedule}, loglike={a.mode}" + ("" if a.snooker is None else f", theta_snooker={a.snooker:g}"))
     if a.config == "cfg4":
         return (f"cfg4: hierarchical Binomial (Hierarchical_Example.jl shape), S={w['dims'][0]} subjects, D={D}, blocks [hyper; subject], "
                 f"n_groups={G}x{world} (BASELINE: 128 groups over 8 GPUs), Np={Np}, schedule={a.schedule}")
@@ -138,6 +143,12 @@ def profile_is_current(rec_file):
         return False
 
 
+def variant_tag(a):
+    """file-name suffix of a profiled flag variant (tools/collect_profiles.py names them the same way)"""
+    tag = "" if a.n_groups is None else f"_n-groups{a.n_groups}"
+    return tag + ("" if a.snooker is None else f"_snooker{a.snooker:g}")
+
+
 def measured_traffic(a, launches, k_iters):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
     (profiles/<round>/bench_<config>_<mode>_pmc.json, written by tools/collect_profiles.py: FETCH_SIZE and WRITE_SIZE in
@@ -146,7 +157,7 @@ def measured_traffic(a, launches, k_iters):
     Only for shapes that were profiled (the config's default, or an --n-groups variant with a committed summary); otherwise None.  NOT measured in the run that prints it (see traffic_source)."""
     if a.Np is not None or a.nobs is not None or a.dim is not None or a.schedule != "two_colour" or a.fuse:
         return None, None
-    variant = "" if a.n_groups is None else f"_n-groups{a.n_groups}"  # (tools/collect_profiles.py names flag variants so)
+    variant = variant_tag(a)  # (tools/collect_profiles.py names flag variants so)
     for rnd in (PROFILE_ROUND,):
         path = os.path.join(ROOT, "profiles", rnd, f"bench_{a.config}_{a.mode}{variant}_pmc.json")
         try:

@@ -549,15 +549,16 @@ bool is_mvn(int fam) { return fam == FAM_MVN_FULL || fam == FAM_MVN_ISO; }
 
 // the K1 instance for (tile in LDS?, fused tail)
 using K1Fn = void (*)(KParams);
-K1Fn k1_instance(bool tile, int tail, bool plain, int wg = 256) {
-#define K1_ROW(WG_, TILE, RES_, PLAIN_)                                                                              \
-    {k_propose<WG_, TILE, TAIL_NONE, RES_, PLAIN_>, k_propose<WG_, TILE, TAIL_PREP, RES_, PLAIN_>,                   \
-     k_propose<WG_, TILE, TAIL_PREP_MFMA, RES_, PLAIN_>, k_propose<WG_, TILE, TAIL_OBS, RES_, PLAIN_>}
-    static const K1Fn tab[4][4] = {K1_ROW(256, false, false, false), K1_ROW(256, true, false, false), K1_ROW(256, true, false, true),
-                                   K1_ROW(512, false, false, false)};
+// `lean`: 0 the general instance, 1 the default sampler only, 2 the default sampler + snooker (k_propose's LEAN)
+K1Fn k1_instance(bool tile, int tail, int lean, int wg = 256) {
+#define K1_ROW(WG_, TILE, RES_, LEAN_)                                                                              \
+    {k_propose<WG_, TILE, TAIL_NONE, RES_, LEAN_>, k_propose<WG_, TILE, TAIL_PREP, RES_, LEAN_>,                   \
+     k_propose<WG_, TILE, TAIL_PREP_MFMA, RES_, LEAN_>, k_propose<WG_, TILE, TAIL_OBS, RES_, LEAN_>}
+    static const K1Fn tab[5][4] = {K1_ROW(256, false, false, 0), K1_ROW(256, true, false, 0), K1_ROW(256, true, false, 1),
+                                   K1_ROW(512, false, false, 0), K1_ROW(256, true, false, 2)};
 #undef K1_ROW
     if (wg == 512) return tab[3][tail];  // a 512-thread workgroup per particle (very long rows, no tile)
-    return tab[tile ? (plain ? 2 : 1) : 0][tail];  // the plain instance exists for the LDS-tile forms only
+    return tab[tile ? (lean == 1 ? 2 : lean == 2 ? 4 : 1) : 0][tail];  // the lean instances exist for the LDS-tile forms only
 }
 
 // which tail K1 carries for this model, mode and schedule
@@ -586,11 +587,13 @@ void set_tail_flags(demc_handle* h, KParams& k) {
     k.write_prop = (!k.fuse_accept || k.trace) ? 1 : 0;
 }
 // the default sampler and nothing else: K1 has an instance with every other branch compiled out
-bool is_plain(const demc_handle* h, const KParams& k) {
+int lean_level(const demc_handle* h, const KParams& k) {
     const demc_config& c = h->c;
-    return k.mode == MODE_STEP && c.proposal_kind == 0 && c.partner_kind == DEMC_PARTNER_CURRENT && c.update_kind == 0 &&
-           c.fitness_kind == 0 && c.theta_snooker == 0.0 && c.kappa == 1.0 && c.n_blocks == 0 && !k.trace && !h->rp_active;
+    const bool base = k.mode == MODE_STEP && c.proposal_kind == 0 && c.partner_kind == DEMC_PARTNER_CURRENT && c.update_kind == 0 &&
+                      c.fitness_kind == 0 && c.kappa == 1.0 && c.n_blocks == 0 && !k.trace && !h->rp_active;
+    return !base ? 0 : c.theta_snooker == 0.0 ? 1 : 2;  // + snooker updates: their own lean instance
 }
+bool is_plain(const demc_handle* h, const KParams& k) { return lean_level(h, k) == 1; }
 int tail_of(const KParams& k) { return k.prep_mfma ? TAIL_PREP_MFMA : k.fuse_prep ? TAIL_PREP : k.fuse_obs ? TAIL_OBS : TAIL_NONE; }
 
 int launch_phase(demc_handle* h, KParams& k) {
@@ -649,10 +652,10 @@ int launch_phase(demc_handle* h, KParams& k) {
     tick(h, 0, true);
     const int tail = tail_of(k);
     const size_t lds = tile ? lds_tile + (k.plan ? plan_bytes : 0) : h->k1_lds - h->k1_tile_bytes;
-    const bool plain = is_plain(h, k);
+    const int lean = (tile && wg == 256) ? lean_level(h, k) : 0;
     h->last = demc_handle::LastPlan();
-    h->last.k1 = 0; h->last.wg = wg; h->last.tile = tile; h->last.tail = tail; h->last.plain = plain && tile && wg == 256;
-    LAUNCH_T(h, k1_instance(tile, tail, plain, wg), dim3(k.n_groups * n_split), dim3(wg), lds, k);
+    h->last.k1 = 0; h->last.wg = wg; h->last.tile = tile; h->last.tail = tail; h->last.plain = lean;
+    LAUNCH_T(h, k1_instance(tile, tail, lean, wg), dim3(k.n_groups * n_split), dim3(wg), lds, k);
     tick(h, 0, false);
     if (k.fuse_accept) return DEMC_OK;
     int rc = launch_loglike(h, k);
@@ -665,13 +668,13 @@ int launch_phase(demc_handle* h, KParams& k) {
 }
 
 // ---- resident form of K1: one workgroup per group, both colour phases of several iterations in one launch ----
-K1Fn k1_resident_instance(int wg, int tail, bool plain) {
-#define K1_ROW(WG_, PLAIN_)                                                                                      \
-    {k_propose<WG_, true, TAIL_NONE, true, PLAIN_>, k_propose<WG_, true, TAIL_PREP, true, PLAIN_>,               \
-     k_propose<WG_, true, TAIL_PREP_MFMA, true, PLAIN_>, k_propose<WG_, true, TAIL_OBS, true, PLAIN_>}
-    static const K1Fn tab[4][4] = {K1_ROW(256, false), K1_ROW(512, false), K1_ROW(256, true), K1_ROW(512, true)};
+K1Fn k1_resident_instance(int wg, int tail, int lean) {
+#define K1_ROW(WG_, LEAN_)                                                                                      \
+    {k_propose<WG_, true, TAIL_NONE, true, LEAN_>, k_propose<WG_, true, TAIL_PREP, true, LEAN_>,               \
+     k_propose<WG_, true, TAIL_PREP_MFMA, true, LEAN_>, k_propose<WG_, true, TAIL_OBS, true, LEAN_>}
+    static const K1Fn tab[6][4] = {K1_ROW(256, 0), K1_ROW(512, 0), K1_ROW(256, 1), K1_ROW(512, 1), K1_ROW(256, 2), K1_ROW(512, 2)};
 #undef K1_ROW
-    return tab[(wg == 512 ? 1 : 0) + (plain ? 2 : 0)][tail];
+    return tab[(wg == 512 ? 1 : 0) + 2 * lean][tail];
 }
 
 // Decides once per model whether the resident form applies and with which geometry (lanes per particle, workgroup size,
@@ -728,9 +731,9 @@ int launch_resident(demc_handle* h, long long iter0, int n_iters) {
     k.plan = (k.lpp >= 4) ? 1 : 0;
     if (const char* e = experiment("DEMC_K1_PLAN")) k.plan = k.plan && e[0] == '1';  // A/B experiments
     h->last = demc_handle::LastPlan();
-    h->last.k1 = 2; h->last.wg = h->res_wg; h->last.tile = 1; h->last.tail = tail_of(k); h->last.plain = is_plain(h, k);
+    h->last.k1 = 2; h->last.wg = h->res_wg; h->last.tile = 1; h->last.tail = tail_of(k); h->last.plain = lean_level(h, k);
     tick(h, 0, true);
-    LAUNCH_T(h, k1_resident_instance(h->res_wg, tail_of(k), is_plain(h, k)), dim3(k.n_groups), dim3(h->res_wg), h->res_lds,
+    LAUNCH_T(h, k1_resident_instance(h->res_wg, tail_of(k), lean_level(h, k)), dim3(k.n_groups), dim3(h->res_wg), h->res_lds,
                        k);
     tick(h, 0, false);
     return DEMC_OK;
@@ -806,13 +809,15 @@ int launch_lean(demc_handle* h, long long iter0, int n_iters, bool stream) {
 // ---- streaming-resident form: resident K1 with the observation stream inside (k_propose<..., STREAM>) ----
 // 256-thread form: one wave per SIMD, i.e. the whole register file (512 per lane, AGPRs included) behind each wave -- what does
 // not fit the 256 architectural VGPRs spills to AGPRs instead of scratch memory; 512 threads when a colour needs the lanes.
-K1Fn k1_stream_instance(int wg, int tail, bool plain) {
-    static const K1Fn tab[2][2][2] = {
-        {{k_propose<256, true, TAIL_PREP, true, false, true>, k_propose<256, true, TAIL_PREP_MFMA, true, false, true>},
-         {k_propose<256, true, TAIL_PREP, true, true, true>, k_propose<256, true, TAIL_PREP_MFMA, true, true, true>}},
-        {{k_propose<512, true, TAIL_PREP, true, false, true>, k_propose<512, true, TAIL_PREP_MFMA, true, false, true>},
-         {k_propose<512, true, TAIL_PREP, true, true, true>, k_propose<512, true, TAIL_PREP_MFMA, true, true, true>}}};
-    return tab[wg == 512 ? 1 : 0][plain ? 1 : 0][tail == TAIL_PREP_MFMA ? 1 : 0];
+K1Fn k1_stream_instance(int wg, int tail, int lean) {
+    static const K1Fn tab[2][3][2] = {
+        {{k_propose<256, true, TAIL_PREP, true, 0, true>, k_propose<256, true, TAIL_PREP_MFMA, true, 0, true>},
+         {k_propose<256, true, TAIL_PREP, true, 1, true>, k_propose<256, true, TAIL_PREP_MFMA, true, 1, true>},
+         {k_propose<256, true, TAIL_PREP, true, 2, true>, k_propose<256, true, TAIL_PREP_MFMA, true, 2, true>}},
+        {{k_propose<512, true, TAIL_PREP, true, 0, true>, k_propose<512, true, TAIL_PREP_MFMA, true, 0, true>},
+         {k_propose<512, true, TAIL_PREP, true, 1, true>, k_propose<512, true, TAIL_PREP_MFMA, true, 1, true>},
+         {k_propose<512, true, TAIL_PREP, true, 2, true>, k_propose<512, true, TAIL_PREP_MFMA, true, 2, true>}}};
+    return tab[wg == 512 ? 1 : 0][lean][tail == TAIL_PREP_MFMA ? 1 : 0];
 }
 
 // Decides once per model whether the streaming-resident form applies.  It is for populations too small to fill the chip
@@ -886,8 +891,8 @@ int launch_stream(demc_handle* h, long long iter0, int n_iters) {
     // takes most of a CU's LDS) -- so a plain launch has the same residency as a cooperative one, without its launch-time
     // cost (+15-19 us, MI355X_MICROARCH.md "coop-launch"); every spin in the kernel is bounded regardless.
     h->last = demc_handle::LastPlan();
-    h->last.k1 = 3; h->last.wg = h->st_wg; h->last.tile = 1; h->last.tail = tail_of(k); h->last.plain = is_plain(h, k); h->last.stream = 1;
-    LAUNCH_T(h, k1_stream_instance(h->st_wg, tail_of(k), is_plain(h, k)), dim3(c.n_groups * h->st_C), dim3(h->st_wg), h->st_lds,
+    h->last.k1 = 3; h->last.wg = h->st_wg; h->last.tile = 1; h->last.tail = tail_of(k); h->last.plain = lean_level(h, k); h->last.stream = 1;
+    LAUNCH_T(h, k1_stream_instance(h->st_wg, tail_of(k), lean_level(h, k)), dim3(c.n_groups * h->st_C), dim3(h->st_wg), h->st_lds,
                        k);
     const hipError_t e = hipGetLastError();
     tick(h, 0, false);
@@ -978,18 +983,18 @@ int size_k1_lds(demc_handle* h) {
     // sizes in one process do not lower each other's limit
     for (int t = 0; t < 2; ++t)
         for (int tail = 0; tail < 4; ++tail)
-            for (int plain = 0; plain < 2; ++plain) {
-                HIPCHK(hipFuncSetAttribute((const void*)k1_instance(t != 0, tail, plain != 0),
+            for (int lean = 0; lean < 3; ++lean) {
+                HIPCHK(hipFuncSetAttribute((const void*)k1_instance(t != 0, tail, lean),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
-                HIPCHK(hipFuncSetAttribute((const void*)k1_resident_instance(t ? 512 : 256, tail, plain != 0),
+                HIPCHK(hipFuncSetAttribute((const void*)k1_resident_instance(t ? 512 : 256, tail, lean),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
-                HIPCHK(hipFuncSetAttribute((const void*)k1_instance(false, tail, false, 512),
+                HIPCHK(hipFuncSetAttribute((const void*)k1_instance(false, tail, 0, 512),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
             }
     for (int wgs = 256; wgs <= 512; wgs += 256)
         for (int tail = 1; tail <= 2; ++tail)
-            for (int plain = 0; plain < 2; ++plain)
-                HIPCHK(hipFuncSetAttribute((const void*)k1_stream_instance(wgs, tail, plain != 0),
+            for (int lean = 0; lean < 3; ++lean)
+                HIPCHK(hipFuncSetAttribute((const void*)k1_stream_instance(wgs, tail, lean),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
     HIPCHK(hipFuncSetAttribute((const void*)k_longrow<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
     HIPCHK(hipFuncSetAttribute((const void*)k_longrow<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
@@ -2368,17 +2373,17 @@ int32_t demc_last_kernels(demc_handle* h, char* out, int32_t nbytes) {
     static const char* const tails[4] = {"TAIL_NONE", "TAIL_PREP", "TAIL_PREP_MFMA", "TAIL_OBS"};
     char buf[256];
     buf[0] = '\0';
-    const char* tf[2] = {"false", "true"};
+    const char* tf[3] = {"false", "true", "2"};  // (the LEAN level: 0 general, 1 plain, 2 plain + snooker)
     switch (L.k1) {
         case 0:
-            std::snprintf(buf, sizeof buf, "k_propose<%d,%s,%s,false,%s>", L.wg, tf[L.tile != 0], tails[L.tail & 3], tf[L.plain != 0]);
+            std::snprintf(buf, sizeof buf, "k_propose<%d,%s,%s,false,%s>", L.wg, tf[L.tile != 0], tails[L.tail & 3], tf[L.plain]);
             break;
         case 1: std::snprintf(buf, sizeof buf, "k_longrow<%d>", L.wg); break;
         case 2:
-            std::snprintf(buf, sizeof buf, "k_propose<%d,true,%s,true,%s>", L.wg, tails[L.tail & 3], tf[L.plain != 0]);
+            std::snprintf(buf, sizeof buf, "k_propose<%d,true,%s,true,%s>", L.wg, tails[L.tail & 3], tf[L.plain]);
             break;
         case 3:
-            std::snprintf(buf, sizeof buf, "k_propose<%d,true,%s,true,%s,true>", L.wg, tails[L.tail & 3], tf[L.plain != 0]);
+            std::snprintf(buf, sizeof buf, "k_propose<%d,true,%s,true,%s,true>", L.wg, tails[L.tail & 3], tf[L.plain]);
             break;
         case 4: std::snprintf(buf, sizeof buf, "k_res_mvn<%d,%s,%d>", L.wg, tf[L.stream != 0], L.dt); break;
         default: break;

@@ -724,8 +724,13 @@ enum K1Tail : int { TAIL_NONE = 0, TAIL_PREP = 1, TAIL_PREP_MFMA = 2, TAIL_OBS =
 // same fixed order, and every one then makes the same accept decisions and keeps its LDS copy of the group current;
 // workgroup 0 of the group writes HBM (state, weights, history).  Every proposal still visits every observation, as the
 // reference's loglike does; what disappears is the K1 -> K2 -> K3 launch chain per colour phase.
-template <int WG, bool TILE, int TAIL, bool RES, bool PLAIN, bool STREAM = false>
+template <int WG, bool TILE, int TAIL, bool RES, int LEAN, bool STREAM = false>
 __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(KParams p0) {
+    // LEAN 0: every option of the sampler.  LEAN 1 ("plain"): the default sampler and nothing else.  LEAN 2: the default sampler
+    // plus snooker updates (theta_snooker > 0: the reference's multivariate, hierarchical and LBA examples) -- replay, block
+    // masks, recombination, the optimiser's updates, the other proposal kinds and the trace compiled out as in LEAN 1.
+    constexpr bool PLAIN = LEAN != 0;  // none of the general options
+    constexpr bool SNK = LEAN != 1;    // snooker branches compiled in
     constexpr bool FUSE_PREP = TAIL == TAIL_PREP || TAIL == TAIL_PREP_MFMA;
     constexpr bool PREP_MFMA = TAIL == TAIL_PREP_MFMA;
     constexpr bool FUSE_OBS = TAIL == TAIL_OBS;
@@ -1014,7 +1019,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
                      ra = bcast_u4<3>(mine, 4, 0);
             const double u_snk = u53(r0.x, r0.y), u_base = u53(r0.z, r0.w);
             const double u_g1 = u53(rg.x, rg.y), u_g2 = u53(rg.z, rg.w);
-            const bool snooker = !PLAIN && u_snk <= p.theta_snooker;  // crossover.jl:31
+            const bool snooker = SNK && u_snk <= p.theta_snooker;  // crossover.jl:31
             int i0, i1, i2 = -1;
             double g1, g2 = 0.0;
             if (snooker) {
@@ -1205,7 +1210,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
             i0 = plan_i[4 * ql + 1]; i1 = plan_i[4 * ql + 2]; i2 = plan_i[4 * ql + 3];
             g1 = plan_d[4 * ql + 0]; g2 = plan_d[4 * ql + 1]; u_acc = plan_d[4 * ql + 2];
             Pa = rows + (size_t)i0 * D; Pb2 = rows + (size_t)i1 * D;
-            if (!PLAIN && kind == 1) {
+            if (SNK && kind == 1) {
                 Pc = rows + (size_t)i2 * D;
                 // project(Pm,Pd), project(Pn,Pd): dots over all scalars (utilities.jl:239-246)
                 double vm = 0.0, vn = 0.0, vd = 0.0;
@@ -1235,7 +1240,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
                     u_g1 = replayed(p.rp_part, slot * 5 + 2, u_g1);
                     u_g2 = replayed(p.rp_part, slot * 5 + 3, u_g2);
                 }
-                const bool snooker = !PLAIN && u_snk <= p.theta_snooker;  // crossover.jl:31
+                const bool snooker = SNK && u_snk <= p.theta_snooker;  // crossover.jl:31
                 kind = snooker ? 1 : 0;
                 if (hist_partners) {
                     // resample (crossover.jl:113-124): distinct cells of rows 1:(iter-1) x local particles
@@ -1332,7 +1337,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
         // crossover / snooker value of scalar j given its uniform (before recombination! / reset!)
         auto cross = [&](int j, double tj, double uu) -> double {
             const double bj = -eps + eps2 * uu;  // b = Uniform(-eps, eps) crossover.jl:166
-            if (!PLAIN && kind == 1) {  // (Pt + gamma*(Pr1 - Pr2)) + b  crossover.jl:253
+            if (SNK && kind == 1) {  // (Pt + gamma*(Pr1 - Pr2)) + b  crossover.jl:253
                 const double dj = tj - Pa[j];
                 const double t1 = dj * cm - dj * cn;
                 return (tj + t1 * g1) + bj;
@@ -1432,7 +1437,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
             }
             double v0, v1;
             value_pair(k, v0, v1);
-            if (!PLAIN && kind == 1) {  // adjust_loglike norms (crossover.jl:268-273)
+            if (SNK && kind == 1) {  // adjust_loglike norms (crossover.jl:268-273)
                 const double a0 = v0 - Pa[j0], b0 = pt[j0] - Pa[j0];
                 s1 += a0 * a0; s2 += b0 * b0;
                 if (has1) {
@@ -1474,7 +1479,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
         prior = group_sum(prior, lpp, s_gsum);
         oob = group_sum(oob, lpp, s_gsumi);
         double adj = 0.0;
-        if (!PLAIN && kind == 1) {  // (d-1)(log|a| - log|b|): stable form of log(|a|^(d-1)/|b|^(d-1))  crossover.jl:268-273
+        if (SNK && kind == 1) {  // (d-1)(log|a| - log|b|): stable form of log(|a|^(d-1)/|b|^(d-1))  crossover.jl:268-273
             s1 = group_sum(s1, lpp, s_gsum);
             s2 = group_sum(s2, lpp, s_gsum);
             adj = (double)(D - 1) * (0.5 * log(s1) - 0.5 * log(s2));

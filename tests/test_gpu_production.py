@@ -208,3 +208,26 @@ def test_the_three_likelihood_modes_make_the_same_decisions(demc):
         assert np.array_equal(outs[0][1], other[1]) and np.array_equal(outs[0][3], other[3])
         assert np.array_equal(outs[0][0], other[0])
         np.testing.assert_allclose(outs[0][2], other[2], rtol=1e-10)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# LEAN 2: the default sampler + snooker updates (theta_snooker > 0: test/multivariate_normal_tests.jl:58,
+# Examples/Hierarchical_Example.jl:112, Examples/Run_LBA.jl) has kernel instances of its own -- replay, block masks,
+# recombination, optimiser updates, the other proposal kinds and the trace compiled out, the snooker branches in
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", ["cfg1_resident", "cfg2_suffstat_resident", "cfg2_streaming_resident", "cfg3_chain", "cfg5_chain"])
+def test_snooker_lean_instances_match_the_oracle(demc, orc, shape):
+    from demc_amd import workloads as W
+    if shape == "cfg1_resident":      # Gaussian example, the whole update in the resident kernel's own observation loop
+        w, G, Np, kern, kw = W.cfg1(), 8, 10, "k_propose<256,true,TAIL_OBS,true,2>", {}
+    elif shape == "cfg2_suffstat_resident":
+        w, G, Np, kern, kw = W.cfg2(N=3000), 32, 64, "k_propose<256,true,TAIL_PREP_MFMA,true,2>", dict(loglike_mode=1)
+    elif shape == "cfg2_streaming_resident":
+        w, G, Np, kern, kw = W.cfg2(N=3000), 32, 64, "k_propose<256,true,TAIL_PREP_MFMA,true,2,true>", dict(loglike_mode=0)
+    elif shape == "cfg3_chain":
+        w, G, Np, kern, kw = W.cfg3(N=1500, G=16), 16, 256, "k_propose<256,true,TAIL_PREP_MFMA,false,2>", dict(loglike_mode=0, fuse=2, geometry_groups=256)
+    else:
+        w, G, Np, kern, kw = W.cfg5(N=400, G=8, Np=16), 8, 16, "k_propose<256,true,TAIL_NONE,false,2>", {}
+    ran = free_run(demc, orc, w, 8, [kern], G, Np, theta_exact=False, theta_snooker=0.3,
+                   lp_rtol=1e-5 if shape == "cfg5_chain" else 1e-9, **kw)
+    assert "k_res_mvn" not in ran

@@ -118,10 +118,10 @@ def main():
                 e[ctr + "_KB_total"] = sum(v)
                 e["launches_total"] = len(v)
                 totals[short(kname)] += (2.0 if ctr == "FETCH_SIZE" else 1.0) * sum(v) * 1024.0
-        dom = dominant_kernel(totals, DOMINANT[(cfg, mode)], resident=True)
+        dom = dominant_kernel(totals, DOMINANT.get((cfg, mode), "k_res_mvn|k_propose<"), resident=True)
         if dom:
             e = res[dom]
-            resident = "k_propose<" in DOMINANT[(cfg, mode)]
+            resident = "k_propose<" in DOMINANT.get((cfg, mode), "k_res_mvn|k_propose<")
             rec = {"kernel": dom, "note": "HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 half-count of wide streaming reads)"}
             if resident:  # a launch covers several iterations: reduce to bytes per iteration over the whole run
                 rec["bytes_per_iteration"] = totals[dom] / (STEPS + WARMUP)
