@@ -561,6 +561,8 @@ __global__ __launch_bounds__(WG, 512 / WG) void k_longrow(KParams p) {
         auto load = [&](int m) -> Blk {
             Blk r;
             const size_t o = 4 * (size_t)m;
+            // (the own row is read by this workgroup alone, once -- but loading it non-temporally, so that it would not push the
+            // partner rows out of L2, made the whole cfg4 9 % SLOWER; non-temporal history stores changed nothing)
             r.t0 = *reinterpret_cast<const double2*>(pt + o);
             r.t1 = *reinterpret_cast<const double2*>(pt + o + 2);
             if constexpr (HB) {  // scalar 2 + s belongs to subject s

@@ -33,7 +33,8 @@ def _run_single(D, prob, G, Np, n_it, th0, **kw):
     return out
 
 
-@pytest.mark.parametrize("family,kw", [("mvn_full", dict(loglike_mode=1)), ("gaussian", dict()), ("hier_binomial", dict())])
+@pytest.mark.parametrize("family,kw", [("mvn_full", dict(loglike_mode=1)), ("mvn_full", dict(loglike_mode=0)), ("gaussian", dict()),
+                                       ("hier_binomial", dict())])
 def test_library_communicator_at_world_one_equals_demc_step(D, family, kw):
     """demc_comm_unique_id -> demc_comm_init -> demc_step: pack -> ncclAllGather on the handle's stream -> apply, through
     the C-ABI alone (no torch.distributed anywhere), reproduces demc_step's on-device migration bit for bit; so does the
@@ -64,7 +65,13 @@ def test_library_communicator_at_world_one_equals_demc_step(D, family, kw):
         e.comm_destroy()
         e.close()
         for i, (x, y) in enumerate(zip(ref, out)):
-            assert np.array_equal(x, y), f"{form}: array {i}"
+            if form == "overlap" and kw.get("loglike_mode") == 0 and i in (2, 5):
+                # STREAMING on a small population: demc_step runs the streaming-resident form, the subset updates of the
+                # overlapped exchange the K1 -> K2 -> K3 chain -- the observation sums are split differently (log-densities
+                # to rounding, every draw and decision identical; include/demc.h, demc_comm_set_overlap)
+                np.testing.assert_allclose(x, y, rtol=1e-10)
+            else:
+                assert np.array_equal(x, y), f"{form}: array {i}"
 
 
 def test_communicator_shape_is_checked_and_a_sharded_step_needs_one(D):
