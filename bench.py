@@ -44,7 +44,8 @@ def parse():
                          "O(D^2) per proposal; direct = the residual form sum_i |L^-1(x_i - mu)|^2 term by term on the FP64 vector pipe")
     ap.add_argument("--schedule", default="two_colour", choices=["two_colour", "synchronous"])
     ap.add_argument("--n-groups", type=int, default=None, help="groups per GPU (default: the config's)")
-    ap.add_argument("--np", type=int, default=None, dest="Np")
+    ap.add_argument("--np", "--particles-per-group", type=int, default=None, dest="Np",
+                    help="(under torch.distributed.run spell it --particles-per-group: the launcher's parser claims --np as an abbreviation)")
     ap.add_argument("--nobs", type=int, default=None, help="observations / subjects / trials (default: the config's)")
     ap.add_argument("--dim", type=int, default=None, help="data dimension of cfg2 / cfg3")
     ap.add_argument("--burnin", type=int, default=1000, help="DE burnin (reference default 1000)")
@@ -438,6 +439,25 @@ def cpu_baseline(a, w, seconds_target=14.0):
                        f"proposal visits every observation; gcc -O3 -march=native -fopenmp")
 
 
+def control_plane_store(rank, world):
+    """Control plane of the library collective = the launcher's key-value store and nothing else: it carries the
+    communicator id from rank 0 to the others (no process group is created).  Under torch.distributed.run the agent
+    hosts the store at MASTER_ADDR:MASTER_PORT and every rank is a client; started bare (spawn_ranks) rank 0 hosts it."""
+    from datetime import timedelta
+    from torch.distributed import TCPStore
+    agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"
+    return TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, is_master=(rank == 0 and not agent),
+                    timeout=timedelta(seconds=600))
+
+
+def exchange_comm_id(store, rank, make_id):
+    """rank 0 draws the id (make_id() -> 128 bytes, demc_comm_unique_id) and publishes it; everybody reads it back"""
+    key = "demc/comm_id/" + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+    if rank == 0:
+        store.set(key, make_id())
+    return bytes(store.get(key))
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -469,13 +489,7 @@ def main():
         dist_.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         dist = dist_
     elif library:
-        # Control plane = the launcher's key-value store and nothing else: it carries the communicator id from rank 0 to the
-        # others.  (Under torch.distributed.run the agent hosts the store; started bare, rank 0 does.)  No process group.
-        from datetime import timedelta
-        from torch.distributed import TCPStore
-        agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"
-        store = TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, is_master=(rank == 0 and not agent),
-                         timeout=timedelta(seconds=600))
+        store = control_plane_store(rank, world)
 
     w = build_workload(a)
     G, Np, D = w["G"], w["Np"], w["D"]
@@ -488,10 +502,7 @@ def main():
     eng.set_state(w["init"](P, np.random.default_rng(20260003 + rank)))
     if library:
         # the whole sharded iteration behind the C-ABI: demc_step on a handle that owns its RCCL communicator
-        key = "demc/comm_id/" + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
-        if rank == 0:
-            store.set(key, eng.comm_unique_id())
-        eng.comm_init(store.get(key), rank, world)
+        eng.comm_init(exchange_comm_id(store, rank, eng.comm_unique_id), rank, world)
         eng.comm_set_overlap(a.async_migration)
         step = eng.step_enqueue
     else:

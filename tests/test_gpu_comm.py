@@ -172,3 +172,24 @@ def test_plain_c_multi_rank_driver(tmp_path):
         out = subprocess.run([exe, "--ranks", "1"] + extra, env=env, capture_output=True, text=True, timeout=180)
         assert out.returncode == 0, out.stdout + out.stderr
         assert "C-ABI multi-rank driver OK" in out.stdout and "world 1" in out.stdout
+
+
+def test_bench_under_the_drivers_launcher_with_the_library_collective():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port P bench.py --gpus 1`
+    with DEMC_FORCE_DIST=1: the agent's store carries the communicator id, the engine's own RCCL communicator does the
+    exchanges (world 1 is all a 1-GPU box can run), barrier and max-over-ranks go through demc_comm_allreduce -- the JSON
+    line comes out with the collective named and all-gathers counted"""
+    import json
+    import socket
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, DEMC_FORCE_DIST="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "30", "--warmup", "10",
+                          "--n-groups", "16", "--nobs", "4000", "--dim", "8", "--accuracy-iters", "0", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, env=env)  # (no --np: the launcher's parser claims it as an abbreviation)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert "demc_comm_init" in r["config"]["collective"] and r["config"]["all_gathers_rank0"] >= 1 and r["n_gpus"] == 1

@@ -1,10 +1,14 @@
 """Host-side mirror of src/structs.jl / src/main.jl: constructor defaults and error behaviour, nested-Theta
 flattening, names, history re-keying and bundle_samples bookkeeping (test/utility_tests.jl "Discard Burnin").
 The engine is the CPU oracle INJECTED by the test (the product has no CPU path)."""
+import os
+import sys
 import warnings
 
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 import demc_amd as D
 from demc_amd import sampler as S
@@ -188,3 +192,52 @@ def test_bench_spawns_its_own_ranks_when_started_bare():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env2, capture_output=True,
                          text=True, timeout=300)
     assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr
+
+
+def _id_exchange_script():
+    return (
+        "import os, sys, hashlib\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "store = bench.control_plane_store(rank, world)\n"
+        "uid = bench.exchange_comm_id(store, rank, lambda: bytes(range(128)))\n"
+        "assert uid == bytes(range(128)), (rank, uid[:8])\n"
+        "store.set('done/%%d' %% rank, b'1')\n"
+        "[store.get('done/%%d' %% r) for r in range(world)]   # nobody leaves before everybody has the id (rank 0 may host the store)\n"
+        "print('rank', rank, 'of', world, 'got the id', hashlib.sha1(uid).hexdigest()[:8], flush=True)\n" % ROOT)
+
+
+def test_comm_id_travels_over_the_launchers_store_started_bare(tmp_path):
+    """bench.py --gpus N with the library collective: the 128-byte communicator id goes from rank 0 to the others through a
+    TCPStore that rank 0 hosts (spawn_ranks' environment) -- exercised here with two CPU processes and a stand-in id"""
+    import socket
+    import subprocess
+    script = tmp_path / "idx.py"
+    script.write_text(_id_exchange_script())
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1",
+                                                                     MASTER_PORT=str(port)), stdout=subprocess.PIPE, text=True)
+             for r in range(3)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("got the id" in o for o in outs)
+
+
+@pytest.mark.timeout(300)
+def test_comm_id_travels_over_the_agent_store_under_torch_distributed_run(tmp_path):
+    """the same under the driver's launcher (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P`): the agent hosts the store (TORCHELASTIC_USE_AGENT_STORE), every rank connects as a client"""
+    import socket
+    import subprocess
+    script = tmp_path / "idx.py"
+    script.write_text(_id_exchange_script())
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    assert out.stdout.count("got the id") == 2
