@@ -590,8 +590,8 @@ void set_tail_flags(demc_handle* h, KParams& k) {
 int lean_level(const demc_handle* h, const KParams& k) {
     const demc_config& c = h->c;
     const bool base = k.mode == MODE_STEP && c.proposal_kind == 0 && c.partner_kind == DEMC_PARTNER_CURRENT && c.update_kind == 0 &&
-                      c.fitness_kind == 0 && c.kappa == 1.0 && c.n_blocks == 0 && !k.trace && !h->rp_active;
-    return !base ? 0 : c.theta_snooker == 0.0 ? 1 : 2;  // + snooker updates: their own lean instance
+                      c.fitness_kind == 0 && c.kappa == 1.0 && !k.trace && !h->rp_active;
+    return !base ? 0 : (c.theta_snooker == 0.0 && c.n_blocks == 0) ? 1 : 2;  // + snooker / block updates: their own lean instance
 }
 bool is_plain(const demc_handle* h, const KParams& k) { return lean_level(h, k) == 1; }
 int tail_of(const KParams& k) { return k.prep_mfma ? TAIL_PREP_MFMA : k.fuse_prep ? TAIL_PREP : k.fuse_obs ? TAIL_OBS : TAIL_NONE; }

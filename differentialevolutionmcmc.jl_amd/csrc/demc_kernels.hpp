@@ -727,10 +727,12 @@ enum K1Tail : int { TAIL_NONE = 0, TAIL_PREP = 1, TAIL_PREP_MFMA = 2, TAIL_OBS =
 template <int WG, bool TILE, int TAIL, bool RES, int LEAN, bool STREAM = false>
 __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(KParams p0) {
     // LEAN 0: every option of the sampler.  LEAN 1 ("plain"): the default sampler and nothing else.  LEAN 2: the default sampler
-    // plus snooker updates (theta_snooker > 0: the reference's multivariate, hierarchical and LBA examples) -- replay, block
-    // masks, recombination, the optimiser's updates, the other proposal kinds and the trace compiled out as in LEAN 1.
+    // plus snooker updates and block updates (theta_snooker > 0, blocking_on: what the reference's multivariate, hierarchical,
+    // LBA and blocking examples / tests ask of sample()) -- replay, recombination, the optimiser's updates, the other proposal
+    // kinds and the trace compiled out as in LEAN 1.
     constexpr bool PLAIN = LEAN != 0;  // none of the general options
     constexpr bool SNK = LEAN != 1;    // snooker branches compiled in
+    constexpr bool MSK = LEAN != 1;    // block masks (reset!) compiled in
     constexpr bool FUSE_PREP = TAIL == TAIL_PREP || TAIL == TAIL_PREP_MFMA;
     constexpr bool PREP_MFMA = TAIL == TAIL_PREP_MFMA;
     constexpr bool FUSE_OBS = TAIL == TAIL_OBS;
@@ -1366,14 +1368,14 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
             v0 = t0; v1 = t1;
             if (kind == 3) return;
             bool keep0 = false, keep1 = false;  // reset! (crossover.jl:336-352): asked for now, with the row loads
-            if (!PLAIN && p.mask) {
+            if (MSK && p.mask) {
                 keep0 = !p.mask[j0];
                 keep1 = has1 && !p.mask[j1];
             }
             // block sweeps (block_update!, main.jl:174-179): a scalar outside the block keeps its value whatever the crossover
             // proposes (reset!), so neither its noise draw nor the partner rows are needed -- in the hyper-parameter sweep of
             // a hierarchical model that is all but a few scalars of the row.  (Mutation ignores the mask, main.jl:205.)
-            if (!PLAIN && kind != 2 && keep0 && (keep1 || !has1)) return;
+            if (MSK && kind != 2 && keep0 && (keep1 || !has1)) return;
             // (noise block k >> 1 covers the dim pairs 2(k >> 1) and 2(k >> 1) + 1: four scalars per block)
             const U4 nz = draw_block(p.seed, S_NOISE, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)(k >> 1));
             double u0 = u32unit((k & 1) ? nz.z : nz.x), u1 = u32unit((k & 1) ? nz.w : nz.y);

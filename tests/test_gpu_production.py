@@ -215,10 +215,19 @@ def test_the_three_likelihood_modes_make_the_same_decisions(demc):
 # Examples/Hierarchical_Example.jl:112, Examples/Run_LBA.jl) has kernel instances of its own -- replay, block masks,
 # recombination, optimiser updates, the other proposal kinds and the trace compiled out, the snooker branches in
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", ["cfg1_resident", "cfg2_suffstat_resident", "cfg2_streaming_resident", "cfg3_chain", "cfg5_chain"])
+@pytest.mark.parametrize("shape", ["cfg1_resident", "cfg2_suffstat_resident", "cfg2_streaming_resident", "cfg3_chain", "cfg5_chain",
+                                   "cfg1_blocks", "cfg2_blocks_snooker"])
 def test_snooker_lean_instances_match_the_oracle(demc, orc, shape):
+    """LEAN 2 also carries block updates (blocking_on / blocks: test/blocking_tests.jl:33-53): the last two shapes"""
     from demc_amd import workloads as W
-    if shape == "cfg1_resident":      # Gaussian example, the whole update in the resident kernel's own observation loop
+    snk = 0.3
+    if shape == "cfg1_blocks":        # test/blocking_tests.jl: blocks [[true,false],[false,true]], no snooker
+        w, G, Np, kern, kw, snk = W.cfg1(), 8, 10, "k_propose<256,true,TAIL_OBS,true,2>", {}, 0.0
+        w["masks"] = np.array([[1, 0], [0, 1]], np.uint8)
+    elif shape == "cfg2_blocks_snooker":
+        w, G, Np, kern, kw = W.cfg2(N=3000), 32, 64, "k_propose<256,true,TAIL_PREP_MFMA,true,2>", dict(loglike_mode=1)
+        w["masks"] = np.array([[1] * 4 + [0] * 4, [0] * 4 + [1] * 4], np.uint8)
+    elif shape == "cfg1_resident":    # Gaussian example, the whole update in the resident kernel's own observation loop
         w, G, Np, kern, kw = W.cfg1(), 8, 10, "k_propose<256,true,TAIL_OBS,true,2>", {}
     elif shape == "cfg2_suffstat_resident":
         w, G, Np, kern, kw = W.cfg2(N=3000), 32, 64, "k_propose<256,true,TAIL_PREP_MFMA,true,2>", dict(loglike_mode=1)
@@ -228,6 +237,6 @@ def test_snooker_lean_instances_match_the_oracle(demc, orc, shape):
         w, G, Np, kern, kw = W.cfg3(N=1500, G=16), 16, 256, "k_propose<256,true,TAIL_PREP_MFMA,false,2>", dict(loglike_mode=0, fuse=2, geometry_groups=256)
     else:
         w, G, Np, kern, kw = W.cfg5(N=400, G=8, Np=16), 8, 16, "k_propose<256,true,TAIL_NONE,false,2>", {}
-    ran = free_run(demc, orc, w, 8, [kern], G, Np, theta_exact=False, theta_snooker=0.3,
+    ran = free_run(demc, orc, w, 8, [kern], G, Np, theta_exact=False, theta_snooker=snk,
                    lp_rtol=1e-5 if shape == "cfg5_chain" else 1e-9, **kw)
     assert "k_res_mvn" not in ran
