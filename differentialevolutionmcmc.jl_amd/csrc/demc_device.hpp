@@ -105,8 +105,29 @@ __device__ inline double softplus(double x) { return x > 0 ? x + log1p(exp(-x)) 
 // denominator lies in [2, 3]: no scaling needed).  About a third of the instructions of the library's log1p on top of
 // exp; agrees with softplus() to ~2e-16 relative (tests/test_gpu_parity.py compares the hierarchical families with the
 // oracle's libm forms at 1e-9).  The hierarchical likelihoods spend most of their instructions here.
+// exp(a) for a <= 0 without a quarter-rate instruction: the library's exp spends v_rndne_f64, v_cvt_i32_f64 and v_ldexp_f64 (16
+// cycles a wave each, against 4 for an FP64 add) on range reduction and scaling.  Here: n = round(a log2 e) by adding and
+// subtracting 1.5 * 2^52 (n sits in the low word of the sum), r = a - n ln 2 in two FMAs (hi / lo split), e^r by its degree-13
+// Taylor polynomial (|r| <= 0.347: truncation 4e-18), and 2^n built in the exponent field by integer adds.  a is clamped at
+// -700 (e^-700 ~ 1e-304: still a normal number; below it the callers' results do not change).  Relative error < 2.5e-16.
+__device__ __forceinline__ double exp_nonpos(double a) {
+    a = fmax(a, -700.0);
+    const double kMagic = 6755399441055744.0;  // 1.5 * 2^52
+    const double tn = fma(a, 1.4426950408889634074, kMagic);
+    const double nf = tn - kMagic;
+    const int n = __double2loint(tn);           // low word of the sum = n (two's complement, -1010 <= n <= 0)
+    double r = fma(nf, -6.93147180369123816490e-01, a);
+    r = fma(nf, -1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;              // 1/13!
+    p = fma(p, r, 1.0 / 479001600.0); p = fma(p, r, 1.0 / 39916800.0); p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0); p = fma(p, r, 1.0 / 40320.0); p = fma(p, r, 1.0 / 5040.0); p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0); p = fma(p, r, 1.0 / 24.0); p = fma(p, r, 1.0 / 6.0); p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0); p = fma(p, r, 1.0);
+    const double two_n = __hiloint2double((n + 1023) << 20, 0);  // 2^n, n + 1023 >= 13
+    return p * two_n;
+}
 __device__ inline double softplus_fast(double x) {
-    const double t = exp(-fabs(x));
+    const double t = exp_nonpos(-fabs(x));
     const double den = 2.0 + t;
     double r = __builtin_amdgcn_rcp(den);
     r = fma(fma(-den, r, 1.0), r, r);

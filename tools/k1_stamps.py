@@ -19,7 +19,7 @@ demc_amd._ffi.LIB_PATH = os.path.join(ROOT, "differentialevolutionmcmc.jl_amd", 
 from demc_amd import workloads as W  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--n-groups", type=int, default=256)
+ap.add_argument("--n-groups", type=int, default=None)
 ap.add_argument("--np", type=int, default=256, dest="Np")
 ap.add_argument("--dim", type=int, default=32)
 ap.add_argument("--nobs", type=int, default=100000)
@@ -29,7 +29,7 @@ a = ap.parse_args()
 if a.config:  # one of tools/run_configs.py's BASELINE shapes (e.g. cfg4: a whole workgroup per particle)
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import run_configs  # noqa: E402
-    c = run_configs.build(a.config, np.random.default_rng(20260000 + int(a.config[-1])))
+    c = run_configs.build(a.config, np.random.default_rng(20260000 + int(a.config[-1])), **({"G": a.n_groups} if a.n_groups else {}))
     ex = dict(c["extra"])
     masks = ex.pop("masks", None)
     eng = demc_amd.HipEngine(n_groups=c["G"], Np=c["Np"], D=c["D"], n_rows=40, schedule=2, seed=1, trace=0, **ex)
@@ -40,8 +40,12 @@ if a.config:  # one of tools/run_configs.py's BASELINE shapes (e.g. cfg4: a whol
         eng.set_blocks(masks)
     eng.set_state(c["init"](c["G"] * c["Np"]))
     eng.step(1, 30)
+    if masks is not None and os.environ.get("STAMP_BLOCK"):  # stamps of ONE block sweep's launch (e.g. 0: the hyper-parameter sweep)
+        eng.set_blocks(masks[int(os.environ["STAMP_BLOCK"]):int(os.environ["STAMP_BLOCK"]) + 1])
+        eng.step(31, 2)
     n_wg = c["G"] * c["Np"] // 2  # upper bound on the workgroups of a launch; unused stamp slots are filtered out below
 else:
+    a.n_groups = a.n_groups or 256
     prob = W.cfg3(N=a.nobs, d=a.dim, G=a.n_groups, Np=a.Np)
     eng = demc_amd.HipEngine(n_groups=a.n_groups, Np=a.Np, D=a.dim, n_rows=40, schedule=2, seed=1,
                              loglike_mode=1 if a.mode == "suffstat" else 0, trace=0)

@@ -14,10 +14,10 @@ import demc_amd as D  # noqa: E402
 from demc_amd import families as F  # noqa: E402
 
 
-def build(name, rng):
+def build(name, rng, **kw):
     """the BASELINE configs as demc_amd.workloads builds them (bench.py's data), in this tool's older dict shape"""
     from demc_amd import workloads as W
-    w = W.BUILDERS[name]()
+    w = W.BUILDERS[name](**kw)
     extra = dict(w["engine"])
     if w["masks"] is not None:
         extra["masks"] = w["masks"]
