@@ -14,7 +14,7 @@
 
 #include <cmath>
 
-#include "demc_erfcx_table.hpp"
+#include "demc_logphi_table.hpp"
 #include "demc_phi_table.hpp"
 
 namespace demc {
@@ -172,21 +172,6 @@ inline double prior_const(int kind, double a, double b) {
     }
 }
 
-// erfcx(y) = exp(y^2) erfc(y) for y >= 0 from the generated piecewise polynomial table (tools/gen_erfcx_table.py,
-// relative error ~1e-15): interval index = exponent and top 5 mantissa bits of z = 1 + y, polynomial in (z - centre).
-// tab points at a copy of kErfcxTable (LDS in the kernels that call this per observation).
-__device__ inline double erfcx_pos(const double* tab, double y) {
-    const double z = 1.0 + fmin(y, 30.99);  // beyond that exp(-y^2) has long underflowed
-    const long long bits = __double_as_longlong(z);
-    const int idx = (int)(bits >> 47) - (1023 << 5);
-    const double c = __longlong_as_double((bits & ~((1LL << 47) - 1)) | (1LL << 46));
-    const double dz = z - c;
-    const double* a = tab + idx * (kErfcxDeg + 1);
-    double r = a[kErfcxDeg];
-#pragma unroll
-    for (int k = kErfcxDeg - 1; k >= 0; --k) r = fma(r, dz, a[k]);
-    return r;
-}
 // Phi(z) and phi(z)/S from the generated piecewise polynomial of Phi (tools/gen_phi_table.py: absolute error 1.1e-16 for Phi
 // and for the phi recovered from it; |z| clamped to 8.5, beyond which they are 0 / 1 in double precision).  S = kPhiPerUnit
 // rows per unit of z.  The argument arrives SCALED, zs = S z: row i = round(zs + 8.5 S) of the table is the polynomial of Phi
@@ -197,8 +182,8 @@ __device__ inline double erfcx_pos(const double* tab, double y) {
 // the row address is a 24-bit multiply, which runs at full rate.  Rows are NOT padded to a power of two: with a 128-byte
 // stride every row starts on LDS bank 0 and lanes that read different rows serialise -- measured 2.7x slower than the
 // 80-byte stride.)  For sums of order one -- the LBA density and distribution function -- where absolute accuracy is what
-// counts; the log-survival of the LNR keeps the exp + erfcx form (relative accuracy in the tail).  tab points at a copy of
-// kPhiTable.  The clamp is v_max / v_min: a NaN argument is read as -8.5 (callers that must turn a NaN into -Inf test their
+// counts; the log-survival of the LNR has a table of its own (log_Phi_neg_table below: relative accuracy in the tail).  tab
+// points at a copy of kPhiTable.  The clamp is v_max / v_min: a NaN argument is read as -8.5 (callers that must turn a NaN into -Inf test their
 // own inputs, see lba_trial).
 constexpr double kPhiS = (double)kPhiPerUnit;
 constexpr double kPhiHalf = kPhiZmax * kPhiPerUnit;              // 8.5 S: an integer
@@ -220,10 +205,28 @@ __device__ __forceinline__ void phiS_Phi_table(const double* tab, double zs, dou
     Ph = P;
     phS = dP;
 }
-// log Phi(-z) (log-survival of a standard normal), finite far into the tail
-__device__ inline double log_Phi_neg(const double* tab, double z) {
-    const double r0 = 0.5 * erfcx_pos(tab, fabs(z) * kInvSqrt2);
-    return z >= 0.0 ? log(r0) - 0.5 * z * z : log1p(-r0 * exp(-0.5 * z * z));
+// log Phi(-z), the log-survival of a standard normal, finite far into the tail,
+// from its own table (tools/gen_logphi_table.py: one degree-9 polynomial per interval of 1/8 on [-8.5, 38.5], error
+// 2.2e-16 relative to max(1, |g|)): nine FMAs and ten coefficients per value -- no erfcx, no exp, no log.  Row and u as for the
+// Phi table (1.5 * 2^52 added and subtracted).  Below -8.5 the value is 0 to double precision (clamp); beyond 38.5 --
+// survival probabilities under 1e-324 -- Mills' ratio: log Phi(-z) = -z^2/2 - log z - log sqrt(2 pi) + log(1 - 1/z^2 + 3/z^4
+// - 15/z^6) (relative error < 1e-11 there), out of line.  tab points at a copy of kLogPhiTable.
+__device__ __attribute__((noinline)) double log_Phi_neg_far(double z) {
+    const double i2 = 1.0 / (z * z);
+    return -0.5 * z * z - log(z) - 0.5 * kLog2Pi + log1p(i2 * (-1.0 + i2 * (3.0 - 15.0 * i2)));
+}
+static_assert(kLogPhiZlo == -8.5 && kLogPhiPerUnit == 8 && kLogPhiRow == 10 && kLogPhiDeg == 9, "log_Phi_neg_table is written for this table shape");
+__device__ __forceinline__ double log_Phi_neg_table(const double* tab, double z) {
+    if (z > kLogPhiZhi) return log_Phi_neg_far(z);  // (NaN falls through to the clamp and reads row 0)
+    const double zc = fmin(fmax(8.0 * z, -68.0), 8.0 * kLogPhiZhi);
+    const double kM = 6755399441055744.0 + 68.0;
+    const double t = zc + kM;
+    const double u = zc - (t - kM);
+    const double* a = tab + __mul24(__double2loint(t), kLogPhiRow);
+    double P = a[9];
+#pragma unroll
+    for (int k = 8; k >= 0; --k) P = fma(P, u, a[k]);
+    return P;
 }
 
 // LBA (Examples/Run_LBA.jl:33-37; SequentialSamplingModels conventions: b = A + k, sigma = 1,

@@ -294,7 +294,7 @@ __device__ __forceinline__ double lba_range_sum(const KParams& p, const double* 
     return acc + log(prod);
 }
 
-// LNR log-likelihood of the trials i0, i0+stride, ... < i1 for one proposal (lognormal_race_tests.jl:9-12); tab = kErfcxTable
+// LNR log-likelihood of the trials i0, i0+stride, ... < i1 for one proposal (lognormal_race_tests.jl:9-12); tab = kLogPhiTable
 __device__ __forceinline__ double lnr_range_sum(const KParams& p, const double* th, long long i0, long long i1, int stride, const double* tab) {
     const int na = p.n_acc;
     double nu[8];
@@ -311,7 +311,7 @@ __device__ __forceinline__ double lnr_range_sum(const KParams& p, const double* 
             const double lt = log(t);
             for (int a = 0; a < na; ++a) {
                 const double z = (lt - nu[a]) * isg;
-                ll += (a + 1 == c) ? (-(z * z + kLog2Pi) / 2.0 - lsg - lt) : log_Phi_neg(tab, z);
+                ll += (a + 1 == c) ? (-(z * z + kLog2Pi) / 2.0 - lsg - lt) : log_Phi_neg_table(tab, z);
             }
         }
         acc += ll;
@@ -1850,14 +1850,14 @@ __global__ __launch_bounds__(256) void k_direct_mvn(KParams p, int n_chunks) {
 // so data loads are wave-uniform (scalar) and the loop is pure FP64 VALU.  grid = (proposal blocks, chunks).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_obs_loglike(KParams p, int n_chunks) {
-    // LDS copy of the family's table: Phi / phi polynomials (LBA), erfcx polynomials (LNR)
-    constexpr int kTabPhi = kPhiIntervals * kPhiRow, kTabErfcx = kErfcxIntervals * (kErfcxDeg + 1);
+    // LDS copy of the family's table: Phi / phi polynomials (LBA), log Phi(-z) polynomials (LNR)
+    constexpr int kTabPhi = kPhiIntervals * kPhiRow, kTabErfcx = kLogPhiRows * kLogPhiRow;  // (LNR: the log Phi(-z) table)
     __shared__ double s_tab[kTabPhi > kTabErfcx ? kTabPhi : kTabErfcx];
     if (p.family == FAM_LBA) {
         for (int i = threadIdx.x; i < kTabPhi; i += 256) s_tab[i] = kPhiTable[i];
         __syncthreads();
     } else if (p.family == FAM_LNR) {
-        for (int i = threadIdx.x; i < kTabErfcx; i += 256) s_tab[i] = kErfcxTable[i];
+        for (int i = threadIdx.x; i < kTabErfcx; i += 256) s_tab[i] = kLogPhiTable[i];
         __syncthreads();
     }
     const int q = blockIdx.x * 256 + threadIdx.x;

@@ -458,7 +458,13 @@ double orc_lnr_logpdf(const double* nu, int32_t n_acc, double sigma, double tau,
         const double z = (lt - nu[i]) / sigma;
         if (i + 1 == choice)
             ll += -(z * z + LOG_2PI) / 2.0 - log(sigma) - lt;
-        else
+        else if (z > 37.0) {
+            /* erfc underflows near z = 38.5 and log(0) would turn a (hopeless but legal) proposal into -Inf; Distributions'
+             * logccdf (StatsFuns.normlogccdf, what SequentialSamplingModels' LNR calls) stays finite.  Mills' ratio:
+             * log Phi(-z) = -z^2/2 - log z - log sqrt(2 pi) + log(1 - 1/z^2 + 3/z^4 - 15/z^6), relative error < 1e-11 here */
+            const double i2 = 1.0 / (z * z);
+            ll += -0.5 * z * z - log(z) - 0.5 * LOG_2PI + log1p(i2 * (-1.0 + i2 * (3.0 - 15.0 * i2)));
+        } else
             ll += log(0.5 * erfc(z * 0.70710678118654752440));
     }
     return ll;

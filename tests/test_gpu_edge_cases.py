@@ -252,3 +252,28 @@ def test_longrow_repeat_runs_agree_bit_for_bit(demc):
             sigs.add(hashlib.md5(b"".join(np.ascontiguousarray(q).tobytes() for q in parts)).hexdigest())
         assert len(sigs) == 1, (fam, extra)
 
+
+
+def test_lnr_log_survival_table_against_the_oracle_far_into_both_tails(demc, orc):
+    """the LNR's log Phi(-z) comes from a polynomial table on [-8.5, 38.5] and from Mills' ratio beyond: drifts that put the
+    losing accumulators at z from -30 (survival 1) to +60 (survival 1e-784: log-survival -1800) against the oracle's libm form"""
+    from demc_amd import families as F
+    rng = np.random.default_rng(5)
+    N, na = 40, 3
+    choice = rng.integers(1, na + 1, N).astype(float)
+    rt = rng.uniform(0.5, 1.5, N)
+    data = np.concatenate([choice, rt])
+    D = na + 1
+    th = np.zeros((16, D))
+    th[:, :na] = np.linspace(-62.0, 30.0, 16)[:, None] + rng.normal(0, 0.3, (16, na))  # z = (log t - nu)/sigma
+    th[:, na] = 0.1
+    outs = []
+    for mk in (demc.HipEngine, orc.Oracle):
+        e = mk(n_groups=2, Np=8, D=D, schedule=1)
+        e.set_model(F.FAM_LNR, data, [N, na], [1.0])
+        e.set_priors([0] * D, [0.0] * D, [1.0] * D)
+        e.set_bounds([-np.inf] * na + [0.0], [np.inf] * na + [0.4])
+        outs.append(e.logpost(th))
+        e.close()
+    assert np.isfinite(outs[1]).all() and outs[1].min() < -5e4
+    np.testing.assert_allclose(outs[0], outs[1], rtol=1e-9)

@@ -17,7 +17,7 @@ def _rtol(prob):
     """1e-9 everywhere except the LBA.  Its survival factor 1 - F(t), F(t) = 1 + (t/A)[n1 Phi(n1) - n2 Phi(n2) + phi(n1)
     - phi(n2)], is formed by cancellation (as in SequentialSamplingModels and in the oracle): for a trial far in the
     tail (1 - F ~ 1e-11, the density just above the 1e-10 floor) the last-bit differences between libm's erfc and the
-    device's erfcx table are amplified to ~1e-4 in that trial's log-density -- for ANY two implementations of the
+    device's Phi table are amplified to ~1e-4 in that trial's log-density -- for ANY two implementations of the
     formula.  Typical agreement is 1e-12; the seeded 400-case sweep needs 1e-5 (one such trial in ~230 cases)."""
     from demc_amd import families as F
     return 1e-5 if prob["fam"] == F.FAM_LBA else LOGPOST_RTOL
@@ -490,7 +490,7 @@ def test_rejects_unsupported(demc):
 
 
 def test_lba_lnr_against_scipy_goldens(demc):
-    """the device's single-exponential phi/Phi (erfcx table) against the scipy goldens directly"""
+    """the device's table-driven Phi / phi (LBA) and log Phi(-z) (LNR) against the scipy goldens directly"""
     import os
     from demc_amd import families as F
     G = np.load(os.path.join(os.path.dirname(__file__), "golden", "logpdf_golden.npz"))
