@@ -764,8 +764,7 @@ void plan_lean(demc_handle* h) {
     // STREAMING: only where the streaming-resident form applies (plan_stream: small populations), and only with one wave per
     // SIMD (256 threads: what the observation stage needs beyond 256 VGPRs then lives in AGPRs, not scratch)
     if (!h->st_ok || wg != 256) return;
-    size_t bytes = base + ((size_t)(wg / 4) * h->dpad + (size_t)(wg / 64) * nact_max) * sizeof(double) +
-                   2 * sizeof(unsigned) * (size_t)h->st_C * nact_max + 16;
+    size_t bytes = base + ((size_t)(wg / 4) * h->dpad + (size_t)(wg / 64) * nact_max) * sizeof(double) + 16;
     if (bytes > kMaxDynLds) return;
     const size_t xbytes = (size_t)(h->st_chunk_tiles + 1) * (h->dpad / 4) * 64 * sizeof(double);
     // (the X chunk rides in LDS exactly when plan_stream found room for it; this kernel's other buffers are no larger)

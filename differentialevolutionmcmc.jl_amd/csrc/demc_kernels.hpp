@@ -18,6 +18,7 @@
 // as contiguous segments; every lane owns dims {2k, 2k+1} for k = sl, sl+LPP, ... which is also
 // the granularity of one Philox block (two 53-bit uniforms).
 #pragma once
+#include <type_traits>
 #include "demc_device.hpp"
 
 namespace demc {
@@ -615,7 +616,71 @@ typedef __attribute__((address_space(1))) const double* glb_cptr;
 // XP = lds_cptr or glb_cptr: the address space is part of the type so that the B loads are ds_read / global_load (a generic
 // pointer makes them flat loads, which wait on both memory counters and serialise the prefetch against the MFMAs).
 // `zt` = index (relative to xsrc) of an all-zero tile that absorbs the odd tail of the two-tile ping-pong.
-template <int KS, int MT, typename XP>
+// The tile loop of cross_tiles for KS = 2, MT = 2 out of an LDS copy (BASELINE cfg2: d = 8, 32 moving particles per group),
+// as ONE asm statement.  Written with the builtin, inside the resident kernels (256 VGPRs live), the compiler keeps the
+// loop-carried accumulators in VGPRs while selecting the AGPR form of the instruction: every trip copies 16 registers into
+// AGPRs, runs its 8 MFMAs, idles until the last has drained (s_nop 15) and copies them back -- 108 cycles per MFMA measured
+// against 64 for the bare chain (tools/mfma_f64_chain.hip, tools/cross_stage_bench.hip).  Here the accumulators are operands
+// of the one statement, so they stay in AGPRs from the first tile to the last.  n >= 1 tiles from LDS byte address va
+// (the lane's element of tile 0; a tile is 2 k-steps x 64 lanes x 8 bytes); two register sets in ping-pong, one tile always
+// in flight, every load in bounds.  Per accumulator the products are added in the order of the builtin loop: same bits.
+// Wait states (cdna_hip_programming.md 5.7): two before the first MFMA reads operands the compiler has just written (s_nop 1);
+// MFMA -> MFMA taking D whole as C: none; D -> any other reader: 18 for this 16-pass instruction (s_nop 15 + s_nop 7 closing
+// the string).  Every ds_read of the statement has landed (lgkmcnt(0)) before its last MFMA group issues.
+#define DEMC_MFMA4(bx, by)                                              \
+    "v_mfma_f64_16x16x4_f64 %[c0], %[a00], %[" #bx "], %[c0]\n\t"        \
+    "v_mfma_f64_16x16x4_f64 %[c1], %[a10], %[" #bx "], %[c1]\n\t"        \
+    "v_mfma_f64_16x16x4_f64 %[c0], %[a01], %[" #by "], %[c0]\n\t"        \
+    "v_mfma_f64_16x16x4_f64 %[c1], %[a11], %[" #by "], %[c1]\n\t"
+__device__ __forceinline__ void cross_loop_lds_2x2(d4& c0, d4& c1, double a00, double a01, double a10, double a11, unsigned va, int n) {
+    double p0, p1, q0, q1;    // the two register sets: k-steps 0 and 1 of a tile
+    int np = (n - 1) >> 1;    // two-tile trips; they leave one or two tiles for the tail
+    const int two = n - 2 * np - 1;  // 1: the tail has two tiles
+    asm volatile(
+        "s_nop 1\n\t"
+        "ds_read_b64 %[p0], %[va]\n\t"
+        "ds_read_b64 %[p1], %[va] offset:512\n\t"
+        "s_cmp_eq_u32 %[np], 0\n\t"
+        "s_cbranch_scc1 2f\n"
+        "1:\n\t"
+        "ds_read_b64 %[q0], %[va] offset:1024\n\t"
+        "ds_read_b64 %[q1], %[va] offset:1536\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t"
+        DEMC_MFMA4(p0, p1)
+        "ds_read_b64 %[p0], %[va] offset:2048\n\t"
+        "ds_read_b64 %[p1], %[va] offset:2560\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t"
+        DEMC_MFMA4(q0, q1)
+        "v_add_u32 %[va], 0x800, %[va]\n\t"
+        "s_sub_u32 %[np], %[np], 1\n\t"
+        "s_cmp_lg_u32 %[np], 0\n\t"
+        "s_cbranch_scc1 1b\n"
+        "2:\n\t"
+        "s_cmp_eq_u32 %[two], 0\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        "ds_read_b64 %[q0], %[va] offset:1024\n\t"
+        "ds_read_b64 %[q1], %[va] offset:1536\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t"
+        DEMC_MFMA4(p0, p1)
+        "s_waitcnt lgkmcnt(0)\n\t"
+        DEMC_MFMA4(q0, q1)
+        "s_branch 4f\n"
+        "3:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        DEMC_MFMA4(p0, p1)
+        "4:\n\t"
+        "s_nop 15\n\t"
+        "s_nop 7"
+        : [c0] "+a"(c0), [c1] "+a"(c1), [p0] "=&v"(p0), [p1] "=&v"(p1), [q0] "=&v"(q0), [q1] "=&v"(q1), [va] "+v"(va), [np] "+s"(np)
+        : [a00] "v"(a00), [a01] "v"(a01), [a10] "v"(a10), [a11] "v"(a11), [two] "s"(two)
+        : "scc", "memory");
+}
+#undef DEMC_MFMA4
+// ASMLOOP: take the one-statement tile loop where it exists (KS = 2, MT = 2, LDS copy).  Only k_res_mvn asks for it: inside
+// the general k_propose<512,...,STREAM> (164 KB of code, 128 VGPRs + 128 AGPRs once the statement pins accumulators to
+// AGPRs) the dispatch died with HSA_STATUS_ERROR_INVALID_ISA even on shapes that never reach the statement; not understood,
+// so that kernel keeps the builtin loop it has been tested with.
+template <int KS, int MT, typename XP, bool ASMLOOP = false>
 __device__ inline void cross_tiles(lds_cptr ybuf, int dpad, int n_act, int ptile0, XP xsrc, int ksx, int t_lo, int t_hi, int zt,
                                    lds_ptr out, int lane) {
     double a[MT][KS];
@@ -634,6 +699,10 @@ __device__ inline void cross_tiles(lds_cptr ybuf, int dpad, int n_act, int ptile
     for (int mt = 0; mt < MT; ++mt) acc[mt] = (d4){0.0, 0.0, 0.0, 0.0};
     const int tstride = ksx * 64;
     XP xb = xsrc + lane;
+    if constexpr (ASMLOOP && KS == 2 && MT == 2 && std::is_same<XP, lds_cptr>::value) {
+        const int tl = __builtin_amdgcn_readfirstlane(t_lo), th = __builtin_amdgcn_readfirstlane(t_hi);  // wave-uniform by construction
+        if (th > tl) cross_loop_lds_2x2(acc[0], acc[1], a[0][0], a[0][1], a[1][0], a[1][1], (unsigned)(size_t)(xb + tl * tstride), th - tl);
+    } else {
     double b0[KS], b1[KS];
     {
         XP x = xb + (t_lo < t_hi ? t_lo : zt) * tstride;
@@ -663,6 +732,7 @@ __device__ inline void cross_tiles(lds_cptr ybuf, int dpad, int n_act, int ptile
             for (int mt = 0; mt < MT; ++mt)
                 acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt][ks], b1[ks], acc[mt], 0, 0, 0);
     }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -673,16 +743,16 @@ __device__ inline void cross_tiles(lds_cptr ybuf, int dpad, int n_act, int ptile
         }
 }
 // particle tiles in groups of MT (registers: KS x MT fragments), as few accumulators as the tiles need
-template <int KS, typename XP>
+template <int KS, typename XP, bool ASMLOOP = false>
 __device__ inline void cross_ks(lds_cptr ybuf, int dpad, int n_act, XP xsrc, int t_lo, int t_hi, int zt, lds_ptr out, int lane) {
     const int n_pt = (n_act + 15) >> 4;
     constexpr int MTMAX = KS >= 16 ? 2 : 4;
     int p0 = 0;
-    for (; p0 + MTMAX <= n_pt; p0 += MTMAX) cross_tiles<KS, MTMAX, XP>(ybuf, dpad, n_act, p0, xsrc, KS, t_lo, t_hi, zt, out, lane);
+    for (; p0 + MTMAX <= n_pt; p0 += MTMAX) cross_tiles<KS, MTMAX, XP, ASMLOOP>(ybuf, dpad, n_act, p0, xsrc, KS, t_lo, t_hi, zt, out, lane);
     const int rest = n_pt - p0;
-    if (MTMAX == 4 && rest == 3) cross_tiles<KS, 4, XP>(ybuf, dpad, n_act, p0, xsrc, KS, t_lo, t_hi, zt, out, lane);
-    else if (MTMAX == 4 && rest == 2) cross_tiles<KS, 2, XP>(ybuf, dpad, n_act, p0, xsrc, KS, t_lo, t_hi, zt, out, lane);
-    else if (rest >= 1) cross_tiles<KS, 1, XP>(ybuf, dpad, n_act, p0, xsrc, KS, t_lo, t_hi, zt, out, lane);
+    if (MTMAX == 4 && rest == 3) cross_tiles<KS, 4, XP, ASMLOOP>(ybuf, dpad, n_act, p0, xsrc, KS, t_lo, t_hi, zt, out, lane);
+    else if (MTMAX == 4 && rest == 2) cross_tiles<KS, 2, XP, ASMLOOP>(ybuf, dpad, n_act, p0, xsrc, KS, t_lo, t_hi, zt, out, lane);
+    else if (rest >= 1) cross_tiles<KS, 1, XP, ASMLOOP>(ybuf, dpad, n_act, p0, xsrc, KS, t_lo, t_hi, zt, out, lane);
 }
 // dispatch on the number of k-steps (dpad / 4)
 template <typename XP>

@@ -14,7 +14,10 @@
 //   * select_base: cumulative weights on the DPP network (wave_cdf) by wave 0 while the other waves draw, then a two-level
 //     search (chunk offsets, then inside the chunk);
 //   * SUFFSTAT: the whole update here.  STREAMING (STREAM = true): additionally the observation stream of the
-//     streaming-resident form (C workgroups per group, granule hand-over) -- same protocol as k_propose<...,STREAM>.
+//     streaming-resident form (C workgroups per group, granule hand-over) -- same protocol as k_propose<...,STREAM>, but
+//     every lane polls the granules of its own particle (no staging, no barrier inside the wait);
+//   * DT = 8 (cfg2): Sigma^-1 (theta' - xbar) on the vector pipe inside the quad, and the tile loop of the observation stage
+//     as one asm statement (cross_loop_lds_2x2: accumulators pinned to AGPRs).
 // Same addressed draws and the same per-scalar arithmetic as k_propose: proposals and decisions are the ones the general
 // kernel produces (tests/test_gpu_parity.py::test_lean_resident_kernel_*); prior sums run in a different lane order
 // (log-densities equal to rounding).
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
     const bool even = DT > 0 || (D & 1) == 0;
     const int half = Np / 2, nact_max = Np - half;
     // LDS: tile [Np][D] | weights [Np] | cdf [nact_max] + chunk offsets [16] | centred theta' rows [WG/4][D+2] |
-    //      STREAM: y rows [WG/4][dpad] | per-wave partials [WG/64][nact_max] | granule payloads [C][nact_max] u32x2 | X chunk
+    //      STREAM: y rows [WG/4][dpad] | per-wave partials [WG/64][nact_max] | X chunk
     double* tile = lds;
     double* w_s = tile + (size_t)Np * D;
     double* cdf = w_s + Np;
@@ -66,8 +69,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
     double* scr = coff + 16;
     double* ybuf = scr + (size_t)(WG / 4) * scr_stride;
     double* part_l = ybuf + (STREAM ? (size_t)(WG / 4) * p.dpad : 0);
-    unsigned* part_c = reinterpret_cast<unsigned*>(part_l + (STREAM ? (size_t)(WG / 64) * nact_max : 0));
-    double* xs = reinterpret_cast<double*>((reinterpret_cast<size_t>(part_c + (STREAM ? 2 * (size_t)p.st_C * nact_max : 0)) + 15) & ~(size_t)15);
+    double* xs = reinterpret_cast<double*>((reinterpret_cast<size_t>(part_l + (STREAM ? (size_t)(WG / 64) * nact_max : 0)) + 15) & ~(size_t)15);
     const int xt_lo = STREAM ? c_idx * p.st_chunk_tiles : 0;
     const int xt_hi = STREAM ? (xt_lo + p.st_chunk_tiles < p.n_tiles ? xt_lo + p.st_chunk_tiles : p.n_tiles) : 0;
 
@@ -121,6 +123,18 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
                 const int k = 4 * ks + kq, c = 16 * nt + col;
                 bfrag[nt][ks] = (k < d && c < d) ? p.Ainv[k * d + c] : 0.0;
             }
+    }
+    // DT == 8: the product stays on the vector pipe (see the phase loop); lane sl of a quad owns columns 2 sl, 2 sl + 1 of A^-1
+    constexpr bool DIRECT8 = DT == 8;
+    double ai8[2][8], sx8[2];
+    if constexpr (DIRECT8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            ai8[0][k] = p.Ainv[k * 8 + 2 * sl];
+            ai8[1][k] = p.Ainv[k * 8 + 2 * sl + 1];
+        }
+        sx8[0] = p.sx ? p.sx[2 * sl] : 0.0;
+        sx8[1] = p.sx ? p.sx[2 * sl + 1] : 0.0;
     }
     const int mc0 = lane & 15, mc1 = mc0 + 16;  // the two columns this lane sees of every MFMA result
     const double sx0 = (p.sx && mc0 < d) ? p.sx[mc0] : 0.0, sx1 = (p.sx && mc1 < d) ? p.sx[mc1] : 0.0;
@@ -211,7 +225,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
             if (!(total > 0.0) || !(total < INFINITY)) {
                 ibase = (int)(u_base * pool_n);
                 ibase = ibase < pool_n ? ibase : pool_n - 1;
-            } else {  // first i with cdf[i] >= t, else last: binary search (cdf is monotone)
+            } else {  // first i with cdf[i] >= t, else last: binary search (cdf is monotone; a four-lane count of the entries below t measured the same)
                 const double t = u_base * total;
                 int lo = 0, hi = pool_n - 1;
                 while (lo < hi) {
@@ -306,7 +320,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
         prior = subgroup_sum(prior, 4);
         oob = subgroup_sum(oob, 4);
         // ---- y = A^-1 (theta' - xbar) on the matrix cores: centred rows through LDS into operand order ----
-        {
+        if constexpr (!DIRECT8) {
             double* row = scr + (size_t)q * scr_stride;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -314,9 +328,34 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
                 if (j < D) row[j] = v8[e] - xb[e];
             }
         }
-        wave_lds_sync();
         double aux, S = 0.0;
-        {
+        if constexpr (DIRECT8) {
+            // d = 8: the 8 x 8 product on the vector pipe inside the quad -- lanes 0 and 1 hold the centred scalars 0..3 and
+            // 4..7, quad_perm hands them round, lane sl forms columns 2 sl and 2 sl + 1 (16 FMAs) and its share of theta~.y.
+            // The MFMA route (LDS transposition, two matrix instructions, four 16-lane reductions, LDS again) is a chain
+            // of ~2.3 k cycles for 64 FMAs per particle.
+            double c[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double ce = v8[e] - xb[e];
+                c[e] = dpp_mov<0x00>(ce);      // quad_perm:[0,0,0,0]
+                c[4 + e] = dpp_mov<0x55>(ce);  // quad_perm:[1,1,1,1]
+            }
+            double y0 = 0.0, y1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                y0 = fma(c[k], ai8[0][k], y0);
+                y1 = fma(c[k], ai8[1][k], y1);
+            }
+            const double c0_ = sl == 0 ? c[0] : sl == 1 ? c[2] : sl == 2 ? c[4] : c[6];
+            const double c1_ = sl == 0 ? c[1] : sl == 1 ? c[3] : sl == 2 ? c[5] : c[7];
+            aux = subgroup_sum(fma(c1_, y1, c0_ * y0), 4);
+            if (!STREAM)
+                S = subgroup_sum(fma(y1, sx8[1], y0 * sx8[0]), 4);
+            else
+                *reinterpret_cast<double2*>(ybuf + (size_t)q * p.dpad + 2 * sl) = make_double2(y0, y1);
+        } else {
+            wave_lds_sync();
             const int kq = lane >> 4, rowi = lane & 15;
             const int wrow0 = wave * 16;  // the wave's 16 particles are rows 0..15 of the A operand
             const double* trow = scr + (size_t)(wrow0 + rowi) * scr_stride;
@@ -360,18 +399,26 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
         if (STREAM) {
             // ---- the observation stream: cross terms of the phase's proposals against this workgroup's chunk of tiles ----
             __syncthreads();
+            DEMC_STAMP(16);  // every proposal of the phase prepared
             {
                 const int nw_ = WG / 64;
                 const int nt = xt_hi - xt_lo, per_w = (nt + nw_ - 1) / nw_;
                 const int t_lo = wave * per_w < nt ? wave * per_w : nt, t_hi = t_lo + per_w < nt ? t_lo + per_w : nt;
                 lds_ptr outw = (lds_ptr)(part_l + (size_t)wave * nact_max);
-                if (p.st_x_lds)
+                if constexpr (DT == 8 || DT == 32) {  // dpad = DT: the k-step count is a constant of the instance
+                    if (p.st_x_lds)
+                        cross_ks<DT / 4, lds_cptr, true>((lds_cptr)ybuf, DT, n_act, (lds_cptr)xs, t_lo, t_hi, p.st_chunk_tiles, outw, lane);
+                    else
+                        cross_ks<DT / 4, glb_cptr>((lds_cptr)ybuf, DT, n_act, (glb_cptr)(p.Xf + (size_t)xt_lo * (DT >> 2) * 64), t_lo, t_hi,
+                                                   p.n_tiles - xt_lo, outw, lane);
+                } else if (p.st_x_lds)
                     cross_stage<lds_cptr>((lds_cptr)ybuf, p.dpad, n_act, (lds_cptr)xs, t_lo, t_hi, p.st_chunk_tiles, outw, lane);
                 else
                     cross_stage<glb_cptr>((lds_cptr)ybuf, p.dpad, n_act, (glb_cptr)(p.Xf + (size_t)xt_lo * (p.dpad >> 2) * 64), t_lo, t_hi,
                                           p.n_tiles - xt_lo, outw, lane);
             }
             __syncthreads();
+            DEMC_STAMP(17);  // cross terms of this workgroup's chunk done
             const unsigned epoch = (unsigned)(step + 1);
             unsigned long long* gran = p.st_gran + (((size_t)(step & 1) * p.n_groups + gi) * p.st_C) * nact_max * 2;
             if (tid < n_act) {
@@ -381,36 +428,45 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
                 store_granule(mine_g, epoch, (unsigned)__double2loint(v));
                 store_granule(mine_g + 1, epoch, (unsigned)__double2hiint(v));
             }
+            DEMC_STAMP(18);  // granules stored
             if (step + 1 < n_steps) draw_phase(step + 1, pre_mine, pre_nzA, pre_nzB);  // while the granules travel
-            {
-                const int tot = p.st_C * n_act * 2;
+            DEMC_STAMP(11);  // next phase's blocks drawn
+            // every lane collects what ITS particle needs and nothing else: lane sl of the quad polls chunks sl, sl + 4, ...
+            // (both granules of a double, all of the lane's chunks in flight together) until their tags carry this epoch -- no
+            // staging in LDS, no workgroup barrier inside the wait, and the waves without a moving particle do not wait at
+            // all.  The quad then adds its four partial sums as a fixed tree: the same bits in every workgroup of the group.
+            if (valid) {
+                double part = 0.0;
                 unsigned spins = 0;
-                for (;;) {
-                    int ok = 1;
-                    for (int e = tid; e < tot; e += WG) {
-                        const int cc = e / (2 * n_act), r = e - cc * 2 * n_act;
-                        const unsigned long long x = load_granule(gran + (size_t)cc * nact_max * 2 + r);
-                        ok &= (unsigned)(x >> 32) == epoch;
-                        part_c[(size_t)cc * nact_max * 2 + r] = (unsigned)x;
+                for (int c0 = sl; c0 < p.st_C; c0 += 16) {  // up to four chunks (eight granules) in flight per lane
+                    unsigned long long x[4][2];
+                    for (;;) {
+                        bool ok = true;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int cc = c0 + 4 * i < p.st_C ? c0 + 4 * i : c0;
+                            const unsigned long long* gq = gran + ((size_t)cc * nact_max + q) * 2;
+                            x[i][0] = load_granule(gq);
+                            x[i][1] = load_granule(gq + 1);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) ok &= (unsigned)(x[i][0] >> 32) == epoch && (unsigned)(x[i][1] >> 32) == epoch;
+                        if (ok) break;
+                        if (++spins > (1u << 22)) {  // cannot happen with co-resident workgroups; never spin unbounded
+                            *p.st_err = 1u;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
                     }
-                    if (__syncthreads_and(ok)) break;
-                    if (++spins > (1u << 22)) {
-                        if (tid == 0) *p.st_err = 1u;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (c0 + 4 * i < p.st_C) part += __hiloint2double((int)(unsigned)x[i][1], (int)(unsigned)x[i][0]);
                 }
-            }
-            if (valid) {  // S = sum over the chunks, in chunk order: the same bits in every workgroup of the group
-                double acc_s = 0.0;
-                for (int cc = 0; cc < p.st_C; ++cc) {
-                    const unsigned* h2 = part_c + ((size_t)cc * nact_max + q) * 2;
-                    acc_s += __hiloint2double((int)h2[1], (int)h2[0]);
-                }
-                S = acc_s;
+                S = subgroup_sum(part, 4);
             }
         }
         DEMC_STAMP(8);  // (STREAM: cross terms streamed and handed over)
+        DEMC_STAMP(19);
         // ---- compute_posterior! + mh_update! + store_samples! (utilities.jl:92-99, 55-58, 201-210, 161-180) ----
         const double w = w_s[pl];
         const double wp = oob ? -INFINITY : prior + (p.c0 - 0.5 * (p.c1 - 2.0 * S + (double)p.N * aux));

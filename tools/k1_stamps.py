@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, "differentialevolutionmcmc.jl_amd", "csrc")
 subprocess.check_call(["make", "-B", "-C", csrc, "-s", "STAMPS=1", "OUT=../libdemc_hip_stamps.so"] +
-                      (["STAMP_PASS=" + os.environ["STAMP_PASS"]] if "STAMP_PASS" in os.environ else []))
+                      (["STAMP_PASS=" + os.environ["STAMP_PASS"]] if "STAMP_PASS" in os.environ else []) +
+                      (["EXTRA=" + os.environ["STAMP_EXTRA"]] if "STAMP_EXTRA" in os.environ else []))  # e.g. -DDEMC_X_...=1 experiments
 import demc_amd  # noqa: E402
 demc_amd._ffi.LIB_PATH = os.path.join(ROOT, "differentialevolutionmcmc.jl_amd", "libdemc_hip_stamps.so")
 from demc_amd import workloads as W  # noqa: E402
@@ -90,3 +91,5 @@ if a.mode == "streaming" and (full[:, 16] > 0).any():
     st = np.median(full[full[:, 16] > 0][:, 16:21], 0)
     print("  streaming-resident: all proposals prepared %.0f; chunk cross terms %.0f; granules stored %.0f; collected %.0f; "
           "accept + moves done %.0f" % tuple(st))
+    if (full[:, 11] > 0).any():  # k_res_mvn: the next phase's draws sit between the store and the first poll
+        print("  next phase's blocks drawn (between store and poll) %.0f" % np.median(full[full[:, 16] > 0][:, 11]))
