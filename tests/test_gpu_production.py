@@ -60,6 +60,17 @@ def test_cfg2_shape_streaming_lean_kernel(demc, orc, beta):
     free_run(demc, orc, w, 10, ["k_res_mvn<256,true,8>"], w["G"], w["Np"], theta_exact=beta == 0.0, beta=beta, loglike_mode=0)
 
 
+@pytest.mark.parametrize("N", [2050, 2048, 1030])
+def test_cfg2_tile_loop_tails(demc, orc, N):
+    """the observation stage of k_res_mvn<256,true,8> is one asm statement (cross_loop_lds_2x2: two-tile trips, then a tail of
+    one or two tiles): observation counts that hand a wave 5 / 2 / 3 / 1 tiles (N = 2050: 129 tiles, the last one ragged, 17
+    per workgroup and 10 for the last), 4 everywhere (2048), and 1 / 1 / 0 / 0 in the last workgroup (1030: 65 tiles) --
+    every entry and exit of the statement, against the oracle"""
+    from demc_amd import workloads as W
+    w = W.cfg2(N=N)
+    free_run(demc, orc, w, 6, ["k_res_mvn<256,true,8>"], w["G"], w["Np"], theta_exact=True, beta=0.0, loglike_mode=0)
+
+
 @pytest.mark.parametrize("beta", [0.0, 0.1])
 def test_cfg3_geometry_suffstat_lean_kernel(demc, orc, beta):
     """cfg3's group shape (Np = 256, D = 32) in SUFFSTAT mode -> k_res_mvn<512,false,32>, on 8 groups and N = 2000 so that
