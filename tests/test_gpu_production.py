@@ -71,6 +71,15 @@ def test_cfg2_tile_loop_tails(demc, orc, N):
     free_run(demc, orc, w, 6, ["k_res_mvn<256,true,8>"], w["G"], w["Np"], theta_exact=True, beta=0.0, loglike_mode=0)
 
 
+@pytest.mark.parametrize("Np,kernel", [(200, "k_res_mvn<512,false,8>"), (64, "k_res_mvn<256,false,8>"), (30, "k_res_mvn<256,false,8>")])
+def test_d8_vector_pipe_product_in_the_suffstat_instances(demc, orc, Np, kernel):
+    """D = 8 instances form Sigma^-1 (theta' - xbar) on the vector pipe inside the quad (no MFMA, no LDS transposition): the
+    512-thread form (100 moving particles), the 256-thread form, and a group whose halves (15) leave quads without a particle"""
+    from demc_amd import workloads as W
+    w = W.cfg2(N=1500, G=6, Np=Np)
+    free_run(demc, orc, w, 8, [kernel], 6, Np, theta_exact=True, beta=0.0, loglike_mode=1)
+
+
 @pytest.mark.parametrize("beta", [0.0, 0.1])
 def test_cfg3_geometry_suffstat_lean_kernel(demc, orc, beta):
     """cfg3's group shape (Np = 256, D = 32) in SUFFSTAT mode -> k_res_mvn<512,false,32>, on 8 groups and N = 2000 so that
