@@ -429,6 +429,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
                 store_granule(mine_g + 1, epoch, (unsigned)__double2hiint(v));
             }
             DEMC_STAMP(18);  // granules stored
+            DEMC_STAMP_AT(22, 0, (double)(__builtin_amdgcn_s_memrealtime() & 0xffffffffull));  // ... on the 100 MHz clock all CUs share (hand-over skew: tools/k1_stamps.py)
             if (step + 1 < n_steps) draw_phase(step + 1, pre_mine, pre_nzA, pre_nzB);  // while the granules travel
             DEMC_STAMP(11);  // next phase's blocks drawn
             // every lane collects what ITS particle needs and nothing else: lane sl of the quad polls chunks sl, sl + 4, ...
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
                         for (int i = 0; i < 4; ++i) {
                             const int cc = c0 + 4 * i < p.st_C ? c0 + 4 * i : c0;
                             const unsigned long long* gq = gran + ((size_t)cc * nact_max + q) * 2;
-                            x[i][0] = load_granule(gq);
+x[i][0] = load_granule(gq);
                             x[i][1] = load_granule(gq + 1);
                         }
 #pragma unroll
@@ -467,6 +468,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
         }
         DEMC_STAMP(8);  // (STREAM: cross terms streamed and handed over)
         DEMC_STAMP(19);
+        DEMC_STAMP_AT(23, 0, (double)(__builtin_amdgcn_s_memrealtime() & 0xffffffffull));
         // ---- compute_posterior! + mh_update! + store_samples! (utilities.jl:92-99, 55-58, 201-210, 161-180) ----
         const double w = w_s[pl];
         const double wp = oob ? -INFINITY : prior + (p.c0 - 0.5 * (p.c1 - 2.0 * S + (double)p.N * aux));

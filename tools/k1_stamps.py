@@ -91,5 +91,20 @@ if a.mode == "streaming" and (full[:, 16] > 0).any():
     st = np.median(full[full[:, 16] > 0][:, 16:21], 0)
     print("  streaming-resident: all proposals prepared %.0f; chunk cross terms %.0f; granules stored %.0f; collected %.0f; "
           "accept + moves done %.0f" % tuple(st))
+    if (full[:, 23] > 0).any():  # k_res_mvn: store / collect times of the workgroups of a group on one clock (slots 22, 23)
+        # (blockIdx = j * 8 + xcd; workgroup c of group g = 8 * (j / C) + xcd sits at j = (g / 8) * C + c; the trace holds the first P / 24 blocks)
+        C = 8
+        blk = np.arange(full.shape[0])
+        grp = ((blk >> 3) // C) * 8 + (blk & 7)
+        rows = []
+        for g_ in np.unique(grp):
+            m_ = grp == g_
+            if m_.sum() != C:
+                continue
+            st_, co_ = full[m_, 22], full[m_, 23]
+            rows.append((st_.max() - st_.min(), co_.min() - st_.max(), co_.max() - st_.max()))
+        r_ = np.median(np.array(rows), 0)
+        print("  hand-over on the 100 MHz clock (10 ns ticks), %d whole groups (median): last store - first store %.0f; first collect - last store %.0f; "
+              "last collect - last store %.0f" % ((len(rows),) + tuple(r_)))
     if (full[:, 11] > 0).any():  # k_res_mvn: the next phase's draws sit between the store and the first poll
         print("  next phase's blocks drawn (between store and poll) %.0f" % np.median(full[full[:, 16] > 0][:, 11]))
