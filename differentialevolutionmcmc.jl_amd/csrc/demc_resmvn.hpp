@@ -141,6 +141,9 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
     if (even || (STREAM && p.st_x_lds)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    // the ids of the two particles this quad moves (first half, second half): they only change between launches (migration),
+    // and a load from HBM in the accept stage of every phase is a latency the whole group ends up waiting for
+    const int id_lo = (int)p.id[(size_t)g * Np + (q < half ? q : 0)], id_hi = (int)p.id[(size_t)g * Np + half + (q < Np - half ? q : 0)];
     const double eps = p.eps, eps2 = p.eps - (-p.eps);
     const long long n_steps = (long long)p.n_iters * 2;
     // The addressed draws of a colour phase (the particle's PART block, its NOISE blocks) depend on (seed, iteration, slot)
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
         DEMC_STAMP(7);  // A^-1 product and its dot products
         if (STREAM) {
             // ---- the observation stream: cross terms of the phase's proposals against this workgroup's chunk of tiles ----
-            __syncthreads();
+            lds_barrier();  // (LDS only: see the end of the phase)
             DEMC_STAMP(16);  // every proposal of the phase prepared
             {
                 const int nw_ = WG / 64;
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
                     cross_stage<glb_cptr>((lds_cptr)ybuf, p.dpad, n_act, (glb_cptr)(p.Xf + (size_t)xt_lo * (p.dpad >> 2) * 64), t_lo, t_hi,
                                           p.n_tiles - xt_lo, outw, lane);
             }
-            __syncthreads();
+            lds_barrier();  // (LDS only: see the end of the phase)
             DEMC_STAMP(17);  // cross terms of this workgroup's chunk done
             const unsigned epoch = (unsigned)(step + 1);
             unsigned long long* gran = p.st_gran + (((size_t)(step & 1) * p.n_groups + gi) * p.st_C) * nact_max * 2;
@@ -484,7 +487,7 @@ x[i][0] = load_granule(gq);
                     const size_t hrow = (size_t)store_row * p.P + slot;
                     p.acc_hist[hrow] = (unsigned char)acc;
                     p.lp_hist[hrow] = acc ? wp : w;
-                    p.id_hist[hrow] = (int)p.id[slot];
+                    p.id_hist[hrow] = ph ? id_hi : id_lo;
                 }
             }
             double* trow = p.theta + slot * D;
@@ -515,7 +518,11 @@ x[i][0] = load_granule(gq);
             }
         }
         DEMC_STAMP(9);  // accept + row moves
-        __syncthreads();  // the other colour reads what this phase wrote (rows, weights)
+        // LDS only.  __syncthreads() also waits for this phase's stores to HBM (state, weights, history) to be acknowledged,
+        // which nothing in the kernel reads back: that was 1.7 k cycles of every phase of the SUFFSTAT form, and in the
+        // streaming form it made workgroup 0 of each group -- the one that writes HBM -- 0.4 us late for the next hand-over,
+        // with its seven peers waiting (tools/k1_stamps.py, slots 22 / 23).  Stores to one address stay in issue order.
+        lds_barrier();  // the other colour reads what this phase wrote (rows, weights)
         DEMC_STAMP(10);
     }
 }

@@ -103,6 +103,14 @@ if a.mode == "streaming" and (full[:, 16] > 0).any():
                 continue
             st_, co_ = full[m_, 22], full[m_, 23]
             rows.append((st_.max() - st_.min(), co_.min() - st_.max(), co_.max() - st_.max()))
+        cpos = (blk >> 3) % C
+        whole = np.isin(grp, [g_ for g_ in np.unique(grp) if (grp == g_).sum() == C])
+        first = {g_: full[grp == g_, 22].min() for g_ in np.unique(grp[whole])}
+        rel = np.array([full[i, 22] - first[grp[i]] for i in np.flatnonzero(whole)])
+        relc = np.array([full[i, 23] - first[grp[i]] for i in np.flatnonzero(whole)])
+        print("  store time after the group's first store, by workgroup c (median over groups, 10 ns ticks): " +
+              " ".join("%.0f" % np.median(rel[cpos[whole] == c_]) for c_ in range(C)) + ";  collect: " +
+              " ".join("%.0f" % np.median(relc[cpos[whole] == c_]) for c_ in range(C)))
         r_ = np.median(np.array(rows), 0)
         print("  hand-over on the 100 MHz clock (10 ns ticks), %d whole groups (median): last store - first store %.0f; first collect - last store %.0f; "
               "last collect - last store %.0f" % ((len(rows),) + tuple(r_)))
