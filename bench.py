@@ -315,7 +315,7 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
                   valu_busy_frac=pipes.get("valu_busy_frac"), lds_busy_frac=pipes.get("lds_busy_frac"),
                   measured_valu_insts_per_eval=(pipes["SQ_INSTS_VALU_mean"] * 64.0 / (float(N) * P * k_iters / n_launch)
                                                 if "SQ_INSTS_VALU_mean" in pipes else None), pipe_source=pipes_src,
-                  limiting_pipe="LDS (table reads: 6 look-ups x 80 B x 64 lanes per wave and trial against 128 B/clk per CU) -- see DESIGN section 6",
+                  limiting_pipe="LDS (table reads: 6 look-ups x 5 ds_read_b128 per wave and trial, 4 LDS-array cycles each conflict-free, bank conflicts on top) -- see DESIGN section 6",
                   trial_proposal_evaluations_per_s=evals / t_s, launch_ms=t_s / n_launch * 1e3, launches=n_launch,
                   updates_per_launch=P * k_iters / n_launch, traffic=None, traffic_source=None, wasted_traffic_ratio=None)
     rf["timing"] = "HIP events recorded on the timed iterations, on the stream the kernels run on"
