@@ -678,9 +678,10 @@ __device__ __forceinline__ void cross_loop_lds_2x2(d4& c0, d4& c1, double a00, d
 #undef DEMC_MFMA4
 // ASMLOOP: take the one-statement tile loop where it exists (KS = 2, MT = 2, LDS copy).  Only k_res_mvn asks for it: inside
 // the general k_propose<512,...,STREAM> (164 KB of code, 128 VGPRs + 128 AGPRs once the statement pins accumulators to
-// AGPRs) the dispatch died with HSA_STATUS_ERROR_INVALID_ISA even on shapes that never reach the statement (AGPRs alone are
-// not it: the same kernel with its accumulators forced into AGPRs by an empty "+a" statement runs); not understood, so that
-// kernel keeps the builtin loop it has been tested with.
+// AGPRs) the dispatch died with HSA_STATUS_ERROR_INVALID_ISA even on shapes that never reach the statement.  Narrowed down, not
+// understood: the same kernel runs with its accumulators forced into AGPRs by an empty "+a" statement, and with a statement
+// of LDS reads only; it dies as soon as a statement holds a v_mfma_f64_16x16x4_f64 (aligned operands, no branches, identical
+// kernel descriptor apart from the scratch size, identical opcode set).  That kernel keeps the builtin loop it is tested with.
 template <int KS, int MT, typename XP, bool ASMLOOP = false>
 __device__ inline void cross_tiles(lds_cptr ybuf, int dpad, int n_act, int ptile0, XP xsrc, int ksx, int t_lo, int t_hi, int zt,
                                    lds_ptr out, int lane) {
