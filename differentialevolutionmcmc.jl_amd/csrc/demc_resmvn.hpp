@@ -56,7 +56,10 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
     const int g_glob = p.group_offset + g;
     double* grows = p.theta + (size_t)g * Np * D;
     double* gw = p.weight + (size_t)g * Np;
-    const bool wr_hbm = !STREAM || c_idx == 0;
+    // STREAM: ONE workgroup of the group writes HBM (state, weights, history) -- the one with the LAST chunk of observation
+    // tiles, which is the short one (n_tiles rarely divides by C): its stores cost ~0.25 us per phase, and whoever stores its
+    // hand-over granules last is whom the other seven wait for (tools/k1_stamps.py, slots 22 / 23)
+    const bool wr_hbm = !STREAM || c_idx == p.st_C - 1;
     const bool even = DT > 0 || (D & 1) == 0;
     const int half = Np / 2, nact_max = Np - half;
     // LDS: tile [Np][D] | weights [Np] | cdf [nact_max] + chunk offsets [16] | centred theta' rows [WG/4][D+2] |
