@@ -16,8 +16,9 @@
 //   * SUFFSTAT: the whole update here.  STREAMING (STREAM = true): additionally the observation stream of the
 //     streaming-resident form (C workgroups per group, granule hand-over) -- same protocol as k_propose<...,STREAM>, but
 //     every lane polls the granules of its own particle (no staging, no barrier inside the wait);
-//   * DT = 8 (cfg2): Sigma^-1 (theta' - xbar) on the vector pipe inside the quad, and the tile loop of the observation stage
-//     as one asm statement (cross_loop_lds_2x2: accumulators pinned to AGPRs).
+//   * DT = 8 (cfg2): two scalars per lane (all four lanes of the quad work on the row), Sigma^-1 (theta' - xbar) on the vector
+//     pipe inside the quad, and the tile loop of the observation stage as one asm statement (cross_loop_lds_2x2:
+//     accumulators pinned to AGPRs).
 // Same addressed draws and the same per-scalar arithmetic as k_propose: proposals and decisions are the ones the general
 // kernel produces (tests/test_gpu_parity.py::test_lean_resident_kernel_*); prior sums run in a different lane order
 // (log-densities equal to rounding).
@@ -100,9 +101,12 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
             for (int i = tid; i < (p.dpad >> 2) * 64; i += WG) xs[(size_t)p.st_chunk_tiles * (p.dpad >> 2) * 64 + i] = 0.0;
     }
     // lane geometry: particle slot q = tid / 4 of the pass, lane sl of the particle owns noise blocks m = sl and sl + 4,
-    // i.e. scalars 4 sl .. 4 sl + 3 and 16 + 4 sl .. 16 + 4 sl + 3 (D <= 32)
+    // i.e. scalars 4 sl .. 4 sl + 3 and 16 + 4 sl .. 16 + 4 sl + 3 (D <= 32).  DT == 8: two scalars per lane instead (2 sl,
+    // 2 sl + 1: half of noise block sl / 2) -- all four lanes of the quad work on the row, not two of them on four scalars each
     const int q = tid >> 2, sl = tid & 3;
-    const int jA = 4 * sl, jB = 16 + 4 * sl;  // first scalar of the lane's two blocks
+    constexpr int SPL = DT == 8 ? 2 : 4;                         // scalars per lane and block
+    const int jA = SPL * sl, jB = DT == 8 ? 64 : 16 + 4 * sl;    // first scalar of the lane's two blocks (DT == 8: one)
+    const uint32_t nbA = DT == 8 ? (uint32_t)(sl >> 1) : (uint32_t)sl;  // the NOISE block behind the lane's first scalars
     // xbar of the lane's 8 scalars, and the table segment of each (4 bits apiece; the entries themselves stay in LDS)
     double xb[8];
     unsigned segs = 0;
@@ -162,9 +166,9 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
         const int pl_ = a_lo_ + (q_ < n_act_ ? q_ : 0);
         const uint32_t es = (uint32_t)g_glob * (uint32_t)Np + (uint32_t)pl_;
         mine_o = draw_block(p.seed, S_PART, 0, (uint64_t)iter_, es, (uint32_t)sl_);
-        nzA_o = draw_block(p.seed, S_NOISE, 0, (uint64_t)iter_, es, (uint32_t)sl_);
+        nzA_o = draw_block(p.seed, S_NOISE, 0, (uint64_t)iter_, es, DT == 8 ? (uint32_t)(sl_ >> 1) : (uint32_t)sl_);
         nzB_o = nzA_o;
-        if (16 + 4 * sl_ < D) nzB_o = draw_block(p.seed, S_NOISE, 0, (uint64_t)iter_, es, (uint32_t)(sl_ + 4));
+        if (DT != 8 && 16 + 4 * sl_ < D) nzB_o = draw_block(p.seed, S_NOISE, 0, (uint64_t)iter_, es, (uint32_t)(sl_ + 4));
     };
     if (STREAM) draw_phase(0, pre_mine, pre_nzA, pre_nzB);
     for (long long step = 0; step < n_steps; ++step) {
@@ -218,10 +222,11 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
         const double g1 = 0.5 + (1.0 - 0.5) * u53(rg.x, rg.y);
         const double g2 = use_base ? 0.5 + (1.0 - 0.5) * u53(rg.z, rg.w) : 0.0;
         // noise: block sl (scalars jA..jA+3) and block sl + 4 (scalars jB..jB+3)
-        const U4 nzA = STREAM ? pre_nzA : draw_block(p.seed, S_NOISE, 0, (uint64_t)iter, eslot, (uint32_t)sl);
+        const U4 nzA = STREAM ? pre_nzA : draw_block(p.seed, S_NOISE, 0, (uint64_t)iter, eslot, nbA);
         U4 nzB = STREAM ? pre_nzB : nzA;
         if (!STREAM && jB < D) nzB = draw_block(p.seed, S_NOISE, 0, (uint64_t)iter, eslot, (uint32_t)(sl + 4));
-        const uint32_t nw[8] = {nzA.x, nzA.y, nzA.z, nzA.w, nzB.x, nzB.y, nzB.z, nzB.w};
+        const bool hi2 = DT == 8 && (sl & 1);  // (DT == 8: the lane's two scalars are the second half of the block)
+        const uint32_t nw[8] = {hi2 ? nzA.z : nzA.x, hi2 ? nzA.w : nzA.y, nzA.z, nzA.w, nzB.x, nzB.y, nzB.z, nzB.w};
 
         DEMC_STAMP(1);  // particle and noise blocks drawn
         int ibase = 0;
@@ -259,8 +264,11 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
         DimTab tb1 = s_seg[0].t;
         tb1.lo = uni(tb1.lo); tb1.hi = uni(tb1.hi); tb1.a = uni(tb1.a); tb1.b = uni(tb1.b); tb1.c = uni(tb1.c);
         tb1.kind = __builtin_amdgcn_readfirstlane(tb1.kind);
-        auto load4 = [&](const double* row, int j0, double (&o)[4]) {  // four consecutive scalars of a tile row
-            if (even && j0 + 3 < D) {
+        auto load4 = [&](const double* row, int j0, double (&o)[4]) {  // four (DT == 8: two) consecutive scalars of a tile row
+            if constexpr (DT == 8) {
+                const double2 a = *reinterpret_cast<const double2*>(row + j0);
+                o[0] = a.x; o[1] = a.y;
+            } else if (even && j0 + 3 < D) {
                 const double2 a = *reinterpret_cast<const double2*>(row + j0), b = *reinterpret_cast<const double2*>(row + j0 + 2);
                 o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
             } else
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
         double zz[8];  // mutation sweeps only: the standard normals of the lane's scalars
         if (is_mut) {
 #pragma unroll
-            for (int pe = 0; pe < 4; ++pe) {
+            for (int pe = 0; pe < (DT == 8 ? 1 : 4); ++pe) {
                 const double2 z = box_muller_outofline(nw[2 * pe], nw[2 * pe + 1]);
                 zz[2 * pe] = z.x;
                 zz[2 * pe + 1] = z.y;
@@ -290,7 +298,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
                 if (use_base) load4(Pc, j0, cc);
             }
 #pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4) {
+            for (int e4 = 0; e4 < SPL; ++e4) {
                 const int e = 4 * blk + e4, j = j0 + e4;
                 if (j < D) {
                     const double tj = tt[e4];
@@ -336,25 +344,22 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
         }
         double aux, S = 0.0;
         if constexpr (DIRECT8) {
-            // d = 8: the 8 x 8 product on the vector pipe inside the quad -- lanes 0 and 1 hold the centred scalars 0..3 and
-            // 4..7, quad_perm hands them round, lane sl forms columns 2 sl and 2 sl + 1 (16 FMAs) and its share of theta~.y.
+            // d = 8: the 8 x 8 product on the vector pipe inside the quad -- lane m holds the centred scalars 2 m and 2 m + 1,
+            // quad_perm hands them round, lane sl forms columns 2 sl and 2 sl + 1 (16 FMAs) and its share of theta~.y.
             // The MFMA route (LDS transposition, two matrix instructions, four 16-lane reductions, LDS again) is a chain
             // of ~2.3 k cycles for 64 FMAs per particle.
+            const double c0_ = v8[0] - xb[0], c1_ = v8[1] - xb[1];
             double c[8];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const double ce = v8[e] - xb[e];
-                c[e] = dpp_mov<0x00>(ce);      // quad_perm:[0,0,0,0]
-                c[4 + e] = dpp_mov<0x55>(ce);  // quad_perm:[1,1,1,1]
-            }
+            c[0] = dpp_mov<0x00>(c0_); c[1] = dpp_mov<0x00>(c1_);  // quad_perm:[0,0,0,0]
+            c[2] = dpp_mov<0x55>(c0_); c[3] = dpp_mov<0x55>(c1_);  // quad_perm:[1,1,1,1]
+            c[4] = dpp_mov<0xAA>(c0_); c[5] = dpp_mov<0xAA>(c1_);  // quad_perm:[2,2,2,2]
+            c[6] = dpp_mov<0xFF>(c0_); c[7] = dpp_mov<0xFF>(c1_);  // quad_perm:[3,3,3,3]
             double y0 = 0.0, y1 = 0.0;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 y0 = fma(c[k], ai8[0][k], y0);
                 y1 = fma(c[k], ai8[1][k], y1);
             }
-            const double c0_ = sl == 0 ? c[0] : sl == 1 ? c[2] : sl == 2 ? c[4] : c[6];
-            const double c1_ = sl == 0 ? c[1] : sl == 1 ? c[3] : sl == 2 ? c[5] : c[7];
             aux = subgroup_sum(fma(c1_, y1, c0_ * y0), 4);
             if (!STREAM)
                 S = subgroup_sum(fma(y1, sx8[1], y0 * sx8[0]), 4);
@@ -501,7 +506,14 @@ x[i][0] = load_granule(gq);
                 const int j = blk ? jB : jA;
                 if (j >= D) continue;
                 if (!acc && !hrow) continue;
-                if (j + 3 < D && (D & 3) == 0) {  // whole block: 32-byte accesses (a rejected particle's row comes from the tile)
+                if constexpr (DT == 8) {  // the lane's two scalars: one 16-byte access each way
+                    const double2 a01 = acc ? make_double2(v8[0], v8[1]) : *reinterpret_cast<const double2*>(lrow + j);
+                    if (acc) {
+                        *reinterpret_cast<double2*>(lrow + j) = a01;
+                        if (wr_hbm) *reinterpret_cast<double2*>(trow + j) = a01;
+                    }
+                    if (hrow) *reinterpret_cast<double2*>(hrow + j) = a01;
+                } else if (j + 3 < D && (D & 3) == 0) {  // whole block: 32-byte accesses (a rejected particle's row comes from the tile)
                     const double2 a01 = acc ? make_double2(v8[4 * blk], v8[4 * blk + 1]) : *reinterpret_cast<const double2*>(lrow + j);
                     const double2 a23 = acc ? make_double2(v8[4 * blk + 2], v8[4 * blk + 3]) : *reinterpret_cast<const double2*>(lrow + j + 2);
                     if (acc) {
