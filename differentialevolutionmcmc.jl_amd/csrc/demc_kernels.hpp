@@ -735,14 +735,23 @@ __device__ inline void cross_tiles(lds_cptr ybuf, int dpad, int n_act, int ptile
                 acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt][ks], b1[ks], acc[mt], 0, 0, 0);
     }
     }
+    // A lane holds four rows of a result tile (particles (lane >> 4) + 4 r), each to be summed over the 16 lanes of its group.
+    // Folded as a transposition instead of four separate 16-lane sums: lanes exchange the half of their rows they give up
+    // (xor 1: rows {0,1} <-> {2,3}; xor 2: one row each), then the four quads of the group add up (row_ror 4, 8) -- 5 exchanges
+    // and 5 additions per tile instead of 16 and 16.  Lane l ends with row 2 (l & 1) + ((l >> 1) & 1); a fixed tree, same bits
+    // in every workgroup.
+    const bool b0 = lane & 1, b1 = lane & 2;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double v = subgroup_sum(acc[mt][r], 16);
-            const int q = (ptile0 + mt) * 16 + (lane >> 4) + 4 * r;
-            if ((lane & 15) == 0 && q < n_act) out[q] = v;
-        }
+    for (int mt = 0; mt < MT; ++mt) {
+        const d4 v = acc[mt];
+        const double k0 = b0 ? v[2] : v[0], k1 = b0 ? v[3] : v[1], s0 = b0 ? v[0] : v[2], s1 = b0 ? v[1] : v[3];
+        const double r0 = k0 + dpp_mov<kDppXor1>(s0), r1 = k1 + dpp_mov<kDppXor1>(s1);
+        double u = (b1 ? r1 : r0) + dpp_mov<kDppXor2>(b1 ? r0 : r1);
+        u += dpp_mov<0x124>(u);  // row_ror:4
+        u += dpp_mov<0x128>(u);  // row_ror:8
+        const int q = (ptile0 + mt) * 16 + (lane >> 4) + 4 * (2 * (lane & 1) + ((lane >> 1) & 1));
+        if ((lane & 12) == 0 && q < n_act) out[q] = u;
+    }
 }
 // particle tiles in groups of MT (registers: KS x MT fragments), as few accumulators as the tiles need
 template <int KS, typename XP, bool ASMLOOP = false>
