@@ -450,19 +450,20 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
             if (valid) {
                 double part = 0.0;
                 unsigned spins = 0;
-                for (int c0 = sl; c0 < p.st_C; c0 += 16) {  // up to four chunks (eight granules) in flight per lane
-                    unsigned long long x[4][2];
+                auto collect = [&](auto ns_c, int c0) {  // NS chunks of this lane (c0, c0 + 4, ...): 2 NS granules in flight
+                    constexpr int NS = decltype(ns_c)::value;
+                    unsigned long long x[NS][2];
                     for (;;) {
                         bool ok = true;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
+                        for (int i = 0; i < NS; ++i) {
                             const int cc = c0 + 4 * i < p.st_C ? c0 + 4 * i : c0;
                             const unsigned long long* gq = gran + ((size_t)cc * nact_max + q) * 2;
-x[i][0] = load_granule(gq);
+                            x[i][0] = load_granule(gq);
                             x[i][1] = load_granule(gq + 1);
                         }
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) ok &= (unsigned)(x[i][0] >> 32) == epoch && (unsigned)(x[i][1] >> 32) == epoch;
+                        for (int i = 0; i < NS; ++i) ok &= (unsigned)(x[i][0] >> 32) == epoch && (unsigned)(x[i][1] >> 32) == epoch;
                         if (ok) break;
                         if (++spins > (1u << 22)) {  // cannot happen with co-resident workgroups; never spin unbounded
                             *p.st_err = 1u;
@@ -471,8 +472,12 @@ x[i][0] = load_granule(gq);
                         __builtin_amdgcn_s_sleep(1);
                     }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < NS; ++i)
                         if (c0 + 4 * i < p.st_C) part += __hiloint2double((int)(unsigned)x[i][1], (int)(unsigned)x[i][0]);
+                };
+                for (int c0 = sl; c0 < p.st_C; c0 += 16) {
+                    if (p.st_C <= 8) collect(std::integral_constant<int, 2>(), c0);  // (cfg2: two chunks per lane)
+                    else collect(std::integral_constant<int, 4>(), c0);
                 }
                 S = subgroup_sum(part, 4);
             }
