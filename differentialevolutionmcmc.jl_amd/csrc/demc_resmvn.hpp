@@ -469,7 +469,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
                             *p.st_err = 1u;
                             break;
                         }
-                        __builtin_amdgcn_s_sleep(1);
+                        __builtin_amdgcn_s_sleep(1);  // (without it: the same)
                     }
 #pragma unroll
                     for (int i = 0; i < NS; ++i)
