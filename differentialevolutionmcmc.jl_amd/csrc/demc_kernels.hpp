@@ -205,6 +205,21 @@ __device__ inline T subgroup_sum(T v, int lpp) {
     if (lpp >= 64) v += __shfl_xor(v, 32);
     return v;
 }
+// A lane holds four values v[0..3], one for each of four ROWS, and every row is to be summed over the 16 lanes of the lane's
+// group (the layout of a v_mfma_f64_16x16x4_f64 result: rows (lane >> 4) + 4 r, column lane & 15).  Folded as a transposition
+// instead of four separate 16-lane sums: lanes exchange the half of their rows they give up (xor 1: rows {0,1} <-> {2,3};
+// xor 2: one row each), then the four quads of the group add up (row_ror 4, 8) -- 5 exchanges and 5 additions instead of 16
+// and 16.  Every lane returns the sum of row fold4_row(lane); a fixed tree (the same bits wherever it runs).
+__device__ inline int fold4_row(int lane) { return 2 * (lane & 1) + ((lane >> 1) & 1); }
+__device__ inline double fold4_over16(double v0, double v1, double v2, double v3, int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    const double k0 = b0 ? v2 : v0, k1 = b0 ? v3 : v1, s0 = b0 ? v0 : v2, s1 = b0 ? v1 : v3;
+    const double r0 = k0 + dpp_mov<kDppXor1>(s0), r1 = k1 + dpp_mov<kDppXor1>(s1);
+    double u = (b1 ? r1 : r0) + dpp_mov<kDppXor2>(b1 ? r0 : r1);
+    u += dpp_mov<0x124>(u);  // row_ror:4
+    u += dpp_mov<0x128>(u);  // row_ror:8
+    return u;
+}
 // lpp == blockDim (256 or 512): one particle spans the whole workgroup (very large D); the sum crosses the waves through
 // LDS and is formed as a fixed tree over pairs of waves.  Must be called by every thread of the workgroup (the particle --
 // hence the control flow -- is workgroup-uniform then).
@@ -735,21 +750,11 @@ __device__ inline void cross_tiles(lds_cptr ybuf, int dpad, int n_act, int ptile
                 acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt][ks], b1[ks], acc[mt], 0, 0, 0);
     }
     }
-    // A lane holds four rows of a result tile (particles (lane >> 4) + 4 r), each to be summed over the 16 lanes of its group.
-    // Folded as a transposition instead of four separate 16-lane sums: lanes exchange the half of their rows they give up
-    // (xor 1: rows {0,1} <-> {2,3}; xor 2: one row each), then the four quads of the group add up (row_ror 4, 8) -- 5 exchanges
-    // and 5 additions per tile instead of 16 and 16.  Lane l ends with row 2 (l & 1) + ((l >> 1) & 1); a fixed tree, same bits
-    // in every workgroup.
-    const bool b0 = lane & 1, b1 = lane & 2;
+    // four rows per lane, each summed over its 16-lane group: fold4_over16 (a transposition, not four separate sums)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const d4 v = acc[mt];
-        const double k0 = b0 ? v[2] : v[0], k1 = b0 ? v[3] : v[1], s0 = b0 ? v[0] : v[2], s1 = b0 ? v[1] : v[3];
-        const double r0 = k0 + dpp_mov<kDppXor1>(s0), r1 = k1 + dpp_mov<kDppXor1>(s1);
-        double u = (b1 ? r1 : r0) + dpp_mov<kDppXor2>(b1 ? r0 : r1);
-        u += dpp_mov<0x124>(u);  // row_ror:4
-        u += dpp_mov<0x128>(u);  // row_ror:8
-        const int q = (ptile0 + mt) * 16 + (lane >> 4) + 4 * (2 * (lane & 1) + ((lane >> 1) & 1));
+        const double u = fold4_over16(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3], lane);
+        const int q = (ptile0 + mt) * 16 + (lane >> 4) + 4 * fold4_row(lane);
         if ((lane & 12) == 0 && q < n_act) out[q] = u;
     }
 }

@@ -380,6 +380,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
                     acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[0][ks], acc0, 0, 0, 0);
                     if (two_tiles) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[1][ks], acc1, 0, 0, 0);
                 }
+            double a4[4], s4[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int pr = kq + 4 * r;
@@ -395,11 +396,16 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
                     if (mc0 < d) yrow[mc0] = y0;
                     if (mc1 < d) yrow[mc1] = y1;
                 }
-                a_ = subgroup_sum(a_, 16);
-                s_ = subgroup_sum(s_, 16);
-                if (rowi == 0) {
-                    tr[D] = a_;
-                    tr[D + 1] = s_;
+                a4[r] = a_;
+                s4[r] = s_;
+            }
+            {  // the four rows' dot products summed over their 16 columns: one fold each (fold4_over16), not four sums each
+                const double af = fold4_over16(a4[0], a4[1], a4[2], a4[3], lane);
+                const double sf = STREAM ? 0.0 : fold4_over16(s4[0], s4[1], s4[2], s4[3], lane);
+                if ((lane & 12) == 0) {
+                    double* tr = scr + (size_t)(wrow0 + kq + 4 * fold4_row(lane)) * scr_stride;
+                    tr[D] = af;
+                    tr[D + 1] = sf;
                 }
             }
             wave_lds_sync();
