@@ -638,7 +638,7 @@ typedef __attribute__((address_space(1))) const double* glb_cptr;
 // against 64 for the bare chain (tools/mfma_f64_chain.hip, tools/cross_stage_bench.hip).  Here the accumulators are operands
 // of the one statement, so they stay in AGPRs from the first tile to the last.  n >= 1 tiles from LDS byte address va
 // (the lane's element of tile 0; a tile is 2 k-steps x 64 lanes x 8 bytes); two register sets in ping-pong, one tile always
-// in flight, every load in bounds.  Per accumulator the products are added in the order of the builtin loop: same bits.
+// in flight, every load in bounds; four-tile trips first, then at most one two-tile trip, then a tail of one or two tiles.  Per accumulator the products are added in the order of the builtin loop: same bits.
 // Wait states (cdna_hip_programming.md 5.7): two before the first MFMA reads operands the compiler has just written (s_nop 1);
 // MFMA -> MFMA taking D whole as C: none; D -> any other reader: 18 for this 16-pass instruction (s_nop 15 + s_nop 7 closing
 // the string).  Every ds_read of the statement has landed (lgkmcnt(0)) before its last MFMA group issues.
@@ -649,12 +649,38 @@ typedef __attribute__((address_space(1))) const double* glb_cptr;
     "v_mfma_f64_16x16x4_f64 %[c1], %[a11], %[" #by "], %[c1]\n\t"
 __device__ __forceinline__ void cross_loop_lds_2x2(d4& c0, d4& c1, double a00, double a01, double a10, double a11, unsigned va, int n) {
     double p0, p1, q0, q1;    // the two register sets: k-steps 0 and 1 of a tile
-    int np = (n - 1) >> 1;    // two-tile trips; they leave one or two tiles for the tail
-    const int two = n - 2 * np - 1;  // 1: the tail has two tiles
+    int nq = (n - 1) >> 2;    // four-tile trips (one vector instruction per sixteen MFMAs); they leave one to four tiles
+    const int r = n - 4 * nq;
+    int np = (r - 1) >> 1;    // then two-tile trips (none or one); they leave one or two tiles for the tail
+    const int two = r - 2 * np - 1;  // 1: the tail has two tiles
     asm volatile(
         "s_nop 1\n\t"
         "ds_read_b64 %[p0], %[va]\n\t"
         "ds_read_b64 %[p1], %[va] offset:512\n\t"
+        "s_cmp_eq_u32 %[nq], 0\n\t"
+        "s_cbranch_scc1 6f\n"
+        "5:\n\t"
+        "ds_read_b64 %[q0], %[va] offset:1024\n\t"
+        "ds_read_b64 %[q1], %[va] offset:1536\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t"
+        DEMC_MFMA4(p0, p1)
+        "ds_read_b64 %[p0], %[va] offset:2048\n\t"
+        "ds_read_b64 %[p1], %[va] offset:2560\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t"
+        DEMC_MFMA4(q0, q1)
+        "ds_read_b64 %[q0], %[va] offset:3072\n\t"
+        "ds_read_b64 %[q1], %[va] offset:3584\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t"
+        DEMC_MFMA4(p0, p1)
+        "ds_read_b64 %[p0], %[va] offset:4096\n\t"
+        "ds_read_b64 %[p1], %[va] offset:4608\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t"
+        DEMC_MFMA4(q0, q1)
+        "v_add_u32 %[va], 0x1000, %[va]\n\t"
+        "s_sub_u32 %[nq], %[nq], 1\n\t"
+        "s_cmp_lg_u32 %[nq], 0\n\t"
+        "s_cbranch_scc1 5b\n"
+        "6:\n\t"
         "s_cmp_eq_u32 %[np], 0\n\t"
         "s_cbranch_scc1 2f\n"
         "1:\n\t"
@@ -686,7 +712,7 @@ __device__ __forceinline__ void cross_loop_lds_2x2(d4& c0, d4& c1, double a00, d
         "4:\n\t"
         "s_nop 15\n\t"
         "s_nop 7"
-        : [c0] "+a"(c0), [c1] "+a"(c1), [p0] "=&v"(p0), [p1] "=&v"(p1), [q0] "=&v"(q0), [q1] "=&v"(q1), [va] "+v"(va), [np] "+s"(np)
+        : [c0] "+a"(c0), [c1] "+a"(c1), [p0] "=&v"(p0), [p1] "=&v"(p1), [q0] "=&v"(q0), [q1] "=&v"(q1), [va] "+v"(va), [np] "+s"(np), [nq] "+s"(nq)
         : [a00] "v"(a00), [a01] "v"(a01), [a10] "v"(a10), [a11] "v"(a11), [two] "s"(two)
         : "scc", "memory");
 }
