@@ -166,13 +166,32 @@ def spawn_ranks(a):
             print(f"---- rank {r} stderr (tail) ----\n{t}", file=sys.stderr)
         sys.stderr.flush()
 
+    def clear_rank_files():
+        for r in range(a.gpus):
+            try:
+                os.remove(rank_file(r))
+            except OSError:
+                pass
+
+    clear_rank_files()
     res = launch([], {})
     if res["rc"] == EXIT_INIT and a.collective == "library":
         report(res, "library collective failed at communicator creation, starting fresh ranks with --collective torch")
         why = f"library collective: {res['reason']}"
+        clear_rank_files()
         res = launch(["--collective", "torch"], {"DEMC_BENCH_COLLECTIVE_FALLBACK": why})
     if res["rc"] != 0:
         report(res, f"{a.gpus}-rank run FAILED")
+        recs = []
+        for r in range(a.gpus):
+            try:
+                recs.append(json.load(open(rank_file(r))))
+            except (OSError, ValueError):
+                pass
+        if len(recs) == a.gpus:  # every rank got through its timed region: their numbers are not lost with the run
+            line = merge_rank_files(recs, f"run failed after the timed region ({res['reason']}); merged from gpurun_out/rank<r>.json")
+            if line:
+                print(line, flush=True)
         raise SystemExit(res["rc"] if 0 < res["rc"] < 256 else 1)
     sys.stdout.write(res["stdout0"] + ("\n" if res["stdout0"] and not res["stdout0"].endswith("\n") else ""))
     sys.stdout.flush()
@@ -809,7 +828,9 @@ def dict_args(a, **over):
 def run_rows(a, w_headline, demc_amd, local, budget_s=120.0):
     want = None if a.rows in (None, "all") else set(a.rows.split(","))
     rows, t0 = [], time.perf_counter()
-    cache = {("cfg3", None): w_headline} if a.config == "cfg3" and a.n_groups is None and a.Np is None and a.nobs is None and a.dim is None else {}
+    # the headline's workload is reused only when it IS the plain one: sampler flags (--snooker ...) ride in w["engine"], and a
+    # row that inherited them would be labelled and profile-tagged as the plain row while running another kernel
+    cache = {("cfg3", None): w_headline} if is_plain_headline(a) else {}
     for name, over in ROWS:
         if want is not None and name not in want:
             continue
@@ -824,10 +845,141 @@ def run_rows(a, w_headline, demc_amd, local, budget_s=120.0):
             wl = cache[key]
             if b.snooker is not None:  # (the sampler's settings ride in the workload's engine dict: a copy with this row's)
                 wl = dict(wl, engine=dict(wl["engine"], theta_snooker=b.snooker))
+            elif b.config in ("cfg2", "cfg3"):  # (cfg5's own theta_snooker = 0.1 is its workload's; the MvNormal rows' default is 0)
+                assert not wl["engine"].get("theta_snooker"), (name, wl["engine"])
             rows.append(measure_row(name, b, wl, demc_amd, local))
         except Exception as e:  # a row that fails is reported as failed; the headline stands
             rows.append(dict(name=name, error=f"{type(e).__name__}: {e}"[:500]))
     return rows
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# what the run prints: ONE compact last line (what a harness keeps: it holds on to the last few KB of stdout), with
+# everything verbose on an EARLIER line tagged {"detail": ...} and in gpurun_out/bench_detail.json
+# ----------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 6000   # bytes of the last stdout line (round 4's 23 KB line was cut off by the driver's 8 KB tail)
+DETAIL_FILE = os.path.join("gpurun_out", "bench_detail.json")
+ROW_KEYS = ("frac", "launch_ms", "bound", "traffic")  # of a row's roofline, next to name / value / ms_per_step / steps
+
+
+def sig(x, n=5):
+    """numbers to n significant digits (bools, ints, None and strings untouched); containers recursively"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{n}g}")
+    if isinstance(x, dict):
+        return {k: sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [sig(v, n) for v in x]
+    return sig(float(x), n)
+
+
+def short(s, n):
+    return s if s is None or len(s) <= n else s[:n - 3] + "..."
+
+
+def compact_row(r):
+    if "value" not in r:
+        return {k: (short(v, 80) if isinstance(v, str) else v) for k, v in r.items() if k in ("name", "skipped", "error")}
+    rf = r.get("roofline") or {}
+    c = dict(name=r["name"], value=r["value"], ms_per_step=r["ms_per_step"], steps=r["steps"])
+    c.update({k: rf.get(k) for k in ROW_KEYS})
+    if rf.get("counter_frac") is not None:  # (HBM-bound rows that quote the formula in `frac`: the counters' fraction beside it)
+        c["counter_frac"] = rf["counter_frac"]
+    return sig(c)
+
+
+def compact_line(out):
+    """the last stdout line: the contract's fields + roofline + cpu_baseline + headline_context + numeric-only rows, no prose"""
+    cfg, rf, cpu, ctx, acc = out["config"], out.get("roofline"), out.get("cpu_baseline"), out.get("headline_context"), out.get("accuracy") or {}
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data")}
+    line["config"] = dict(workload=short(cfg["workload"], 200), particles_per_gpu=cfg["particles_per_gpu"],
+                          block_sweeps_per_step=cfg["block_sweeps_per_step"], parallelism=short(cfg["parallelism"], 60),
+                          collective=short(cfg.get("collective"), 60), collective_fallback=short(cfg.get("collective_fallback"), 80),
+                          rccl_nranks=cfg.get("rccl_nranks"), all_gathers_per_rank=cfg.get("all_gathers_per_rank"),
+                          ms_per_step_min_over_ranks=cfg.get("ms_per_step_min_over_ranks"),
+                          ms_per_step_max_over_ranks=cfg.get("ms_per_step_max_over_ranks"))
+    line["particle_parameter_updates_per_s"] = out["particle_parameter_updates_per_s"]
+    line["accuracy"] = dict(posterior_mean_l1_rel=acc.get("posterior_mean_l1_rel"),
+                            max_abs_err_in_posterior_sd=acc.get("max_abs_err_in_posterior_sd"),
+                            accept_rate=(acc.get("timed_chain") or {}).get("accept_rate"))
+    line["roofline"] = None if rf is None else dict(
+        {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "launch_ms", "launches", "traffic", "wasted_traffic_ratio",
+                                "device_ms_per_iter", "counter_frac")}, kernel=short(rf.get("kernel"), 60))
+    line["cpu_baseline"] = None if cpu is None else dict(
+        {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "value_single_thread", "cpu_model")}, sample=short(cpu.get("sample"), 160))
+    line["headline_context"] = None if ctx is None else {k: ctx.get(k) for k in ("direct_value", "direct_frac", "cpu_baseline_like_for_like_ratio")}
+    rows = out.get("rows")
+    line["rows"] = None if rows is None else [compact_row(r) for r in rows]
+    line["detail"] = DETAIL_FILE
+    line = sig(line)
+    text = json.dumps(line, separators=(",", ":"))
+    while len(text) > LINE_LIMIT and line["rows"]:  # (cannot happen with ROWS as it is -- tests/test_host.py -- but never print a long line)
+        line["rows"] = line["rows"][:-1]
+        line["rows_truncated"] = True
+        text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:
+        raise RuntimeError(f"bench.py: the final line is {len(text)} bytes (> {LINE_LIMIT})")
+    return text
+
+
+def rank_file(rank):
+    return os.path.join(ROOT, "gpurun_out", f"rank{rank}.json")
+
+
+def write_rank_file(rank, rec):
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        tmp = rank_file(rank) + ".tmp"
+        with open(tmp, "w") as f:
+            json.dump(rec, f)
+        os.replace(tmp, rank_file(rank))
+    except OSError as e:
+        sys.stderr.write(f"bench.py rank {rank}: could not write {rank_file(rank)}: {e}\n")
+
+
+def merge_rank_files(recs, why):
+    """a line from the per-rank files alone (every rank timed its own K steps between the two barriers): what the parent
+    prints when the ranks finished the timed region but the run did not get as far as rank 0's own line.  Marked partial:
+    no roofline / cpu_baseline (those are rank 0's after the teardown)."""
+    recs = sorted(recs, key=lambda r: r["rank"])
+    world = recs[0]["world"]
+    if [r["rank"] for r in recs] != list(range(world)):
+        return None
+    dt = max(r["seconds_timed"] for r in recs)
+    steps = recs[0]["steps"]
+    units = sum(r["particles"] * r["block_sweeps_per_step"] for r in recs) * steps
+    out = {"metric": "particle-updates/sec (proposal+loglike+accept) at D=32, N=1e5" if recs[0]["config"] == "cfg3" else
+                     f"particle-updates/sec (proposal+loglike+accept), {recs[0]['config']}",
+           "value": units / dt, "unit": "particle-updates/s", "n_gpus": world, "steps": steps, "warmup": recs[0]["warmup"],
+           "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+           "data": "synthetic", "partial": short(why, 200),
+           "config": {"workload": short(recs[0]["workload"], 200), "particles_per_gpu": recs[0]["particles"],
+                      "collective": recs[0]["collective"], "collective_fallback": short(recs[0]["collective_fallback"], 80),
+                      "rccl_nranks": recs[0]["rccl_nranks"], "all_gathers_per_rank": [r["all_gathers"] for r in recs],
+                      "ms_per_step_min_over_ranks": min(r["ms_per_step"] for r in recs),
+                      "ms_per_step_max_over_ranks": max(r["ms_per_step"] for r in recs)},
+           "roofline": None, "cpu_baseline": None, "rows": None}
+    text = json.dumps(sig(out), separators=(",", ":"))
+    assert len(text) <= LINE_LIMIT
+    return text
+
+
+def emit(out):
+    """detail first (a tagged stdout line + a file under gpurun_out/), the compact line LAST"""
+    detail = json.dumps({"detail": out})
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, DETAIL_FILE), "w") as f:
+            f.write(json.dumps(out, indent=1))
+    except OSError:
+        pass
+    print(detail, flush=True)
+    print(compact_line(out), flush=True)
 
 
 def main():
@@ -950,9 +1102,16 @@ def main():
     elif not a.no_roofline:
         tm = eng.timing_read()
         eng.timing_enable(False)
-    stage("reduce", 120.0)
     cstats = eng.comm_stats() if library else None
     n_gathers = cstats["exchanges"] if library else (drv.n_exchanges if multi else 0)
+    if multi:  # every rank's own numbers on disk BEFORE the next collective: a late hang still leaves them (merge_rank_files)
+        write_rank_file(rank, dict(rank=rank, world=world, steps=a.steps, warmup=a.warmup, seconds_timed=dt_own,
+                                   ms_per_step=dt_own / a.steps * 1e3, particles=P,
+                                   block_sweeps_per_step=1 if w["masks"] is None else len(w["masks"]),
+                                   all_gathers=n_gathers, rccl_nranks=None if cstats is None else cstats["world"],
+                                   collective="library" if library else "torch", collective_fallback=fallback,
+                                   workload=describe(a, w, world), config=a.config))
+    stage("reduce", 120.0)
     dt = reduce([dt_own], "max")[0]  # MAX over ranks
     dt_min = reduce([dt_own], "min")[0]
     per_rank_gathers = [int(x) for x in reduce([n_gathers if r == rank else 0 for r in range(world)], "sum")]
@@ -1026,7 +1185,7 @@ def main():
             "particle_iterations_per_s": P * world * a.steps / dt,  # (value counts every block sweep as an update: cfg4 has two)
             "accuracy": accuracy, "roofline": roofline, "headline_context": context, "cpu_baseline": cpu, "rows": rows,
         }
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -338,5 +338,11 @@ def test_bench_under_the_drivers_launcher_with_the_library_collective():
                           "--n-groups", "16", "--nobs", "4000", "--dim", "8", "--accuracy-iters", "0", "--no-cpu-baseline"],
                          capture_output=True, text=True, timeout=600, env=env)  # (no --np: the launcher's parser claims it as an abbreviation)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
-    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    r, line = json.loads(lines[0])["detail"], json.loads(lines[-1])
     assert "demc_comm_init" in r["config"]["collective"] and r["config"]["all_gathers_rank0"] >= 1 and r["n_gpus"] == 1
+    # the multi-rank line is the same compact one: what the first N > 1 run prints cannot outgrow the harness either
+    assert len(lines[-1]) < 6000 and line["config"]["rccl_nranks"] == 1 and line["config"]["all_gathers_per_rank"][0] >= 1
+    assert line["config"]["ms_per_step_min_over_ranks"] <= line["config"]["ms_per_step_max_over_ranks"]
+    rec = json.load(open(os.path.join(ROOT, "gpurun_out", "rank0.json")))  # written before the first collective after the timed region
+    assert rec["world"] == 1 and rec["all_gathers"] == line["config"]["all_gathers_per_rank"][0] and rec["rccl_nranks"] == 1

@@ -351,3 +351,99 @@ def test_committed_counter_summaries_belong_to_the_sources_that_ship():
     for name in ["headline"] + [n for n, _ in bench.ROWS]:
         for suffix in ("pmc.json", "kernel_stats.csv", "line.json"):
             assert os.path.exists(os.path.join(ROOT, "profiles", bench.PROFILE_ROUND, f"bench_{name}_{suffix}")), (name, suffix)
+
+
+def _fake_bench_result(bench, n_gpus=1, n_rows=None):
+    """a result object shaped like main()'s `out`, with prose as long as the real one's (round 4's 23 KB line) and one row per
+    entry of bench.ROWS"""
+    prose = "x" * 600
+    rf = dict(bound="mfma", kernel="k_cross_mfma<8,4> (v_mfma_f64_16x16x4_f64)" + prose, achieved=75.85414595078859, peak=78.6,
+              unit="TFLOP/s", frac=0.9650654701118142, flop_counted=prose, what_is_streamed=prose, launch_ms=2.7647163826227192,
+              launches=400, traffic=102952178.93877551, traffic_source=prose, wasted_traffic_ratio=3.0290201628373694, timing=prose,
+              per_kernel_ms_per_iter=dict(propose=0.0431, loglike=5.5294), device_ms_per_iter=5.596939020240679)
+    rows = [dict(name=name, workload=prose, value=4973723.868929676, unit="particle-updates/s", ms_per_step=13.176445200224407,
+                 steps=20, warmup=5, kernels=prose, accept_rate=0.408, finite_weights=True, roofline=dict(rf), seconds=0.91)
+            for name, _ in bench.ROWS][:n_rows]
+    rows.append(dict(name="a_row_that_failed", error="RuntimeError: " + prose))
+    return {"metric": "particle-updates/sec (proposal+loglike+accept) at D=32, N=1e5", "value": 11631628.466947727,
+            "unit": "particle-updates/s", "n_gpus": n_gpus, "steps": 200, "warmup": 50, "ms_per_step": 5.634292754984926,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": prose, "particles_per_gpu": 65536, "block_sweeps_per_step": 1, "parallelism": prose,
+                       "collective": None if n_gpus == 1 else prose, "collective_fallback": None,
+                       "rccl_nranks": None if n_gpus == 1 else n_gpus, "all_gathers_rank0": 21, "all_gathers_per_rank": [21] * n_gpus,
+                       "ms_per_step_min_over_ranks": 5.61, "ms_per_step_max_over_ranks": 5.634292754984926},
+            "particle_parameter_updates_per_s": 372212110.94232726, "particle_iterations_per_s": 11631628.466947727,
+            "accuracy": dict(timed_chain=dict(accept_rate=0.2288818359375, note=prose), posterior_mean_l1_rel=9.978460843456112e-06,
+                             max_abs_err_in_posterior_sd=0.00976138608426626, leg=prose),
+            "roofline": rf, "headline_context": dict(direct_value=4973723.868929676, direct_frac=0.6034435300919369,
+                                                     cpu_baseline_like_for_like_ratio=208.3003426819826, note=prose),
+            "cpu_baseline": dict(value=23877.65572005412, unit="particle-updates/s", cores=16, kind="port",
+                                 value_single_thread=1737.3869838033977, cpu_model="AMD EPYC 9575F 64-Core Processor", sample=prose),
+            "rows": rows if n_gpus == 1 else None}
+
+
+def test_bench_final_line_fits_what_a_harness_keeps(capsys):
+    """round 4's record was lost to a 23 KB line: the LAST stdout line is one JSON object under bench.LINE_LIMIT bytes that
+    carries the contract's fields, roofline, cpu_baseline, headline_context and every row as numbers; the prose goes to an earlier
+    {"detail": ...} line and to gpurun_out/bench_detail.json"""
+    import json
+    bench = _bench_module()
+    assert bench.LINE_LIMIT <= 6000
+    for n_gpus in (1, 8):
+        out = _fake_bench_result(bench, n_gpus)
+        text = bench.compact_line(out)
+        assert len(text) < bench.LINE_LIMIT and "\n" not in text, len(text)
+        line = json.loads(text)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in line, k
+        assert line["config"]["workload"] and line["n_gpus"] == n_gpus
+        for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launch_ms", "traffic", "wasted_traffic_ratio"):
+            assert k in line["roofline"], k
+        assert abs(line["roofline"]["frac"] - out["roofline"]["achieved"] / out["roofline"]["peak"]) < 1e-4
+        assert abs(line["value"] / out["value"] - 1) < 1e-4  # 5 significant digits
+        for k in ("value", "unit", "cores", "kind", "value_single_thread", "cpu_model", "sample"):
+            assert k in line["cpu_baseline"], k
+        assert set(line["headline_context"]) == {"direct_value", "direct_frac", "cpu_baseline_like_for_like_ratio"}
+        assert line["config"]["all_gathers_per_rank"] == [21] * n_gpus
+        assert line["config"]["ms_per_step_min_over_ranks"] == 5.61 and line["config"]["ms_per_step_max_over_ranks"] > 5.63
+        if n_gpus == 1:
+            assert [r["name"] for r in line["rows"]] == [n for n, _ in bench.ROWS] + ["a_row_that_failed"]
+            for r in line["rows"][:-1]:
+                assert set(r) == {"name", "value", "ms_per_step", "steps", "frac", "launch_ms", "bound", "traffic"}, r
+                assert all(not isinstance(v, str) or len(v) < 64 for v in r.values())
+            assert len(line["rows"][-1]["error"]) <= 80
+            assert "rows_truncated" not in line
+        else:
+            assert line["config"]["rccl_nranks"] == 8
+    # what main() prints: the detail line first, the compact line last
+    bench.DETAIL_FILE = os.path.join("gpurun_out", "bench_detail_test.json")
+    try:
+        bench.emit(_fake_bench_result(bench))
+        lines = capsys.readouterr().out.strip().split("\n")
+        assert len(lines) == 2 and "detail" in json.loads(lines[0]) and len(lines[0]) > 6000
+        assert len(lines[1]) < bench.LINE_LIMIT and json.loads(lines[1])["detail"] == bench.DETAIL_FILE
+        assert json.load(open(os.path.join(ROOT, bench.DETAIL_FILE)))["rows"][0]["workload"]
+    finally:
+        try:
+            os.remove(os.path.join(ROOT, bench.DETAIL_FILE))
+        except OSError:
+            pass
+
+
+def test_bench_rank_files_merge_into_one_short_line():
+    """every rank writes gpurun_out/rank<r>.json before the first collective after the timed region; a run that dies later
+    still yields one line (marked partial) with the whole-job value, rccl_nranks, the gathers of every rank and min/max ms"""
+    import json
+    bench = _bench_module()
+    recs = [dict(rank=r, world=8, steps=200, warmup=50, seconds_timed=1.12 + 0.01 * r, ms_per_step=(1.12 + 0.01 * r) / 200 * 1e3,
+                 particles=65536, block_sweeps_per_step=1, all_gathers=21, rccl_nranks=8, collective="library", collective_fallback=None,
+                 workload="cfg3: " + "y" * 500, config="cfg3") for r in (3, 0, 1, 2, 7, 6, 5, 4)]
+    text = bench.merge_rank_files(recs, "run failed after the timed region (rank 2 exited with status 18)")
+    assert len(text) < bench.LINE_LIMIT
+    line = json.loads(text)
+    assert line["n_gpus"] == 8 and line["partial"] and line["config"]["rccl_nranks"] == 8
+    assert line["config"]["all_gathers_per_rank"] == [21] * 8
+    assert abs(line["value"] / (8 * 65536 * 200 / 1.19) - 1) < 1e-4  # whole job / MAX over ranks
+    assert line["config"]["ms_per_step_min_over_ranks"] == 5.6 and line["config"]["ms_per_step_max_over_ranks"] == 5.95
+    assert bench.merge_rank_files(recs[:7], "x") is None  # a rank without a file: no line is made up

@@ -33,6 +33,6 @@ for v in values:
     if not line:
         print(var, "=", v, "FAILED", out.stderr[-500:])
         continue
-    r = json.loads(line[0])
+    r = json.loads(line[-1])  # (the compact line is the last one)
     rf = r.get("roofline") or {}
     print(f"{var}={v or '(unset)':>8}  ms_per_step {r['ms_per_step']:.4f}  launch_ms {rf.get('launch_ms', float('nan')):.4f}  frac {rf.get('frac', float('nan')):.3f}  {note}", flush=True)

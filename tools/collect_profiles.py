@@ -196,7 +196,8 @@ def main():
                 shutil.copy(src, inst)
         with open(os.path.join(out_dir, f"{tag}_line.log"), "w") as log:
             out = subprocess.run(["python3", os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, stdout=subprocess.PIPE, stderr=log, text=True, timeout=600)
-        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{\"metric\"")]
+        # (bench.py prints {"detail": <everything>} first and the compact line last: the committed record is the full one)
+        lines = [json.dumps(json.loads(ln)["detail"]) for ln in out.stdout.splitlines() if ln.startswith("{\"detail\"")]
         if lines:
             open(os.path.join(out_dir, f"bench_{tag}_line.json"), "w").write(lines[-1] + "\n")
             shutil.copy(os.path.join(out_dir, f"bench_{tag}_line.json"), inst)
