@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP64_TFLOPS = 78.6   # MI355X FP64 matrix = vector peak: 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (datasheet)
 PEAK_HBM_GBS = 8000.0     # MI355X HBM3E nominal; /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_ROUND = "r04"     # profiles/<round>/ holds the rocprofv3 PMC passes `traffic` is read from
+PROFILE_ROUND = "r05"     # profiles/<round>/ holds the rocprofv3 PMC passes `traffic` is read from
 
 
 def parse(argv=None):

@@ -143,6 +143,7 @@ struct demc_handle {
     size_t red_cap = 0;
     long long n_exchanges = 0;        // all-gathers issued (diagnostic, demc_comm_stats)
     struct demc_multi* multi = nullptr;
+    bool multi_sealed = false;  // the set is built: demc_set_stream is refused from here on
     // which kernel instances the last update launched (demc_last_kernels: lets a test name the instance it compared)
     struct LastPlan {
         int k1 = -1;  // 0 k_propose per phase, 1 k_longrow, 2 k_propose resident, 3 k_propose streaming-resident, 4 k_res_mvn
@@ -891,6 +892,9 @@ int launch_lean_hist(demc_handle* h, long long iter, bool snooker) {
     else if (h->lean_wg == 512) fn = dt == 8 ? k_res_mvn<512, false, 8, 2> : dt == 32 ? k_res_mvn<512, false, 32, 2> : k_res_mvn<512, false, 0, 2>;
     else if (!base) fn = dt == 8 ? k_res_mvn<256, false, 8, 1> : dt == 32 ? k_res_mvn<256, false, 32, 1> : k_res_mvn<256, false, 0, 1>;
     else fn = dt == 8 ? k_res_mvn<256, false, 8, 2> : dt == 32 ? k_res_mvn<256, false, 32, 2> : k_res_mvn<256, false, 0, 2>;
+    // (the HIST instances hold back the first half's stores for ONE iteration's store_row and form the cdf once per launch;
+    // the kernel itself carries no guard -- demc_resmvn.hpp says why -- so the launcher is where the precondition is checked)
+    if (k.n_iters != 1) return fail(h, DEMC_EINVAL, "lean DE-MC_Z kernel: one iteration per launch");
     LAUNCH_T(h, fn, dim3((unsigned)k.n_groups), dim3(h->lean_wg), h->lean_hist_lds, k);
     tick(h, 0, false);
     const hipError_t e = hipGetLastError();
@@ -1310,6 +1314,9 @@ int32_t demc_destroy(demc_handle* h) {
 int32_t demc_set_stream(demc_handle* h, void* hip_stream) {
     return guarded(h, [&]() -> int32_t {
     if (!h) return DEMC_EINVAL;
+    // a shard of a demc_multi set: shards on one device run on the first such shard's stream (demc_create_multi); a caller who
+    // re-points one would either destroy a stream its borrowers still hold or put two spinning resident kernels in flight at once
+    if (h->multi && h->multi_sealed) return fail(h, DEMC_EINVAL, "demc_set_stream: the streams of a demc_multi set belong to the set");
     USE_DEVICE(h);
     HIPCHK(hipStreamSynchronize(h->stream));
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -2223,6 +2230,13 @@ int32_t demc_create_multi(const demc_config* cfg, int32_t n_shards, const int32_
     if (cfg->n_groups % n_shards != 0) return mfail(m, DEMC_EINVAL, "n_groups (of the whole population) must divide by n_shards");
     if (cfg->group_offset != 0 || (cfg->n_groups_total != 0 && cfg->n_groups_total != cfg->n_groups))
         return mfail(m, DEMC_EINVAL, "demc_create_multi takes the configuration of the WHOLE population (group_offset 0)");
+    // DE-MC_Z (resample, crossover.jl:113-124) draws its partner cells from the history of ALL particles; a shard holds the
+    // history of its own groups only, so a sharded set would sample another pool than the single handle it promises to
+    // reproduce bit for bit: refused (one shard is fine).  The one-process-per-GPU road documents the shard-local pool instead
+    // (include/demc.h).
+    if (cfg->partner_kind == DEMC_PARTNER_HISTORY && n_shards > 1)
+        return mfail(m, DEMC_EUNSUPPORTED, "demc_create_multi: history partners (resample) draw from the history of all particles; "
+                                           "a sharded set cannot reproduce that pool -- use one shard, or partner_kind current");
     const int G = cfg->n_groups / n_shards;
     std::vector<int> devs((size_t)n_shards);
     bool distinct = true;
@@ -2241,6 +2255,7 @@ int32_t demc_create_multi(const demc_config* cfg, int32_t n_shards, const int32_
         if (rc != DEMC_OK) return mfail(m, rc, "shard " + std::to_string(r) + ": " + (m->shard[(size_t)r] ? m->shard[(size_t)r]->err : "demc_create"));
         m->shard[(size_t)r]->multi = m;
     }
+    struct Seal { demc_multi* m; ~Seal() { for (demc_handle* h : m->shard) if (h) h->multi_sealed = true; } } seal{m};
     if (n_shards > 1 && distinct) {
         std::vector<ncclComm_t> comms((size_t)n_shards);
         const ncclResult_t nr = ncclCommInitAll(comms.data(), n_shards, devs.data());

@@ -506,7 +506,14 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
             // second-half particle's).  Every wave must therefore have its base rows in registers before any wave stores
             // anything: one workgroup barrier per launch, here.  (Found by the parity test of cfg3's shape the moment the kernel
             // got faster: 197 of 39 k decisions differed; with the slower register allocation the race had never fired.)
-            if (ph == 1) lds_barrier();
+            // The base rows are GLOBAL loads: the barrier must also wait for them (lds_barrier() orders LDS traffic only, and
+            // the race would then be closed by the register allocation of the day, not by the program).
+            if (ph == 1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
         }
         if constexpr (HIST) {
             if (pend) {  // the first half's writes, now that this half's rows are in registers
