@@ -41,7 +41,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--config", default="cfg3", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
+    ap.add_argument("--config", default="cfg3", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "mvn30"])
     ap.add_argument("--mode", default="streaming", choices=["streaming", "suffstat", "direct"],
                     help="MvNormal likelihood: streaming = expanded quadratic form on the FP64 matrix cores (headline); suffstat = "
                          "O(D^2) per proposal; direct = the residual form sum_i |L^-1(x_i - mu)|^2 term by term on the FP64 vector pipe")
@@ -282,6 +282,10 @@ def _describe(a, w, world):
     if a.config == "cfg4":
         return (f"cfg4: hierarchical Binomial (Hierarchical_Example.jl shape), S={w['dims'][0]} subjects, D={D}, blocks [hyper; subject], "
                 f"n_groups={G}x{world} (BASELINE: 128 groups over 8 GPUs), Np={Np}, schedule={a.schedule}")
+    if a.config == "mvn30":
+        return (f"mvn30: test/multivariate_normal_tests.jl (MvNormal(mu, sigma^2 I), theta = (mu[30], sigma), N={w['dims'][0]} obs), D={D}, "
+                f"n_groups={G}x{world} (the reference: 1 group of 3), Np={Np}, schedule={a.schedule}" +
+                ("" if a.snooker is None else f", theta_snooker={a.snooker:g}"))
     return (f"cfg5: LBA 3 accumulators (Run_LBA.jl), D={D}, N={w['dims'][0]} trials simulated from nu=(3,2,1) A=.8 k=.2 tau=.3, "
             f"n_groups={G}x{world} (BASELINE: 512 groups over 8 GPUs), Np={Np}, snooker 0.1, schedule={a.schedule}")
 
@@ -422,6 +426,25 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
                                 if one else
                                 "k_propose<256,false,...> (no tile: partner rows are history cells [row][slot][D], each D contiguous doubles) "
                                 "+ k_accept_store (burn-in: the base particle is read from the current population)")
+    elif a.config == "mvn30":
+        # test/multivariate_normal_tests.jl:50-59 as the reference runs it (DE-MC_Z + snooker), scaled to fill the chip: the rows are
+        # 31 doubles, the 100 x 30 observations sit in LDS -- per update the path moves 24*D+17 bytes plus, with history
+        # partners, the gathered partner cells (two rows of D, three for a snooker update)
+        t_s = (fused_ms + tm["loglike"]["ms"]) * 1e-3
+        n_launch = max(1, tm["propose"]["launches"])
+        gather = 0.0 if a.partners != "history" else (2.0 + (a.snooker or 0.0)) * 8.0 * D
+        byts = (24.0 * D + 17.0 + gather) * P * k_iters
+        ach = byts / t_s / 1e9
+        LAST_PROFILE_REC.clear()
+        traffic, src = measured_traffic(a, n_launch, k_iters)
+        rf = dict(bound="hbm", kernel="k_propose (general kernel" + (", history partners" if gather else "") + ") with the fused per-observation tail",
+                  achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
+                  bytes_counted="24*D+17 per particle-update (SURVEY 8d)" + (" + the gathered history cells (2 rows of D, 3 for a snooker update)" if gather else ""),
+                  launch_ms=t_s / n_launch * 1e3, launches=n_launch, updates_per_launch=P * k_iters / n_launch,
+                  traffic=traffic, traffic_source=src, wasted_traffic_ratio=None if traffic is None else traffic / (byts / n_launch))
+        fb = LAST_PROFILE_REC.get("fetch_bytes_per_launch")
+        rf["fetch_bytes_per_update"] = None if fb is None else fb / (P * k_iters / n_launch)
+        rf["gather_bytes_per_update"] = gather
     elif a.config == "cfg1":
         t_s = fused_ms * 1e-3
         n_launch = max(1, tm["propose"]["launches"])
@@ -446,6 +469,16 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
         # row (8D) -- `necessary_bytes`.  Both are reported; `frac` (the contract's field) is the honest one: counter traffic.
         survey_bytes = sweeps * (24.0 * D + 17.0 + 16.0 * S) * P * k_iters
         necessary_bytes = (sweeps * 8.0 * D + 8.0 * D + 8.0 * D + 17.0 * sweeps) * P * k_iters
+        # DE-MC_Z (resample, crossover.jl:113-124; Examples/Hierarchical_Example.jl:103-114): the partner rows are cells of the
+        # HISTORY of all particles -- 80 KB rows nobody else reads at that moment, so they DO cross the HBM interface: two per update
+        # of the subject sweep (three for a snooker update, which also needs them in the hyper-parameter sweep for adjust_loglike's
+        # norms, crossover.jl:268-273); the hyper-parameter sweep of a crossover update reads two scalars of each
+        gather_bytes = 0.0
+        if a.partners == "history":
+            snk = a.snooker if a.snooker is not None else (w["engine"].get("theta_snooker") or 0.0)
+            gather_bytes = ((1.0 - snk) * 2.0 + snk * 3.0 * sweeps) * 8.0 * D * P * k_iters
+            necessary_bytes += gather_bytes
+        LAST_PROFILE_REC.clear()
         traffic, src = measured_traffic(a, n_launch, k_iters)
         inst = "k_longrow<256>, two workgroups per CU" if P // 2 >= 512 else "k_longrow<512>"  # (launch_phase's rule, 256 CUs)
         ach_survey = survey_bytes / t_s / 1e9
@@ -463,6 +496,10 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
                   launch_ms=t_s / n_launch * 1e3, launches=n_launch, updates_per_launch=sweeps * P * k_iters / n_launch,
                   traffic=traffic, traffic_source=src,
                   wasted_traffic_ratio=None if traffic is None else traffic / (necessary_bytes / n_launch))
+        if a.partners == "history":
+            rf["gather_bytes_per_update"] = gather_bytes / (sweeps * P * k_iters)
+            fb = LAST_PROFILE_REC.get("fetch_bytes_per_launch")
+            rf["fetch_bytes_per_update"] = None if fb is None else fb / (sweeps * P * k_iters / n_launch)
     else:  # cfg5
         N, na = w["dims"]
         t_s = tm["loglike"]["ms"] * 1e-3
@@ -789,6 +826,12 @@ ROWS = [
     ("cfg2_streaming_post_burnin", dict(config="cfg2", mode="streaming", burnin=0, steps=400, warmup=50)),
     ("cfg4_share", dict(config="cfg4", steps=40, warmup=10)),
     ("cfg4_whole", dict(config="cfg4", n_groups=128, steps=20, warmup=5)),
+    # the reference's OWN hierarchical configuration (Examples/Hierarchical_Example.jl:103-114): sample = resample (DE-MC_Z), theta_snooker
+    # = 0.1, block updates [hyper; subject] -- the 80 KB partner rows are gathered from the history
+    ("cfg4_whole_history_partners_snooker_blocks", dict(config="cfg4", n_groups=128, partners="history", n_initial=4, snooker=0.1,
+                                                        steps=10, warmup=3)),
+    # test/multivariate_normal_tests.jl:50-59 (DE-MC_Z + snooker on MvNormal(mu, sigma^2 I), 31 parameters), groups scaled to fill the chip
+    ("mvn30_demcz_snooker", dict(config="mvn30", partners="history", n_initial=124, snooker=0.1, steps=100, warmup=20)),
     ("cfg5_share", dict(config="cfg5", steps=20, warmup=5)),
     ("cfg5_share_converged", dict(config="cfg5", start="posterior", steps=20, warmup=5)),
     ("cfg1", dict(config="cfg1", steps=400, warmup=50)),

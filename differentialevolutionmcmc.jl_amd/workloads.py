@@ -112,7 +112,22 @@ def cfg5(N=50000, G=64, Np=128, seed=20260005):
                                                     np.abs(rng.normal(0.2, 0.1, (P, 1))) + 0.02, rng.uniform(0.02, mr * 0.98, (P, 1))], 1))
 
 
-BUILDERS = dict(cfg1=cfg1, cfg2=cfg2, cfg3=cfg3, cfg4=cfg4, cfg5=cfg5)
+def mvn30(N=100, d=30, G=256, Np=64, seed=20260006):
+    """test/multivariate_normal_tests.jl:6-38,50-59: data rand(MvNormal(0, I), 100), theta = (mu[1:30], sigma), mu_j ~ N(0,1),
+    sigma ~ Cauchy+(0,1), loglike = sum logpdf(MvNormal(mu, sigma^2 I), data), bounds ((-Inf,Inf),(0,Inf)); the reference runs
+    it as DE-MC_Z with snooker (sample = resample, theta_snooker = 0.1, n_initial = (n_mu + 1) * 4) on Np = 3, n_groups = 1 --
+    here with enough groups to fill the chip (the sampler's settings come from the caller: bench.py's row)"""
+    rng = np.random.default_rng(seed)
+    X = rng.normal(0, 1, (N, d))
+    D = d + 1
+    return dict(name="mvn30", G=G, Np=Np, fam=F.FAM_MVN_ISO, data=X, dims=[N, d], hyper=None, D=D,
+                pk=[F.PRIOR_NORMAL] * d + [F.PRIOR_HALFCAUCHY], pa=[0.0] * D, pb=[1.0] * D, pref=[0] * D,
+                lo=[-INF] * d + [0.0], hi=[INF] * D, masks=None, engine={},
+                truth=np.concatenate([X.mean(0), [1.0]]),
+                init=lambda P, rng: np.concatenate([rng.normal(0, 1, (P, d)), np.abs(rng.standard_cauchy((P, 1))) + 0.1], 1))
+
+
+BUILDERS = dict(cfg1=cfg1, cfg2=cfg2, cfg3=cfg3, cfg4=cfg4, cfg5=cfg5, mvn30=mvn30)
 
 
 def configure(engine, w):
