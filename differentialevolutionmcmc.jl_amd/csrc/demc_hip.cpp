@@ -681,18 +681,37 @@ int launch_phase(demc_handle* h, KParams& k) {
             const bool two_per_cu = (long long)h->geo_groups * k.n_act >= 2LL * h->n_cus && h->lr_two_fit;
             int wg_lr = two_per_cu ? 256 : 512;
             if (const char* e = experiment("DEMC_LR_WG")) wg_lr = std::atoi(e);  // A/B experiments
+#ifdef DEMC_EXPERIMENTS
+            {
+                static bool said = false;
+                if (!said) {
+                    said = true;
+                    int n256 = 0, n384 = 0, n512 = 0;
+                    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n256, (const void*)k_longrow<256>, 256, lr_lds);
+                    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n384, (const void*)k_longrow<384, 2>, 384, lr_lds);
+                    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n512, (const void*)k_longrow<512, 2>, 512, lr_lds);
+                    std::fprintf(stderr, "experiment: k_longrow workgroups per CU at %zu B of dynamic LDS: <256> %d, <384,2> %d, <512,2> %d\n", lr_lds, n256, n384, n512);
+                }
+            }
+#endif
             h->last = demc_handle::LastPlan();
             h->last.k1 = 1; h->last.wg = wg_lr;
             tick(h, 0, true);
             // persistent: as many workgroups as are resident at once, each takes particles blockIdx.x, + gridDim.x, ... (the
             // row moves of one particle then run inside the span loops of the next: demc_longrow.hpp).  A multiple of 8 keeps
             // a workgroup's particles on its own XCD (the kernel's blockIdx -> group mapping).
-            long long grid_lr = (long long)(wg_lr == 256 ? 2 : 1) * h->n_cus;
+            long long grid_lr = (long long)(wg_lr == 512 ? 1 : 2) * h->n_cus;
             if (const char* e = experiment("DEMC_LR_GRID")) grid_lr = std::atoll(e);  // A/B experiments
             if (grid_lr > n_prop || grid_lr < 1) grid_lr = n_prop;
             if ((k.n_groups & 7) == 0 && grid_lr >= 8) grid_lr &= ~7LL;
             if (wg_lr == 256)
                 LAUNCH_T(h, k_longrow<256>, dim3((unsigned)grid_lr), dim3(256), lr_lds, k);
+#ifdef DEMC_EXPERIMENTS
+            else if (wg_lr == 384)
+                LAUNCH_T(h, (k_longrow<384, 2>), dim3((unsigned)grid_lr), dim3(384), lr_lds, k);
+            else if (wg_lr == 1024)  // (512 threads, two workgroups per CU)
+                LAUNCH_T(h, (k_longrow<512, 2>), dim3((unsigned)grid_lr), dim3(512), lr_lds, k);
+#endif
             else
                 LAUNCH_T(h, k_longrow<512>, dim3((unsigned)grid_lr), dim3(512), lr_lds, k);
             tick(h, 0, false);
@@ -807,7 +826,8 @@ void plan_lean(demc_handle* h) {
             const int wgh = (c.Np - c.Np / 2) * 4 > 256 ? 512 : 256;
             h->lean_hist_ok = true; h->lean_wg = wgh;
             // cdf | chunk offsets | centred rows | A^-1 fragments [2][8][64]
-            h->lean_hist_lds = ((size_t)c.Np + 16 + (size_t)(wgh / 4) * ((size_t)c.D + 2) + 16 * 64) * sizeof(double);
+            // ... | held-back rows [wg][8] | current rows [wg][8] | xbar [32] (+ alignment slack): demc_resmvn.hpp, pend_l / t8_l / xb_l
+            h->lean_hist_lds = ((size_t)c.Np + 16 + (size_t)(wgh / 4) * ((size_t)c.D + 2) + 16 * 64 + 2 + (size_t)wgh * 16 + 32) * sizeof(double);
         }
         return;
     }
@@ -1103,6 +1123,10 @@ int size_k1_lds(demc_handle* h) {
 #endif
     HIPCHK(hipFuncSetAttribute((const void*)k_longrow<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
     HIPCHK(hipFuncSetAttribute((const void*)k_longrow<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
+#ifdef DEMC_EXPERIMENTS
+    HIPCHK(hipFuncSetAttribute((const void*)k_longrow<384, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
+    HIPCHK(hipFuncSetAttribute((const void*)k_longrow<512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
+#endif
     {
         void (*lean[])(KParams) = {k_res_mvn<256, false, 0>, k_res_mvn<256, false, 8>, k_res_mvn<256, false, 32>,
                                    k_res_mvn<512, false, 0>, k_res_mvn<512, false, 8>, k_res_mvn<512, false, 32>,

@@ -11,4 +11,8 @@
 namespace demc {
 template __global__ void k_longrow<256>(KParams);
 template __global__ void k_longrow<512>(KParams);
+#ifdef DEMC_EXPERIMENTS  // A/B builds only (DEMC_LR_WG = 384 / 1024): three and four waves per SIMD
+template __global__ void k_longrow<384, 2>(KParams);
+template __global__ void k_longrow<512, 2>(KParams);
+#endif
 }  // namespace demc

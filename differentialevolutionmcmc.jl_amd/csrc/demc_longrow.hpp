@@ -56,8 +56,15 @@ __device__ inline uint32_t wave_get(uint32_t v, int src) { return (uint32_t)__bu
 // not two 80 KB rows of LDS sets the occupancy -- 'k_longrow<256, GS>'.  Whole cfg4, per launch: LDS form 0.174 ms; global
 // scratch at the same two workgroups per CU 0.191; at three (168 VGPRs, 44 spilled) 0.202; at four (128 VGPRs, 88 spilled)
 // 0.219.  More workgroups in flight make the launch SLOWER: the phase is not waiting for latency that more waves could hide.)
-template <int WG>
-__global__ __launch_bounds__(WG, 512 / WG) void k_longrow(KParams p_arg) {
+// PER_CU workgroups of WG threads share a CU (each parks an 80 KB row in LDS: at most two): WG / 64 * PER_CU / 4 waves per SIMD,
+// which is what the register budget follows from -- (256, 2) and (512, 1), the forms that ship: two waves per SIMD, 256 registers.
+// Round 5 measured the forms with MORE waves per CU (A/B builds only; profiles/r05/NOTES.md): (384, 2) -- three waves per SIMD,
+// 168 registers, no spill, seven rounds per particle instead of ten, two workgroups per CU confirmed by the occupancy query --
+// 0.216 ms per launch of the whole cfg4 against 0.167; (512, 2) does not fit twice (LDS) and spills at 128 registers: 0.239.
+// With round 3's global-scratch forms and round 4's LITE instance that makes four measurements that say the same: this kernel
+// gets slower with more waves in flight.
+template <int WG, int PER_CU = (WG <= 256 ? 2 : 1)>
+__global__ __launch_bounds__(WG, (WG / 64 * PER_CU + 3) / 4) void k_longrow(KParams p_arg) {
     // The parameters are read through the kernarg segment pointer, made opaque once per particle of the persistent loop below:
     // otherwise every field the body reads is loaded once, ahead of the loop, and stays live across it -- hundreds of SGPRs,
     // spilled into VGPR lanes, which then spill themselves (256 VGPRs + scratch against 220 for the one-particle kernel).
@@ -534,7 +541,8 @@ __global__ __launch_bounds__(WG, 512 / WG) void k_longrow(KParams p_arg) {
         // the tree k_propose's group_sum uses: pairs of waves, then pairs of pairs
         auto tree = [&](const double* s) {
             const double lo = (s[0] + s[1]) + (s[2] + s[3]);
-            return WG > 256 ? lo + ((s[4] + s[5]) + (s[6] + s[7])) : lo;
+            if constexpr (WG == 384) return lo + (s[4] + s[5]);
+            else return WG > 256 ? lo + ((s[4] + s[5]) + (s[6] + s[7])) : lo;
         };
         vm = tree(s_red[0]); vn = tree(s_red[1]); vd = tree(s_red[2]);
         cm = vm / vd; cn = vn / vd;
@@ -941,8 +949,8 @@ __global__ __launch_bounds__(WG, 512 / WG) void k_longrow(KParams p_arg) {
                 ++R;
                 continue;
             }
-            if ((r & 1) == (wave >= WG / 128 ? 1 : 0)) {
-                for (int jj = tid & (WG / 2 - 1); jj < 256 && 256 * R + jj < D; jj += WG / 2) {
+            if ((r & 1) == (tid >= WG / 2 ? 1 : 0)) {
+                for (int jj = tid % (WG / 2); jj < 256 && 256 * R + jj < D; jj += WG / 2) {
                     const int j = 256 * R + jj;
                     if (part && j >= c_lo && j < c_hi) continue;
                     int qj = 0;
@@ -1006,7 +1014,8 @@ __global__ __launch_bounds__(WG, 512 / WG) void k_longrow(KParams p_arg) {
         for (int j = tid; j < D; j += WG) p.prop[slot * D + j] = scr[j];
     auto tree = [&](const double* s) {
         const double lo = (s[0] + s[1]) + (s[2] + s[3]);
-        return WG > 256 ? lo + ((s[4] + s[5]) + (s[6] + s[7])) : lo;
+        if constexpr (WG == 384) return lo + (s[4] + s[5]);
+        else return WG > 256 ? lo + ((s[4] + s[5]) + (s[6] + s[7])) : lo;
     };
     prior = tree(s_red[0]); like = tree(s_red[1]);
     if (hier_b) like = p.c2 + like;  // + sum_s log C(n, k_s): data-only, summed once at demc_set_model
@@ -1147,6 +1156,10 @@ __global__ __launch_bounds__(WG, 512 / WG) void k_longrow(KParams p_arg) {
 #ifdef DEMC_LONGROW_EXTERN  // the instances live in demc_longrow.cpp (its own translation unit, its own compiler flags)
 extern template __global__ void k_longrow<256>(KParams);
 extern template __global__ void k_longrow<512>(KParams);
+#ifdef DEMC_EXPERIMENTS
+extern template __global__ void k_longrow<384, 2>(KParams);
+extern template __global__ void k_longrow<512, 2>(KParams);
+#endif
 #endif
 
 }  // namespace demc
