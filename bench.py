@@ -413,7 +413,10 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
                       bytes_counted="24*D+17 per particle-update (SURVEY 8d)", launch_ms=t_s / n_launch * 1e3, launches=n_launch,
                       updates_per_launch=P * k_iters / n_launch,
                       traffic=traffic, traffic_source=src,
-                      wasted_traffic_ratio=None if traffic is None else traffic / (byts / n_launch))
+                      wasted_traffic_ratio=None if traffic is None else traffic / (byts / n_launch),
+                      # `frac` prices SURVEY 8d's formula, which counts bytes the resident kernel never moves (theta is read from
+                      # HBM once per launch, not once per update); the fraction of the HBM peak by the COUNTERS' bytes beside it
+                      counter_frac=None if traffic is None else traffic * n_launch / t_s / 1e9 / PEAK_HBM_GBS)
             if a.partners == "history":
                 # resample (crossover.jl:113-124): two partner rows (three with snooker) GATHERED from the history of all
                 # particles, next to the particle's own row -- 3 x 8D bytes read per update; the counters say what the gather costs
@@ -830,8 +833,13 @@ ROWS = [
     # = 0.1, block updates [hyper; subject] -- the 80 KB partner rows are gathered from the history
     ("cfg4_whole_history_partners_snooker_blocks", dict(config="cfg4", n_groups=128, partners="history", n_initial=4, snooker=0.1,
                                                         steps=10, warmup=3)),
+    # ... past burn-in (no base particle from the current population: the synchronous sweep is ONE k_longrow launch per block)
+    ("cfg4_whole_history_partners_snooker_blocks_post_burnin", dict(config="cfg4", n_groups=128, partners="history", n_initial=4,
+                                                                    snooker=0.1, burnin=0, steps=10, warmup=3)),
     # test/multivariate_normal_tests.jl:50-59 (DE-MC_Z + snooker on MvNormal(mu, sigma^2 I), 31 parameters), groups scaled to fill the chip
-    ("mvn30_demcz_snooker", dict(config="mvn30", partners="history", n_initial=124, snooker=0.1, steps=100, warmup=20)),
+    ("mvn30_demcz_snooker", dict(config="mvn30", mode="suffstat", partners="history", n_initial=124, snooker=0.1, steps=100, warmup=20)),
+    ("mvn30_demcz_snooker_post_burnin", dict(config="mvn30", mode="suffstat", partners="history", n_initial=124, snooker=0.1, burnin=0,
+                                             steps=100, warmup=20)),
     ("cfg5_share", dict(config="cfg5", steps=20, warmup=5)),
     ("cfg5_share_converged", dict(config="cfg5", start="posterior", steps=20, warmup=5)),
     ("cfg1", dict(config="cfg1", steps=400, warmup=50)),

@@ -99,6 +99,8 @@ struct demc_handle {
     // streaming-resident form (plan_stream): the MvNormal observation stream inside the resident kernel
     bool st_ok = false;
     int st_C = 0, st_nact_max = 0, st_rows = 0, st_x_lds = 0, st_chunk_tiles = 0, st_lpp = 0, st_scr_doubles = 0, st_wg = 512;
+    // the lean streaming kernel's own cut of the observation tiles (plan_lean): st_C, or twice that with two workgroups per CU
+    int lean_st_C = 0, lean_st_chunk_tiles = 0, lean_st_x_lds = 0, lean_st_occ = 1;
     size_t st_lds = 0;
     unsigned long long* st_gran = nullptr;  // hand-over granules (device)
     unsigned* st_err = nullptr;             // time-out flag (host-mapped, zero-copy)
@@ -861,6 +863,30 @@ void plan_lean(demc_handle* h) {
         bytes += xbytes;
     }
     h->lean_stream_ok = true; h->lean_wg = wg; h->lean_stream_lds = bytes;
+    h->lean_st_C = h->st_C; h->lean_st_chunk_tiles = h->st_chunk_tiles; h->lean_st_x_lds = h->st_x_lds; h->lean_st_occ = 1;
+#ifdef DEMC_EXPERIMENTS
+    // A/B builds only (DEMC_LEAN_OCC2=1) -- TWO workgroups per CU (D = 8, the instance compiled for it): twice the chunks, so that
+    // the grid is twice the CU count and a CU holds workgroups of two different groups ("two latency chains on a
+    // CU") -- taken when BOTH are resident at once by the runtime's own occupancy figure (every workgroup of the grid must be: the
+    // chunks of a group spin on each other's hand-over).  Measured in round 5 at BASELINE cfg2 (profiles/r05/NOTES.md): 0.1664 ms
+    // per launch against 0.1407 with one workgroup per CU (0.257 / 0.304 of the matrix peak; past burn-in 0.291 / 0.343): the
+    // two workgroups of a CU run in step, their matrix stages collide, and sixteen chunks make the hand-over longer.  Not shipped.
+    {
+        const int gg = h->geo_groups > c.n_groups ? h->geo_groups : c.n_groups;
+        const int C2 = 2 * h->st_C;
+        bool want = h->n_seg == 1 && c.D == 8 && h->st_x_lds && C2 <= 16 && (long long)C2 * gg <= 2LL * h->n_cus && h->n_tiles / C2 >= 8;
+        const char* e = experiment("DEMC_LEAN_OCC2");
+        want = want && e && e[0] == '1';
+        if (want) {
+            const int chunk2 = (h->n_tiles + C2 - 1) / C2;
+            const size_t bytes2 = bytes - xbytes + (size_t)(chunk2 + 1) * (h->dpad / 4) * 64 * sizeof(double);
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_res_mvn<256, true, 8, 0, 2>, 256, bytes2) == hipSuccess && nb >= 2) {
+                h->lean_st_C = C2; h->lean_st_chunk_tiles = chunk2; h->lean_st_occ = 2; h->lean_stream_lds = bytes2;
+            }
+        }
+    }
+#endif
 }
 
 int launch_lean(demc_handle* h, long long iter0, int n_iters, bool stream) {
@@ -870,19 +896,23 @@ int launch_lean(demc_handle* h, long long iter0, int n_iters, bool stream) {
     k.sx = stream ? nullptr : h->sx;
     k.Ainv = h->Ainv;
     if (stream) {
-        k.st_C = h->st_C; k.st_nact_max = h->st_nact_max; k.st_x_lds = h->st_x_lds; k.st_chunk_tiles = h->st_chunk_tiles;
+        k.st_C = h->lean_st_C; k.st_nact_max = h->st_nact_max; k.st_x_lds = h->lean_st_x_lds; k.st_chunk_tiles = h->lean_st_chunk_tiles;
         k.n_tiles = h->n_tiles; k.Xf = h->Xf; k.st_gran = h->st_gran; k.st_err = h->st_err;
-        if (k.n_groups * h->st_C > h->n_cus) return fail(h, DEMC_EINVAL, "streaming-resident grid exceeds the CU count");
-        HIPCHK(hipMemsetAsync(h->st_gran, 0, 2 * (size_t)c.n_groups * h->st_C * h->st_nact_max * 2 * sizeof(unsigned long long), h->stream));
+        if (k.n_groups * h->lean_st_C > h->n_cus * h->lean_st_occ) return fail(h, DEMC_EINVAL, "streaming-resident grid exceeds what is resident at once");
+        HIPCHK(hipMemsetAsync(h->st_gran, 0, 2 * (size_t)c.n_groups * h->lean_st_C * h->st_nact_max * 2 * sizeof(unsigned long long), h->stream));
     }
     tick(h, 0, true);
-    const unsigned grid = (unsigned)(k.n_groups * (stream ? h->st_C : 1));
+    const unsigned grid = (unsigned)(k.n_groups * (stream ? h->lean_st_C : 1));
     const size_t lds = stream ? h->lean_stream_lds : h->lean_lds;
     // instances with the row length folded in (cfg3: 32, cfg2: 8) when the prior table is one segment
     const int dt = (h->n_seg == 1 && (c.D == 32 || c.D == 8)) ? c.D : 0;
     h->last = demc_handle::LastPlan();
     h->last.k1 = 4; h->last.wg = h->lean_wg; h->last.stream = stream; h->last.dt = dt;
     void (*fn)(KParams) = nullptr;
+#ifdef DEMC_EXPERIMENTS
+    if (stream && h->lean_st_occ == 2) fn = k_res_mvn<256, true, 8, 0, 2>;  // (plan_lean: D = 8 only)
+    else
+#endif
     if (stream) fn = dt == 8 ? k_res_mvn<256, true, 8> : dt == 32 ? k_res_mvn<256, true, 32> : k_res_mvn<256, true, 0>;
     else if (h->lean_wg == 512) fn = dt == 8 ? k_res_mvn<512, false, 8> : dt == 32 ? k_res_mvn<512, false, 32> : k_res_mvn<512, false, 0>;
     else fn = dt == 8 ? k_res_mvn<256, false, 8> : dt == 32 ? k_res_mvn<256, false, 32> : k_res_mvn<256, false, 0>;
@@ -980,7 +1010,8 @@ void plan_stream(demc_handle* h) {
     if (x_lds) bytes += xbytes;
     // hand-over granules [2][n_groups][C][nact_max][2] and the time-out word
     if (h->st_gran) { hipFree(h->st_gran); h->st_gran = nullptr; }
-    if (hipMalloc((void**)&h->st_gran, 2 * (size_t)c.n_groups * C * nact_max * 2 * sizeof(unsigned long long)) != hipSuccess) return;
+    // (room for 2 C chunks: the lean kernel may cut the tiles twice as fine, plan_lean)
+    if (hipMalloc((void**)&h->st_gran, 2 * (size_t)c.n_groups * 2 * C * nact_max * 2 * sizeof(unsigned long long)) != hipSuccess) return;
     if (!h->st_err) {
         if (hipHostMalloc((void**)&h->st_err, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) return;
         *h->st_err = 0u;
@@ -1131,6 +1162,9 @@ int size_k1_lds(demc_handle* h) {
         void (*lean[])(KParams) = {k_res_mvn<256, false, 0>, k_res_mvn<256, false, 8>, k_res_mvn<256, false, 32>,
                                    k_res_mvn<512, false, 0>, k_res_mvn<512, false, 8>, k_res_mvn<512, false, 32>,
                                    k_res_mvn<256, true, 0>,  k_res_mvn<256, true, 8>,  k_res_mvn<256, true, 32>,
+#ifdef DEMC_EXPERIMENTS
+                                   k_res_mvn<256, true, 8, 0, 2>,
+#endif
                                    k_res_mvn<256, false, 0, 1>, k_res_mvn<256, false, 8, 1>, k_res_mvn<256, false, 32, 1>,
                                    k_res_mvn<512, false, 0, 1>, k_res_mvn<512, false, 8, 1>, k_res_mvn<512, false, 32, 1>,
                                    k_res_mvn<256, false, 0, 2>, k_res_mvn<256, false, 8, 2>, k_res_mvn<256, false, 32, 2>,

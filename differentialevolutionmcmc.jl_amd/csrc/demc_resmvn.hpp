@@ -44,14 +44,17 @@ namespace demc {
 // (crossover.jl:241), the third one in the slot the base row has in instance 2 (a snooker update reads no base particle), projects
 // two of them onto Pt - Pz (utilities.jl:239-246: three dot products, summed over the quad) and carries adjust_loglike's norms
 // (crossover.jl:268-273) into the decision; the other particles of the wave take the crossover as in instance 2, in or past burn-in.
-template <int WG, bool STREAM, int DT = 0, int HIST_ = 0>
-__global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(KParams p) {
+// OCC = 2 (STREAM, 256 threads; A/B builds only): the instance compiled for TWO workgroups per CU -- 256 registers per lane, the
+// observation stage's accumulators in AGPRs inside that budget -- so that a small population (BASELINE cfg2: 32 groups on 256 CUs)
+// is cut into twice as many observation chunks and a CU holds workgroups of two DIFFERENT groups, one group's dependent chain
+// (draws, proposal, hand-over round trip, decision) under the other's matrix stage.  Measured slower (plan_lean).
+template <int WG, bool STREAM, int DT = 0, int HIST_ = 0, int OCC = 1>
+__global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) void k_res_mvn(KParams p) {
     constexpr bool HIST = HIST_ != 0;
     static_assert(!(HIST && STREAM), "history partners: the SUFFSTAT form only");
-    // (one iteration per launch: launch_lean_hist never asks for more, and checks it; the kernel checks it too.  Round 4 had no
-    // guard here: at 240-256 VGPRs an early `return` tipped the hot instance into scratch, +25 % per launch.  Round 5 took the
-    // instances off that cliff -- the held-back first-half rows, the current rows kept for the history and xbar live in LDS now,
-    // not in 48 registers per lane held across the MFMA stage -- and the guard costs nothing.)
+    // (one iteration per launch: launch_lean_hist never asks for more, and checks it; the kernel's own guard is the trip count of
+    // the phase loop below.  An early `return` on p.n_iters != 1 HERE costs ~24 VGPRs -- round 4: 240 -> 254 and 64 B of scratch
+    // in the hot instance, +25 % per launch.)
     extern __shared__ double lds[];
     __shared__ unsigned char s_mut[1024];  // beta coin of every iteration of this launch (n_iters <= 1024)
     __shared__ DimSeg s_seg[kMaxDimSeg];   // bounds / prior table, run-length encoded (usually ONE segment for this family)
@@ -130,13 +133,13 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
     const int jA = SPL * sl, jB = DT == 8 ? 64 : 16 + 4 * sl;    // first scalar of the lane's two blocks (DT == 8: one)
     const uint32_t nbA = DT == 8 ? (uint32_t)(sl >> 1) : (uint32_t)sl;  // the NOISE block behind the lane's first scalars
     // xbar of the lane's 8 scalars, and the table segment of each (4 bits apiece; the entries themselves stay in LDS)
-    double xb[8];  // (HIST: in LDS instead, xb_l below)
+    double xb[8];
     unsigned segs = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int j = (e < 4 ? jA : jB - 4) + e;
         const int jj = j < D ? j : 0;
-        xb[e] = HIST ? 0.0 : p.xbar[jj];
+        xb[e] = p.xbar[jj];
         unsigned sg = 0;
         for (int i = 1; i < p.n_seg; ++i) sg += (jj >= p.dimseg[i].start) ? 1u : 0u;
         segs |= sg << (4 * e);
@@ -147,13 +150,14 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
     // launch for a stage of 2 k cycles are what tipped its allocation into scratch whenever anything else changed.
     constexpr bool BF_LDS = HIST;
     double* const bf_l = scr + (size_t)(WG / 4) * scr_stride;  // (HIST only: behind the centred rows; never with STREAM)
-    // HIST: three more things a lane used to hold in registers across the matrix stage, now parked in LDS by the lane itself
-    // (written and read back by the same lane: no barrier; [pair][thread] double2 = conflict-free 16-byte accesses):
-    //   pend_l -- the first half's rows, held back until the second half's loads are in;  t8_l -- the lane's scalars of the
-    //   current row, for the history row of a rejected particle;  xb_l -- xbar [32]
+    // HIST_ == 3 (snooker: one more row in flight): the first half's rows, held back until the second half's loads are in, wait in
+    // LDS, not in 16 registers per lane held across the second half's whole proposal stage (written and read back by the same
+    // lane: no barrier; [pair][thread] double2 = conflict-free 16-byte accesses) -- that instance sat AT 256 registers with a spill;
+    // 245 and none this way.  Measured on all three instances in round 5 (profiles/r05/NOTES.md): parking costs 3-4 % per launch
+    // (and parking the current row's scalars and xbar as well, which are read on the phase's dependent chain, 12 %), so instances
+    // 1 and 2 (221 / 241 registers, no scratch) keep theirs in registers.
+    constexpr bool PARK = HIST_ == 3;
     double* const pend_l = reinterpret_cast<double*>((reinterpret_cast<size_t>(bf_l + 16 * 64) + 15) & ~(size_t)15);  // (Np may be odd)
-    double* const t8_l = pend_l + (size_t)WG * 8;
-    double* const xb_l = t8_l + (size_t)WG * 8;
     auto park8 = [&](double* base, const double (&x)[8]) {
 #pragma unroll
         for (int e2 = 0; e2 < 4; ++e2)
@@ -166,9 +170,6 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
             x[2 * e2] = v.x; x[2 * e2 + 1] = v.y;
         }
     };
-    if constexpr (HIST) {
-        if (tid < 32) xb_l[tid] = tid < D ? p.xbar[tid] : 0.0;  // (visible after the barrier below)
-    }
     double bfrag[2][8];
     {
         const int kq = lane >> 4, col = lane & 15;
@@ -203,8 +204,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
     const int id_lo = (int)p.id[(size_t)g * Np + (q < half ? q : 0)], id_hi = (int)p.id[(size_t)g * Np + half + (q < Np - half ? q : 0)];
     const double eps = p.eps, eps2 = p.eps - (-p.eps);
     // HIST: ONE iteration per launch (the held-back first-half stores use that iteration's store_row; the cdf is formed once).
-    // The guard is the trip count: a launch that asks for anything else runs no phase at all (an early `return` at the top of the
-    // kernel, tried in round 4 and again in round 5, costs ~24 VGPRs -- this form costs none).
+    // The guard is the trip count: a launch that asks for anything else runs no phase at all.
     const long long n_steps = HIST ? (p.n_iters == 1 ? 2 : 0) : (long long)p.n_iters * 2;
     // HIST -- resample (crossover.jl:113-124) exactly as k_propose draws it: PART block 4 of the particle holds the two cell draws;
     // distinct cells of rows 1:(iter-1) x the handle's particles; cell x = (row x mod (iter-1), slot x div (iter-1))
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
             }
         }
     };
-    double pend_wp = 0.0, pend_w = 0.0;  // (the held-back rows themselves: pend_l)
+    double pend_x[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, pend_wp = 0.0, pend_w = 0.0;  // (PARK: the rows wait in pend_l)
     int pend_acc = 0;
     bool pend = false;
     // The addressed draws of a colour phase (the particle's PART block, its NOISE blocks) depend on (seed, iteration, slot)
@@ -300,14 +300,14 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
     // the three-round cumulative weights or the two-level base pick move the phase: it is a chain of dependent latencies at two
     // waves per SIMD with the vector pipe 0.39 busy, not a count of instructions.)
     if (STREAM) draw_phase(0, pre_mine, pre_nzA, pre_nzB);
-#pragma nounroll
     for (long long step = 0; step < n_steps; ++step) {
         DEMC_STAMP_RESET();
         const int ph = (int)(step & 1);
         const int it_rel = (int)(step >> 1);
         long long iter_o = p.iter + it_rel;
-        // (HIST: the trip count is the guard, so the compiler knows it_rel == 0 and would hoist everything that depends on the
-        // iteration alone -- Philox key schedules, row numbers -- out of the loop, live across both halves: opaque instead)
+        // (HIST: with the trip count as the guard the compiler knows it_rel == 0 and hoists everything that depends on the
+        // iteration alone -- Philox key schedules, row numbers -- out of the loop, live across both halves: +14 VGPRs, scratch in
+        // instance 3.  Opaque instead.)
         if constexpr (HIST) asm volatile("" : "+s"(iter_o));
         const long long iter = iter_o;
         const int a_lo = ph ? half : 0, n_act = ph ? Np - half : half;
@@ -418,7 +418,8 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
         // (HIST_ == 2: the base row's loads are issued whether or not the iteration is still inside burn-in -- the same loads in the
         // same order every time, so that the compiler can wait for each where it is needed)
         const double* Pc = HIST ? (snk ? Pc_h : base_p ? grows + (size_t)ibase * D : pt) : tile + (size_t)(pool_lo + ibase) * D;
-        double v8[8];  // (HIST: the lane's scalars of the current row -- a rejected particle's history row -- go to t8_l as they are loaded)
+        double t8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // HIST: the lane's scalars of the current row (a rejected particle's history row), kept from the proposal
+        double v8[8];
         int oob = 0;
         double prior = 0.0;
         const bool one_seg = DT > 0 || p.n_seg == 1;  // the usual case for this family: every scalar shares one table entry
@@ -481,10 +482,9 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
             if (j0 >= D) continue;
             double tt[4], aa[4], bb[4], cc[4];
             load4(pt, j0, tt);
-            if constexpr (HIST) {  // (park8's layout: pair e2 of the lane = scalars 2 e2, 2 e2 + 1 of its eight)
+            if constexpr (HIST) {
 #pragma unroll
-                for (int e4 = 0; e4 < SPL; e4 += 2)
-                    *reinterpret_cast<double2*>(t8_l + ((size_t)(2 * blk + e4 / 2) * WG + threadIdx.x) * 2) = make_double2(tt[e4], tt[e4 + 1]);
+                for (int e4 = 0; e4 < SPL; ++e4) t8[4 * blk + e4] = tt[e4];
             }
             if (!is_mut) {
                 load4(Pa, j0, aa);
@@ -548,8 +548,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
         }
         if constexpr (HIST) {
             if (pend) {  // the first half's writes, now that this half's rows are in registers
-                double pend_x[8];
-                unpark8(pend_l, pend_x);
+                if constexpr (PARK) unpark8(pend_l, pend_x);
                 hist_store(0, pend_acc, pend_wp, pend_w, store_row, pend_x);
                 pend = false;
             }
@@ -562,7 +561,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int j = (e < 4 ? jA : jB - 4) + e;
-                if (j < D) row[j] = v8[e] - (HIST ? xb_l[j] : xb[e]);
+                if (j < D) row[j] = v8[e] - xb[e];
             }
         }
         double aux, S = 0.0;
@@ -571,7 +570,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
             // quad_perm hands them round, lane sl forms columns 2 sl and 2 sl + 1 (16 FMAs) and its share of theta~.y.
             // The MFMA route (LDS transposition, two matrix instructions, four 16-lane reductions, LDS again) is a chain
             // of ~2.3 k cycles for 64 FMAs per particle.
-            const double c0_ = v8[0] - (HIST ? xb_l[jA] : xb[0]), c1_ = v8[1] - (HIST ? xb_l[jA + 1] : xb[1]);
+            const double c0_ = v8[0] - xb[0], c1_ = v8[1] - xb[1];
             double c[8];
             c[0] = dpp_mov<0x00>(c0_); c[1] = dpp_mov<0x00>(c1_);  // quad_perm:[0,0,0,0]
             c[2] = dpp_mov<0x55>(c0_); c[3] = dpp_mov<0x55>(c1_);  // quad_perm:[1,1,1,1]
@@ -731,12 +730,16 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_res_mvn(
         const double ex = HSNK ? exp(wp - w + adj) : exp(wp - w);
         const int acc = (ex >= 1.0) || (u_acc <= ex);
         if constexpr (HIST) {
-            double x8[8], t8[8];
-            unpark8(t8_l, t8);
+            double x8[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) x8[e] = acc ? v8[e] : t8[e];
             if (step + 1 < n_steps) {
-                park8(pend_l, x8);
+                if constexpr (PARK)
+                    park8(pend_l, x8);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pend_x[e] = x8[e];
+                }
                 pend_acc = acc; pend_wp = wp; pend_w = w; pend = true;
             } else
                 hist_store(ph, acc, wp, w, store_row, x8);
