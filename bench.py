@@ -440,7 +440,8 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
         ach = byts / t_s / 1e9
         LAST_PROFILE_REC.clear()
         traffic, src = measured_traffic(a, n_launch, k_iters)
-        rf = dict(bound="hbm", kernel="k_propose (general kernel" + (", history partners" if gather else "") + ") with the fused per-observation tail",
+        rf = dict(bound="hbm", kernel=("k_res_mvn<...,HIST,iso> (the lean DE-MC_Z body, isotropic form: one launch per iteration, partner rows = history cells)"
+                                       if gather and a.mode == "suffstat" else "k_propose (general kernel) with the fused MvNormal tail"),
                   achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
                   bytes_counted="24*D+17 per particle-update (SURVEY 8d)" + (" + the gathered history cells (2 rows of D, 3 for a snooker update)" if gather else ""),
                   launch_ms=t_s / n_launch * 1e3, launches=n_launch, updates_per_launch=P * k_iters / n_launch,
@@ -837,8 +838,8 @@ ROWS = [
     ("cfg4_whole_history_partners_snooker_blocks_post_burnin", dict(config="cfg4", n_groups=128, partners="history", n_initial=4,
                                                                     snooker=0.1, burnin=0, steps=10, warmup=3)),
     # test/multivariate_normal_tests.jl:50-59 (DE-MC_Z + snooker on MvNormal(mu, sigma^2 I), 31 parameters), groups scaled to fill the chip
-    ("mvn30_demcz_snooker", dict(config="mvn30", mode="suffstat", partners="history", n_initial=124, snooker=0.1, steps=100, warmup=20)),
-    ("mvn30_demcz_snooker_post_burnin", dict(config="mvn30", mode="suffstat", partners="history", n_initial=124, snooker=0.1, burnin=0,
+    ("mvn30_demcz_snooker", dict(config="mvn30", mode="suffstat", Np=256, partners="history", n_initial=124, snooker=0.1, steps=100, warmup=20)),
+    ("mvn30_demcz_snooker_post_burnin", dict(config="mvn30", mode="suffstat", Np=256, partners="history", n_initial=124, snooker=0.1, burnin=0,
                                              steps=100, warmup=20)),
     ("cfg5_share", dict(config="cfg5", steps=20, warmup=5)),
     ("cfg5_share_converged", dict(config="cfg5", start="posterior", steps=20, warmup=5)),
@@ -866,7 +867,7 @@ def row_flags(over):
     """the same as command-line flags (what tools/collect_profiles.py runs under rocprofv3)"""
     out = []
     for k, v in over.items():
-        out += ["--" + k.replace("_", "-"), str(v)]
+        out += ["--" + k.replace("_", "-").lower(), str(v)]  # (Np -> --np)
     return out
 
 
@@ -1185,6 +1186,7 @@ def main():
     roofline = None
     if tm is not None:
         roofline = roofline_of(a, w, tm, a.steps, P, dt / a.steps)
+    kernels_ran = eng.last_kernels() if rank == 0 else None  # (demc_last_kernels: the instances the last step launched)
     stage("teardown", 120.0)
     if library:
         eng.comm_allreduce([])  # nobody leaves (and rank 0 keeps the store up) before everybody has finished
@@ -1234,6 +1236,7 @@ def main():
                        "ms_per_step_min_over_ranks": dt_min / a.steps * 1e3, "ms_per_step_max_over_ranks": dt / a.steps * 1e3},
             "particle_parameter_updates_per_s": value * D,
             "particle_iterations_per_s": P * world * a.steps / dt,  # (value counts every block sweep as an update: cfg4 has two)
+            "kernels": kernels_ran,
             "accuracy": accuracy, "roofline": roofline, "headline_context": context, "cpu_baseline": cpu, "rows": rows,
         }
         emit(out)

@@ -149,7 +149,7 @@ struct demc_handle {
     // which kernel instances the last update launched (demc_last_kernels: lets a test name the instance it compared)
     struct LastPlan {
         int k1 = -1;  // 0 k_propose per phase, 1 k_longrow, 2 k_propose resident, 3 k_propose streaming-resident, 4 k_res_mvn
-        int wg = 0, tile = 0, tail = 0, plain = 0, dt = 0, stream = 0, hist = 0;
+        int wg = 0, tile = 0, tail = 0, plain = 0, dt = 0, stream = 0, hist = 0, iso = 0;
         int k2 = 0;   // 0 none (fused into K1), 1 k_cross_mfma, 2 k_obs_loglike, 3 k_hier_loglike, 4 user plug-in
         int ks = 0, k3 = 0;
     } last;
@@ -817,7 +817,9 @@ void plan_lean(demc_handle* h) {
     // DE-MC_Z (history partners, the synchronous schedule) on the same family in SUFFSTAT mode: the lean body with partner rows
     // from the history, one launch per iteration (step_body) -- all it needs in LDS are select_base's cumulative weights and the
     // centred rows
-    if (h->family == FAM_MVN_FULL && c.D == h->d && h->d <= 32 && c.fuse == 0 && c.schedule == DEMC_SCHED_SYNCHRONOUS &&
+    // (... and on MvNormal(mu, sigma^2 I) with sigma a parameter, D = d + 1: the ISO instances of the same body)
+    const bool lean_fam = (h->family == FAM_MVN_FULL && c.D == h->d) || (h->family == FAM_MVN_ISO && c.D == h->d + 1);
+    if (lean_fam && c.D <= 32 && c.fuse == 0 && c.schedule == DEMC_SCHED_SYNCHRONOUS &&
         c.partner_kind == DEMC_PARTNER_HISTORY && c.loglike_mode == DEMC_LOGLIKE_SUFFSTAT && c.Np >= 4 && h->n_seg >= 1 &&
         (c.Np - c.Np / 2) * 4 <= 512 && h->hist) {
         bool ref = false;
@@ -931,12 +933,23 @@ int launch_lean_hist(demc_handle* h, long long iter, bool snooker) {
     k.sx = h->sx;
     k.Ainv = h->Ainv;
     tick(h, 0, true);
-    const int dt = (h->n_seg == 1 && (c.D == 32 || c.D == 8)) ? c.D : 0;
+    const bool iso = h->family == FAM_MVN_ISO;
+    // (ISO: the row length of the reference's own test -- 30 means and sigma -- has an instance with D compiled in)
+    const int dt = iso ? (c.D == 31 ? 31 : 0) : (h->n_seg == 1 && (c.D == 32 || c.D == 8)) ? c.D : 0;
     h->last = demc_handle::LastPlan();
     const bool base = iter <= c.burnin;  // random_gamma reads a base particle (crossover.jl:164): the instance that loads its row
     h->last.k1 = 4; h->last.wg = h->lean_wg; h->last.stream = 0; h->last.dt = dt; h->last.hist = snooker ? 3 : base ? 2 : 1;
+    h->last.iso = iso;
     void (*fn)(KParams) = nullptr;
-    if (snooker && h->lean_wg == 512) fn = dt == 8 ? k_res_mvn<512, false, 8, 3> : dt == 32 ? k_res_mvn<512, false, 32, 3> : k_res_mvn<512, false, 0, 3>;
+    if (iso) {
+        const int hi = snooker ? 3 : base ? 2 : 1;
+        static void (*const tab[2][2][3])(KParams) = {
+            {{k_res_mvn<256, false, 0, 1, 1, true>, k_res_mvn<256, false, 0, 2, 1, true>, k_res_mvn<256, false, 0, 3, 1, true>},
+             {k_res_mvn<256, false, 31, 1, 1, true>, k_res_mvn<256, false, 31, 2, 1, true>, k_res_mvn<256, false, 31, 3, 1, true>}},
+            {{k_res_mvn<512, false, 0, 1, 1, true>, k_res_mvn<512, false, 0, 2, 1, true>, k_res_mvn<512, false, 0, 3, 1, true>},
+             {k_res_mvn<512, false, 31, 1, 1, true>, k_res_mvn<512, false, 31, 2, 1, true>, k_res_mvn<512, false, 31, 3, 1, true>}}};
+        fn = tab[h->lean_wg == 512 ? 1 : 0][dt == 31 ? 1 : 0][hi - 1];
+    } else if (snooker && h->lean_wg == 512) fn = dt == 8 ? k_res_mvn<512, false, 8, 3> : dt == 32 ? k_res_mvn<512, false, 32, 3> : k_res_mvn<512, false, 0, 3>;
     else if (snooker) fn = dt == 8 ? k_res_mvn<256, false, 8, 3> : dt == 32 ? k_res_mvn<256, false, 32, 3> : k_res_mvn<256, false, 0, 3>;
     else if (h->lean_wg == 512 && !base) fn = dt == 8 ? k_res_mvn<512, false, 8, 1> : dt == 32 ? k_res_mvn<512, false, 32, 1> : k_res_mvn<512, false, 0, 1>;
     else if (h->lean_wg == 512) fn = dt == 8 ? k_res_mvn<512, false, 8, 2> : dt == 32 ? k_res_mvn<512, false, 32, 2> : k_res_mvn<512, false, 0, 2>;
@@ -1170,7 +1183,11 @@ int size_k1_lds(demc_handle* h) {
                                    k_res_mvn<256, false, 0, 2>, k_res_mvn<256, false, 8, 2>, k_res_mvn<256, false, 32, 2>,
                                    k_res_mvn<512, false, 0, 2>, k_res_mvn<512, false, 8, 2>, k_res_mvn<512, false, 32, 2>,
                                    k_res_mvn<256, false, 0, 3>, k_res_mvn<256, false, 8, 3>, k_res_mvn<256, false, 32, 3>,
-                                   k_res_mvn<512, false, 0, 3>, k_res_mvn<512, false, 8, 3>, k_res_mvn<512, false, 32, 3>};
+                                   k_res_mvn<512, false, 0, 3>, k_res_mvn<512, false, 8, 3>, k_res_mvn<512, false, 32, 3>,
+                                   k_res_mvn<256, false, 0, 1, 1, true>, k_res_mvn<256, false, 0, 2, 1, true>, k_res_mvn<256, false, 0, 3, 1, true>,
+                                   k_res_mvn<512, false, 0, 1, 1, true>, k_res_mvn<512, false, 0, 2, 1, true>, k_res_mvn<512, false, 0, 3, 1, true>,
+                                   k_res_mvn<256, false, 31, 1, 1, true>, k_res_mvn<256, false, 31, 2, 1, true>, k_res_mvn<256, false, 31, 3, 1, true>,
+                                   k_res_mvn<512, false, 31, 1, 1, true>, k_res_mvn<512, false, 31, 2, 1, true>, k_res_mvn<512, false, 31, 3, 1, true>};
         for (auto f : lean) HIPCHK(hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
     }
     plan_resident(h);
@@ -2597,7 +2614,8 @@ int32_t demc_last_kernels(demc_handle* h, char* out, int32_t nbytes) {
             std::snprintf(buf, sizeof buf, "k_propose<%d,true,%s,true,%s,true>", L.wg, tails[L.tail & 3], tf[L.plain]);
             break;
         case 4:
-            if (L.hist) std::snprintf(buf, sizeof buf, "k_res_mvn<%d,%s,%d,%d>", L.wg, tf[L.stream != 0], L.dt, L.hist);
+            if (L.hist && L.iso) std::snprintf(buf, sizeof buf, "k_res_mvn<%d,%s,%d,%d,iso>", L.wg, tf[L.stream != 0], L.dt, L.hist);
+            else if (L.hist) std::snprintf(buf, sizeof buf, "k_res_mvn<%d,%s,%d,%d>", L.wg, tf[L.stream != 0], L.dt, L.hist);
             else std::snprintf(buf, sizeof buf, "k_res_mvn<%d,%s,%d>", L.wg, tf[L.stream != 0], L.dt);
             break;
         default: break;

@@ -48,10 +48,16 @@ namespace demc {
 // observation stage's accumulators in AGPRs inside that budget -- so that a small population (BASELINE cfg2: 32 groups on 256 CUs)
 // is cut into twice as many observation chunks and a CU holds workgroups of two DIFFERENT groups, one group's dependent chain
 // (draws, proposal, hand-over round trip, decision) under the other's matrix stage.  Measured slower (plan_lean).
-template <int WG, bool STREAM, int DT = 0, int HIST_ = 0, int OCC = 1>
+// ISO = MvNormal(mu, sigma^2 I) with sigma a PARAMETER (theta = (mu[d], sigma), D = d + 1 <= 32; test/multivariate_normal_tests.jl:
+// 16-33, which the reference runs as DE-MC_Z with snooker, :50-59): the same body with the quadratic form on the vector pipe inside
+// the quad -- aux = |mu - xbar|^2 and S = (mu - xbar) . sum_i x~_i are eight products per lane and one quad sum each, sigma comes
+// from the lane that holds scalar d -- no A^-1, no LDS transposition, no matrix stage; the prior table has two segments (Normal on
+// mu, Cauchy+ on sigma).  HIST instances only: with current-population partners the general kernel's lean instances serve it.
+template <int WG, bool STREAM, int DT = 0, int HIST_ = 0, int OCC = 1, bool ISO = false>
 __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) void k_res_mvn(KParams p) {
     constexpr bool HIST = HIST_ != 0;
     static_assert(!(HIST && STREAM), "history partners: the SUFFSTAT form only");
+    static_assert(!ISO || (HIST && (DT == 0 || DT == 31)), "the isotropic form: DE-MC_Z instances, general row length or D = 31 (the reference's test)");
     // (one iteration per launch: launch_lean_hist never asks for more, and checks it; the kernel's own guard is the trip count of
     // the phase loop below.  An early `return` on p.n_iters != 1 HERE costs ~24 VGPRs -- round 4: 240 -> 254 and 64 B of scratch
     // in the hot instance, +25 % per launch.)
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
         reinterpret_cast<double*>(s_seg)[i] = reinterpret_cast<const double*>(p.dimseg)[i];
     DEMC_STAMP_INIT();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int D = DT ? DT : p.D, Np = p.Np, d = DT ? DT : p.d;  // D == d
+    const int D = DT ? DT : p.D, Np = p.Np, d = DT ? (ISO ? DT - 1 : DT) : p.d;  // D == d (ISO: D == d + 1)
     int g, c_idx = 0;
     if (STREAM) {
         if ((p.n_groups & 7) == 0) {
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
     // tiles, which is the short one (n_tiles rarely divides by C): its stores cost ~0.25 us per phase, and whoever stores its
     // hand-over granules last is whom the other seven wait for (tools/k1_stamps.py, slots 22 / 23)
     const bool wr_hbm = !STREAM || c_idx == p.st_C - 1;
-    const bool even = DT > 0 || (D & 1) == 0;
+    const bool even = DT > 0 ? (DT & 1) == 0 : (D & 1) == 0;
     const int half = Np / 2, nact_max = Np - half;
     // LDS: tile [Np][D] | weights [Np] | cdf [nact_max] + chunk offsets [16] | centred theta' rows [WG/4][D+2] |
     //      STREAM: y rows [WG/4][dpad] | per-wave partials [WG/64][nact_max] | X chunk
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
     for (int e = 0; e < 8; ++e) {
         const int j = (e < 4 ? jA : jB - 4) + e;
         const int jj = j < D ? j : 0;
-        xb[e] = p.xbar[jj];
+        xb[e] = (!ISO || jj < d) ? p.xbar[jj] : 0.0;  // (ISO: scalar d is sigma -- xbar has d entries)
         unsigned sg = 0;
         for (int i = 1; i < p.n_seg; ++i) sg += (jj >= p.dimseg[i].start) ? 1u : 0u;
         segs |= sg << (4 * e);
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
         }
     };
     double bfrag[2][8];
-    {
+    if constexpr (!ISO) {
         const int kq = lane >> 4, col = lane & 15;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -193,6 +199,14 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
         }
         sx8[0] = p.sx ? p.sx[2 * sl] : 0.0;
         sx8[1] = p.sx ? p.sx[2 * sl + 1] : 0.0;
+    }
+    double sxl[8];  // ISO: sum_i x~_i at the lane's eight scalars (zero at sigma's and past the row)
+    if constexpr (ISO) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int j = (e < 4 ? jA : jB - 4) + e;
+            sxl[e] = (p.sx && j < d) ? p.sx[j] : 0.0;
+        }
     }
     const int mc0 = lane & 15, mc1 = mc0 + 16;  // the two columns this lane sees of every MFMA result
     const double sx0 = (p.sx && mc0 < d) ? p.sx[mc0] : 0.0, sx1 = (p.sx && mc1 < d) ? p.sx[mc1] : 0.0;
@@ -268,9 +282,15 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
                 if (even) {
                     if (acc_) *reinterpret_cast<double2*>(trow + j + e) = x;
                     if (hrow) *reinterpret_cast<double2*>(hrow + j + e) = x;
+                } else if (j + e + 1 < D) {  // (odd row length: 16-byte stores at 8-byte alignment, as the loads)
+                    typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+                    d2u xu;
+                    xu.x = x.x; xu.y = x.y;
+                    if (acc_) *reinterpret_cast<d2u*>(trow + j + e) = xu;
+                    if (hrow) *reinterpret_cast<d2u*>(hrow + j + e) = xu;
                 } else {
-                    if (acc_) { trow[j + e] = x.x; if (j + e + 1 < D) trow[j + e + 1] = x.y; }
-                    if (hrow) { hrow[j + e] = x.x; if (j + e + 1 < D) hrow[j + e + 1] = x.y; }
+                    if (acc_) trow[j + e] = x.x;
+                    if (hrow) hrow[j + e] = x.x;
                 }
             }
         }
@@ -422,7 +442,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
         double v8[8];
         int oob = 0;
         double prior = 0.0;
-        const bool one_seg = DT > 0 || p.n_seg == 1;  // the usual case for this family: every scalar shares one table entry
+        const bool one_seg = (DT > 0 && !ISO) || p.n_seg == 1;  // the usual case for this family: every scalar shares one table entry
         // ... which is then wave-uniform: through readfirstlane its fields sit in SGPRs and the switch on the prior kind is a
         // scalar branch (as a per-lane value it compiles to one exec-masked region per prior kind and scalar)
         auto uni = [](double x) {
@@ -437,6 +457,12 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
                 o[0] = a.x; o[1] = a.y;
             } else if (even && j0 + 3 < D) {
                 const double2 a = *reinterpret_cast<const double2*>(row + j0), b = *reinterpret_cast<const double2*>(row + j0 + 2);
+                o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+            } else if (HIST && j0 + 3 < D) {
+                // an odd row length (rows 8-byte aligned only): still two 16-byte loads -- global memory takes them at any dword
+                // alignment -- instead of four 8-byte ones (half the load instructions and address registers of the ISO instances)
+                typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+                const d2u a = *reinterpret_cast<const d2u*>(row + j0), b = *reinterpret_cast<const d2u*>(row + j0 + 2);
                 o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
             } else
 #pragma unroll
@@ -525,7 +551,11 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
                     } else {
                         const DimTab* tb = &s_seg[(segs >> (4 * e)) & 15u].t;
                         oob |= !(v >= tb->lo && v <= tb->hi);
-                        if (tb->kind != PR_FLAT) prior += prior_term_outofline(tb, v);
+                        if (tb->kind == PR_NORMAL) {  // (the bulk of any row: inline; a call per scalar is ~100 instructions and its spills)
+                            const double z = (v - tb->a) * tb->b;
+                            prior += tb->c - 0.5 * (z * z);
+                        } else if (tb->kind != PR_FLAT)
+                            prior += prior_term_outofline(tb, v);
                     }
                 }
             }
@@ -556,7 +586,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
         prior = subgroup_sum(prior, 4);
         oob = subgroup_sum(oob, 4);
         // ---- y = A^-1 (theta' - xbar) on the matrix cores: centred rows through LDS into operand order ----
-        if constexpr (!DIRECT8) {
+        if constexpr (!DIRECT8 && !ISO) {
             double* row = scr + (size_t)q * scr_stride;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -564,8 +594,24 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
                 if (j < D) row[j] = v8[e] - xb[e];
             }
         }
-        double aux, S = 0.0;
-        if constexpr (DIRECT8) {
+        double aux, S = 0.0, sg_iso = 1.0;
+        if constexpr (ISO) {
+            // A = I: the lane's share of |mu~|^2 and mu~ . sum_i x~_i, and sigma from the lane that holds scalar d
+            double a_ = 0.0, s_ = 0.0, sg_ = 0.0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int j = (e < 4 ? jA : jB - 4) + e;
+                const double c = v8[e] - xb[e];
+                if (j < d) {
+                    a_ = fma(c, c, a_);
+                    s_ = fma(c, sxl[e], s_);
+                }
+                if (j == d) sg_ = v8[e];
+            }
+            aux = subgroup_sum(a_, 4);
+            S = subgroup_sum(s_, 4);
+            sg_iso = subgroup_sum(sg_, 4);  // (three zeros and sigma)
+        } else if constexpr (DIRECT8) {
             // d = 8: the 8 x 8 product on the vector pipe inside the quad -- lane m holds the centred scalars 2 m and 2 m + 1,
             // quad_perm hands them round, lane sl forms columns 2 sl and 2 sl + 1 (16 FMAs) and its share of theta~.y.
             // The MFMA route (LDS transposition, two matrix instructions, four 16-lane reductions, LDS again) is a chain
@@ -719,7 +765,12 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
         DEMC_STAMP_AT(23, 0, (double)(__builtin_amdgcn_s_memrealtime() & 0xffffffffull));
         // ---- compute_posterior! + mh_update! + store_samples! (utilities.jl:92-99, 55-58, 201-210, 161-180) ----
         const double w = HIST ? w_h : w_s[pl];
-        const double wp = oob ? -INFINITY : prior + (p.c0 - 0.5 * (p.c1 - 2.0 * S + (double)p.N * aux));
+        double wp;
+        if constexpr (ISO) {  // loglike_from_stats' MVN_ISO form (c1 = sum_i |x~_i|^2)
+            const double nd = (double)p.N * (double)d;
+            wp = oob ? -INFINITY : prior + (-0.5 * nd * kLog2Pi - nd * log(sg_iso) - 0.5 * (p.c1 - 2.0 * S + (double)p.N * aux) / (sg_iso * sg_iso));
+        } else
+            wp = oob ? -INFINITY : prior + (p.c0 - 0.5 * (p.c1 - 2.0 * S + (double)p.N * aux));
         double adj = 0.0;
         if constexpr (HSNK) {
             if (__ballot(snk) != 0ull) {

@@ -288,7 +288,13 @@ int32_t demc_comm_stats(demc_handle* h, int64_t* out3);
  * (demc_config.geometry_groups) -- kernel form and observation-chunk count of the STREAMING likelihood included -- so the set
  * reproduces a single handle of n_groups groups bit for bit.  Shards that share a device run on ONE stream (the first such
  * shard's; do not give them streams of their own with demc_set_stream): the streaming-resident kernels assume the chip to
- * themselves.  demc_comm_init / _destroy / _set_overlap are refused on a shard (DEMC_EINVAL): its communicator belongs to the set.
+ * themselves; demc_set_stream on a shard of a built set is refused, DEMC_EINVAL).  demc_comm_init / _destroy / _set_overlap are
+ * refused on a shard (DEMC_EINVAL): its communicator belongs to the set.
+ * History partners (partner_kind = DEMC_PARTNER_HISTORY, `resample`, crossover.jl:113-124) draw their cells from the history of
+ * ALL particles of the population; a shard holds the history of its own groups only.  A set of more than one shard could
+ * therefore not reproduce the single handle it stands for, and demc_create_multi refuses the combination (DEMC_EUNSUPPORTED).
+ * On the one-process-per-GPU road (group_offset / n_groups_total + demc_comm_init) DE-MC_Z runs with the SHARD-LOCAL pool --
+ * rows 1:(iter-1) x the rank's own particles -- the deviation SURVEY 8(e) names; it is not bit-equal to an unsharded run.
  *   demc_multi_shard(m, r) : the shard's handle, for the per-shard calls -- demc_set_model / _priors / _bounds / _blocks (the
  *                            same on every shard), demc_set_state / demc_get_state / demc_get_history with the shard's own
  *                            P/n_shards particles.  Shards are destroyed with the set.

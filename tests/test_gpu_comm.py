@@ -275,6 +275,20 @@ def test_multi_set_rejects_bad_shapes(D):
     assert err.value.code == D._ffi.EINVAL and "divide" in str(err.value)
     with pytest.raises(D.DemcError):
         D.MultiEngine(2, device_ids=[0, 0], n_groups=8, Np=6, D=2, group_offset=2)
+    # DE-MC_Z draws partner cells from the history of ALL particles (crossover.jl:113-124); a shard holds its own groups' history:
+    # a sharded set cannot reproduce the single handle it stands for, so the combination is refused -- one shard is fine
+    with pytest.raises(D.DemcError) as err:
+        D.MultiEngine(2, device_ids=[0, 0], n_groups=8, Np=6, D=2, n_rows=8, n_initial=2, schedule=1, partner_kind=1)
+    assert err.value.code == D._ffi.EUNSUPPORTED and "history" in str(err.value)
+    one = D.MultiEngine(1, device_ids=[0], n_groups=8, Np=6, D=2, n_rows=8, n_initial=2, schedule=1, partner_kind=1)
+    # the streams of a built set belong to the set (shards on one device borrow the first one's): re-pointing one is refused
+    two = D.MultiEngine(2, device_ids=[0, 0], n_groups=8, Np=6, D=2)
+    for e in two.shards:
+        with pytest.raises(D.DemcError) as err:
+            e.set_stream(None)
+        assert err.value.code == D._ffi.EINVAL and "belong to the set" in str(err.value)
+    two.close()
+    one.close()
 
 
 def test_sharded_driver_with_the_library_collective(D):

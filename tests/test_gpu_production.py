@@ -172,6 +172,47 @@ def test_de_mc_z_with_snooker_as_the_reference_runs_it(demc, orc, d, Np, burnin,
              partner_kind=1, n_initial=8, burnin=burnin, theta_snooker=snooker)
 
 
+@pytest.mark.parametrize("Np,burnin,snooker,beta,kernel", [
+    (64, 0, 0.1, 0.0, "k_res_mvn<256,false,31,3,iso>"),  # the reference's own setting: DE-MC_Z + snooker 0.1 (:50-59), past burn-in
+    (64, 100, 0.1, 0.0, "k_res_mvn<256,false,31,3,iso>"),  # ... inside burn-in: base particles for the crossover particles of a wave
+    (200, 100, 0.5, 0.3, "k_res_mvn<512,false,31,3,iso>"),  # 512 threads, half the particles snooker, mutation sweeps
+    (64, 0, 0.0, 0.0, "k_res_mvn<256,false,31,1,iso>"),   # no snooker: instance 1 past burn-in
+    (30, 100, 0.0, 0.0, "k_res_mvn<256,false,31,2,iso>"),  # ... instance 2 inside it; halves of 15 leave quads without a particle
+])
+def test_mvn30_de_mc_z_takes_the_lean_iso_instance(demc, orc, Np, burnin, snooker, beta, kernel):
+    """test/multivariate_normal_tests.jl:6-59: MvNormal(mu, sigma^2 I) with sigma a parameter (theta = (mu[30], sigma), D = 31:
+    an odd row, two prior segments -- Normal on mu, Cauchy+ on sigma -- and a lower bound on sigma), run by the reference as DE-MC_Z
+    with theta_snooker = 0.1.  Round 4 served it with the general kernel's LEAN-2 instance; round 5 gave the lean DE-MC_Z body an
+    isotropic form (k_res_mvn<..., iso>: |mu - xbar|^2 on the vector pipe inside the quad, no matrix stage).  The workload of
+    bench.py's mvn30 rows on 6 groups, free-running against the oracle: every accept decision and id equal, lp to 1e-9,
+    theta to 1e-10 (snooker projections and mutation's device log are reduced / evaluated in another order)."""
+    from demc_amd import workloads as W
+    w = W.mvn30(G=6, Np=Np)
+    free_run(demc, orc, w, 8 + 12, [], 6, Np, theta_exact=(snooker == 0.0 and beta == 0.0), exact_kernels=kernel, beta=beta, loglike_mode=1,
+             schedule=1, partner_kind=1, n_initial=8, burnin=burnin, theta_snooker=snooker)
+    if Np == 64 and burnin == 100:  # another row length (12 means + sigma: the instance without a compiled-in D)
+        w = W.mvn30(d=12, G=6, Np=Np)
+        free_run(demc, orc, w, 8 + 12, [], 6, Np, theta_exact=False, exact_kernels="k_res_mvn<256,false,0,3,iso>", beta=0.0, loglike_mode=1,
+                 schedule=1, partner_kind=1, n_initial=8, burnin=burnin, theta_snooker=snooker)
+
+
+@pytest.mark.parametrize("burnin,kernels", [
+    (0, "k_longrow<512>"),  # past burn-in nothing a particle reads is written in the launch: ONE k_longrow launch per block sweep
+    (100, "k_propose<256,false,TAIL_NONE,false,2> + k_hier_loglike + k_accept_store"),  # inside: a base row of the current population
+])
+def test_hierarchical_example_configuration_de_mc_z_snooker_blocks(demc, orc, burnin, kernels):
+    """Examples/Hierarchical_Example.jl:88-114 -- the reference's own hierarchical run: `sample = resample` (DE-MC_Z), theta_snooker =
+    0.1, block updates [hyper ; subject] on every iteration -- on cfg4's family with long rows (S = 2100 subjects: a workgroup per
+    particle), as bench.py's cfg4_whole_history_partners_snooker_blocks rows run it: long partner rows gathered from the
+    history, snooker updates that read three of them and need them in the hyper-parameter sweep too (adjust_loglike's norms run
+    over every scalar).  Free-running against the oracle; which kernels serve it is asserted: the long-row kernel past burn-in,
+    the per-phase chain inside it (a base particle of the current population could be written by another workgroup of the launch)."""
+    from demc_amd import workloads as W
+    w = W.cfg4(S=2100, G=4, Np=8)
+    free_run(demc, orc, w, 4 + 8, [], 4, 8, theta_exact=False, exact_kernels=kernels, beta=0.0, schedule=1, partner_kind=1, n_initial=4,
+             burnin=burnin, theta_snooker=0.1, lp_rtol=1e-8)
+
+
 def _de_mc_z_cases(n, seed=20261004):
     rng = np.random.default_rng(seed)
     out = []

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""The ONE current measurement table of DESIGN.md section 6, generated from the committed records of a round:
+    python3 tools/design_tables.py profiles/r05 > /tmp/table.md
+Per row of bench.ROWS (and the headline): value, ms per step, the dominant kernel's launch time and roofline fraction from
+`bench_<row>_line.json` (the un-profiled run's full record), the rocprofv3 --stats average of the same kernel from
+`bench_<row>_kernel_stats.csv`, and the counters (`bench_<row>_pmc.json`, `bench_<row>_pipe_pmc.json`).  Nothing is typed by
+hand into that table: a number that is not in profiles/<round>/ is not in DESIGN.md."""
+import csv
+import json
+import os
+import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+
+def g(x, n=4):
+    return "—" if x is None else f"{x:.{n}g}"
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"\(.*$", "", name)
+    return name.replace("demc::", "")
+
+
+def main(d):
+    print("| row | particle-updates/s | ms / step | kernels (`demc_last_kernels`) | per launch (HIP events; `--stats` average) | `roofline.frac` (bound) | counters |")
+    print("|---|---|---|---|---|---|---|")
+    for row in ["headline"] + [n for n, _ in bench.ROWS]:
+        ln = os.path.join(d, f"bench_{row}_line.json")
+        if not os.path.exists(ln):
+            continue
+        rec = json.load(open(ln))
+        if row != "headline" and rec.get("rows"):
+            rec = rec["rows"][0]
+        rf = rec.get("roofline") or {}
+        stats = ""
+        st = os.path.join(d, f"bench_{row}_kernel_stats.csv")
+        if os.path.exists(st):
+            rows = sorted((r for r in csv.DictReader(open(st)) if "demc" in r["Name"]), key=lambda r: -float(r["TotalDurationNs"]))
+            if rows:
+                r = rows[0]
+                stats = f"; `{short(r['Name'])[:40]}` {r['Calls']} calls, {g(float(r['AverageNs']) / 1e3)} µs"
+        ctr = []
+        if rf.get("traffic") is not None:
+            ctr.append(f"{g(rf['traffic'] / 1e6)} MB/launch ({g(rf.get('wasted_traffic_ratio'), 3)}× algorithmic)")
+        if rf.get("counter_frac") is not None:
+            ctr.append(f"{g(rf['counter_frac'], 3)} of HBM by counter bytes")
+        if rf.get("fetch_bytes_per_update") is not None:
+            ctr.append(f"FETCH {g(rf['fetch_bytes_per_update'])} B/update (gather {g(rf.get('gather_bytes_per_update'))})")
+        pp = os.path.join(d, f"bench_{row}_pipe_pmc.json")
+        if os.path.exists(pp):
+            best = None
+            for k, v in json.load(open(pp)).items():
+                if isinstance(v, dict) and ("SQ_WAVE_CYCLES_mean" in v) and (best is None or v["SQ_WAVE_CYCLES_mean"] > best["SQ_WAVE_CYCLES_mean"]):
+                    best = v
+            if best:
+                for key, label in (("mfma_busy_frac", "MFMA busy"), ("valu_busy_frac", "VALU busy"), ("lds_busy_frac", "LDS busy")):
+                    if best.get(key) is not None:
+                        ctr.append(f"{label} {g(best[key], 3)}")
+        kern = rec.get("kernels") or (rf.get("kernel") or "")[:60]
+        print(f"| `{row}` | {g(rec.get('value'))} | {g(rec.get('ms_per_step'))} | `{kern}` | {g((rf.get('launch_ms') or 0) * 1e3)} µs{stats} | "
+              f"**{g(rf.get('frac'), 3)}** ({rf.get('bound')}) | {'; '.join(ctr) or '—'} |")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
