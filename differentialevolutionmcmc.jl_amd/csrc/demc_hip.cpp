@@ -98,6 +98,7 @@ struct demc_handle {
     size_t res_lds = 0;
     // streaming-resident form (plan_stream): the MvNormal observation stream inside the resident kernel
     bool st_ok = false;
+    bool tf_cheap_obs = false;  // set_tail_flags' "the likelihood is cheap enough for K1" of the last call (launch_phase reads it)
     int st_C = 0, st_nact_max = 0, st_rows = 0, st_x_lds = 0, st_chunk_tiles = 0, st_lpp = 0, st_scr_doubles = 0, st_wg = 512;
     // the lean streaming kernel's own cut of the observation tiles (plan_lean): st_C, or twice that with two workgroups per CU
     int lean_st_C = 0, lean_st_chunk_tiles = 0, lean_st_x_lds = 0, lean_st_occ = 1;
@@ -615,6 +616,7 @@ void set_tail_flags(demc_handle* h, KParams& k) {
     const bool hist_private = c.schedule == DEMC_SCHED_SYNCHRONOUS && c.partner_kind == DEMC_PARTNER_HISTORY && k.mode == MODE_STEP &&
                               !(c.proposal_kind == 0 && k.iter <= c.burnin);
     const bool phase_private = c.schedule == DEMC_SCHED_TWO_COLOUR || c.schedule == DEMC_SCHED_SEQUENTIAL || k.mode == MODE_IDENT || hist_private;
+    h->tf_cheap_obs = cheap_obs;
     k.fuse_obs = (cheap_obs && phase_private && c.fuse != 1) ? 1 : 0;
     k.fuse_accept = (((k.fuse_prep && suff) || k.fuse_obs) && c.fuse != 1 && phase_private) ? 1 : 0;
     k.write_prop = (!k.fuse_accept || k.trace) ? 1 : 0;
@@ -664,10 +666,32 @@ int launch_phase(demc_handle* h, KParams& k) {
     k.plan = (tile && k.mode == MODE_STEP && k.lpp >= 4 && k.lpp <= 64 && lds_tile + plan_bytes <= kMaxDynLds && !h->rp_active) ? 1 : 0;
     if (const char* e = experiment("DEMC_K1_PLAN")) k.plan = k.plan && e[0] == '1';  // A/B experiments
     // long rows of a hierarchical family, whole update fused: the dedicated one-pass kernel (demc_longrow.hpp)
-    if (k.lpp > 64 && h->hier_scr && k.fuse_obs && k.fuse_accept && k.mode == MODE_STEP && !h->rp_active && c.fuse != 2 && h->n_seg > 0) {
-        const size_t cdf_doubles = k.pool_n > 256 ? (size_t)k.pool_n + ((size_t)k.pool_n + 15) / 16 : 0;
-        const size_t lr_lds = ((((size_t)c.D + 1) & ~(size_t)1) + cdf_doubles) * sizeof(double);
-        if (lr_lds <= kMaxDynLds) {
+    const size_t cdf_doubles = k.pool_n > 256 ? (size_t)k.pool_n + ((size_t)k.pool_n + 15) / 16 : 0;
+    const size_t lr_lds = ((((size_t)c.D + 1) & ~(size_t)1) + cdf_doubles) * sizeof(double);
+    const bool lr_shape = k.lpp > 64 && h->hier_scr && k.mode == MODE_STEP && !h->rp_active && c.fuse != 2 && h->n_seg > 0 && lr_lds <= kMaxDynLds;
+    // DE-MC_Z INSIDE burn-in (Examples/Hierarchical_Example.jl:103-114 spends half its run there): random_gamma's base particle
+    // (crossover.jl:156-164) is a row of the current population, which another workgroup of this synchronous launch may be writing,
+    // so set_tail_flags left the sweep unfused (K1 -> k_hier_loglike -> K3 through the proposal buffer: 2.3x the time).  The rows
+    // and weights of the sweep's START are what the synchronous schedule reads anyway: two device-to-device copies (into the
+    // proposal buffers, which a fused sweep does not use) make them a snapshot nobody writes, and the sweep is ONE k_longrow
+    // launch again -- base rows and select_base's weights from the snapshot (KParams::base_theta / base_weight).
+    // The same holds for every family whose update fuses into K1 past burn-in (the general kernel's no-tile form reads its base
+    // rows through the same two pointers): with the snapshot, DE-MC_Z is one launch per sweep inside burn-in as well as past it.
+    const bool suff_mvn = k.fuse_prep && c.loglike_mode == DEMC_LOGLIKE_SUFFSTAT;
+    if (!k.fuse_accept && k.mode == MODE_STEP && c.schedule == DEMC_SCHED_SYNCHRONOUS && c.partner_kind == DEMC_PARTNER_HISTORY &&
+        c.proposal_kind == 0 && k.iter <= c.burnin && (h->tf_cheap_obs || suff_mvn) && c.fuse == 0 && !k.trace && !h->rp_active &&
+        k.theta == h->theta) {
+        bool on = true;
+        if (const char* e = experiment("DEMC_LR_SNAPSHOT")) on = e[0] == '1';  // A/B experiments
+        if (on) {
+            HIPCHK(hipMemcpyAsync(h->prop, h->theta, sizeof(double) * (size_t)h->P * c.D, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->prop_prior, h->weight, sizeof(double) * (size_t)h->P, hipMemcpyDeviceToDevice, h->stream));
+            k.base_theta = h->prop; k.base_weight = h->prop_prior;
+            k.fuse_obs = h->tf_cheap_obs ? 1 : 0; k.fuse_accept = 1; k.write_prop = 0;
+        }
+    }
+    if (lr_shape && k.fuse_obs && k.fuse_accept) {
+        {
             if (const char* e = experiment("DEMC_LR_EXIT")) k.n_split = -std::atoi(e);  // A/B experiments
             if (const char* e = experiment("DEMC_LR_DEFER"))
                 if (e[0] == '0' && k.n_split >= 0) k.n_split = -100;

@@ -144,6 +144,11 @@ struct KParams {
     const double* Xf;               // [n_tiles+1][dpad/4][64] fragment-ordered data (demc_set_model)
     unsigned long long* st_gran;    // [2][n_groups][st_C][st_nact_max][2] hand-over granules {epoch:32 | half of a double:32}
     unsigned* st_err;               // set to 1 if a hand-over timed out (never, with co-resident workgroups)
+    // DE-MC_Z inside burn-in on long rows (k_longrow, synchronous schedule): random_gamma's base particle (crossover.jl:156-164)
+    // is a row of the CURRENT population, which another workgroup of the same launch may be writing -- so the base rows and the
+    // weights select_base reads come from a SNAPSHOT of the sweep's start (null: the live arrays)
+    const double* base_theta;       // [P][D]
+    const double* base_weight;      // [P]
     // run-length tables IN the kernarg (scalar loads, no memory behind them) for wave-uniform look-ups (demc_longrow.hpp):
     // first scalars of the table segments; first scalars of the runs of the sweep's block mask, bit r of mrun_in = run r
     // lies inside the block (no blocks: one run, inside); n_mrun = 0: more runs than kMaxMaskRun.  Bit q of seg_plain:
@@ -1037,7 +1042,9 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
     // half in two_colour -- so nothing a moving particle reads (partners, base row, base weights) can change during
     // the phase, which is what makes the fused accept tail race-free across workgroups.
     const int n_cdf = p.pool_n;
-    const double* pw = (RES ? w_s : gw) + p.pool_lo;
+    // (no-tile form with a snapshot of the sweep's start -- KParams::base_weight / base_theta: DE-MC_Z inside burn-in, where the base
+    // particle is a row of the current population that another workgroup of the synchronous launch may be writing)
+    const double* pw = (RES ? w_s : (!TILE && p.base_weight) ? p.base_weight + (size_t)g * Np : gw) + p.pool_lo;
     // Order of the prologue: a wave's memory results return in issue order, so the few global reads the prologue itself
     // consumes (pool weights, A^-1, xbar) are issued FIRST, all at once, and the bulk tile copy after them; the copy
     // then stays in flight under the softmax prefix sums and the plan stage, none of which touch global memory.
@@ -1098,6 +1105,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
     DEMC_STAMP(15);  // tile copy issued
     // indexed by the row's position in its group; only pool rows (and, through pt below, own rows) are ever touched
     const double* rows = RES ? (const double*)tile : TILE ? (const double*)tile - (ptrdiff_t)p.pool_lo * D : grows;
+    const double* rows_base = (!TILE && p.base_theta) ? p.base_theta + (size_t)g * Np * D : rows;  // where a base row is read from
     if (use_base && wave == 0) {
         // stabilised: e_j = exp(w_j - max w); cumulative weights in the fixed three-level order of the oracle (wave_cdf):
         // sequential inside quads, over the quad totals of a chunk of 16, over the chunk totals.
@@ -1406,7 +1414,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
                 vm = group_sum(vm, lpp, s_gsum); vn = group_sum(vn, lpp, s_gsum); vd = group_sum(vd, lpp, s_gsum);
                 cm = vm / vd; cn = vn / vd;
             } else if (i2 >= 0) {
-                Pbase = rows + (size_t)i2 * D;
+                Pbase = rows_base + (size_t)i2 * D;
                 base_on = true;
             }
         } else if (p.mode == MODE_STEP) {
@@ -1515,7 +1523,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
                             }
                             b += p.pool_lo;
                             if (rpi && rpi[2] >= 0) b = (int)rpi[2];
-                            Pbase = rows + (size_t)b * D;
+                            Pbase = rows_base + (size_t)b * D;
                             i2 = b;
                             base_on = true;
                         }

@@ -148,6 +148,8 @@ __global__ __launch_bounds__(WG, (WG / 64 * PER_CU + 3) / 4) void k_longrow(KPar
     const uint32_t eslot = (uint32_t)g_glob * (uint32_t)Np + (uint32_t)pl;
     const double* grows = p.theta + (size_t)g * Np * D;
     const double* gw = p.weight + (size_t)g * Np;
+    // (the weights select_base reads and the base row: the sweep-start snapshot when the launch has one -- KParams::base_theta)
+    const double* gwb = p.base_weight ? p.base_weight + (size_t)g * Np : gw;
     const double* pt = grows + (size_t)pl * D;
     const double w_cur = gw[pl];
     DEMC_STAMP_AT(16, 64, DEMC_STAMP_NOW() + (unsigned long long)(D & 1));  // kernarg in, addresses formed
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(WG, (WG / 64 * PER_CU + 3) / 4) void k_longrow(KPar
     if (maybe_base) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (lane + 64 * r < p.pool_n) pw_r[r] = gw[p.pool_lo + lane + 64 * r];
+            if (lane + 64 * r < p.pool_n) pw_r[r] = gwb[p.pool_lo + lane + 64 * r];
     }
 
     // ---- per-particle scalars: lanes 0..5 of every wave evaluate one Philox block each, the words travel through SGPRs ----
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(WG, (WG / 64 * PER_CU + 3) / 4) void k_longrow(KPar
     // alone; the other waves go straight to their first row loads and noise draws and meet it at the barrier below.
     const int n_cdf = p.pool_n;
     if (use_base && wave == 0) {
-        const double* pw = gw + p.pool_lo;
+        const double* pw = gwb + p.pool_lo;
         double m = -INFINITY;
         if (n_cdf <= 256) {
 #pragma unroll
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(WG, (WG / 64 * PER_CU + 3) / 4) void k_longrow(KPar
     }
     if (use_base) {
         i2 = s_base;
-        Pbase = grows + (size_t)i2 * D;
+        Pbase = (p.base_theta ? p.base_theta + (size_t)g * Np * D : grows) + (size_t)i2 * D;
         base_on = true;
     }
 

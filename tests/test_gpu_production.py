@@ -197,20 +197,44 @@ def test_mvn30_de_mc_z_takes_the_lean_iso_instance(demc, orc, Np, burnin, snooke
 
 
 @pytest.mark.parametrize("burnin,kernels", [
-    (0, "k_longrow<512>"),  # past burn-in nothing a particle reads is written in the launch: ONE k_longrow launch per block sweep
-    (100, "k_propose<256,false,TAIL_NONE,false,2> + k_hier_loglike + k_accept_store"),  # inside: a base row of the current population
+    (0, "k_longrow<512>"),    # past burn-in nothing a particle reads is written in the launch: ONE k_longrow launch per block sweep
+    (100, "k_longrow<512>"),  # inside it random_gamma reads a base particle of the current population: from a snapshot of the sweep's start
+    (4, "k_longrow<512>"),    # ... and a run that leaves burn-in on the way
 ])
 def test_hierarchical_example_configuration_de_mc_z_snooker_blocks(demc, orc, burnin, kernels):
     """Examples/Hierarchical_Example.jl:88-114 -- the reference's own hierarchical run: `sample = resample` (DE-MC_Z), theta_snooker =
     0.1, block updates [hyper ; subject] on every iteration -- on cfg4's family with long rows (S = 2100 subjects: a workgroup per
     particle), as bench.py's cfg4_whole_history_partners_snooker_blocks rows run it: long partner rows gathered from the
     history, snooker updates that read three of them and need them in the hyper-parameter sweep too (adjust_loglike's norms run
-    over every scalar).  Free-running against the oracle; which kernels serve it is asserted: the long-row kernel past burn-in,
-    the per-phase chain inside it (a base particle of the current population could be written by another workgroup of the launch)."""
+    over every scalar).  Free-running against the oracle; which kernel serves it is asserted: the long-row kernel, past burn-in
+    and -- round 5 -- inside it too (the base particle of the current population, which another workgroup of the synchronous
+    launch may be writing, is read from a device-to-device snapshot of the sweep's start; round 4 fell back to the per-phase
+    chain K1 -> k_hier_loglike -> K3 there, 2.3x the time)."""
     from demc_amd import workloads as W
     w = W.cfg4(S=2100, G=4, Np=8)
     free_run(demc, orc, w, 4 + 8, [], 4, 8, theta_exact=False, exact_kernels=kernels, beta=0.0, schedule=1, partner_kind=1, n_initial=4,
              burnin=burnin, theta_snooker=0.1, lp_rtol=1e-8)
+
+
+@pytest.mark.parametrize("which", ["hier_small", "gaussian", "mvn_general_row"])
+def test_de_mc_z_inside_burn_in_is_one_launch_for_the_general_kernel_too(demc, orc, which):
+    """DE-MC_Z inside burn-in on the families the GENERAL kernel serves (short hierarchical rows with the reference's blocks and
+    snooker, Examples/Gaussian_Example.jl's model, an MvNormal row the lean body has no instance for): random_gamma's base
+    particle is read from the snapshot of the sweep's start (KParams::base_theta), so the synchronous sweep is ONE fused launch
+    -- no K3 -- as it is past burn-in; every decision equal to the oracle's."""
+    from demc_amd import workloads as W
+    extra = dict(theta_snooker=0.1)
+    if which == "hier_small":
+        w, G, Np = W.cfg4(S=40, G=6, Np=16), 6, 16
+    elif which == "gaussian":
+        w, G, Np = W.cfg1(), 4, 10
+        extra = {}
+    else:
+        w, G, Np = W.cfg3(N=500, d=40, G=4, Np=24), 4, 24  # (D = 40 > 32: no lean instance)
+        extra = dict(loglike_mode=1)
+    ran = free_run(demc, orc, w, 4 + 10, [], G, Np, theta_exact=False, beta=0.0, schedule=1, partner_kind=1, n_initial=4, burnin=100,
+                   lp_rtol=1e-8, **extra)
+    assert "k_propose<" in ran and "k_accept_store" not in ran, ran
 
 
 def _de_mc_z_cases(n, seed=20261004):

@@ -39,8 +39,6 @@ def dominant_pattern(over):
         return "k_direct_mvn"
     if cfg in ("cfg2", "cfg3"):
         return "k_res_mvn|k_propose<"  # (history partners: the lean body past burn-in, k_propose<256,false,...> inside it)
-    if cfg == "cfg4" and over.get("partners") == "history" and over.get("burnin", 1000) > 0:
-        return "k_hier_loglike|k_propose<"  # (inside burn-in the synchronous sweep is the per-phase chain, not k_longrow)
     return {"cfg4": "k_longrow", "cfg5": "k_lba_loglike|k_obs_loglike", "cfg1": "k_propose<", "mvn30": "k_res_mvn|k_propose<"}[cfg]
 
 
