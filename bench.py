@@ -350,6 +350,22 @@ def measured_traffic(a, launches, k_iters):
     return None, None
 
 
+def longrow_shape_roof_ms():
+    """(subject-sweep + hyper-parameter-sweep launch of the traffic probe) / 2 in ms, from the committed probe output; None if absent"""
+    import re
+    try:
+        txt = open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "longrow_traffic_probe.txt")).read()
+    except OSError:
+        return None
+    us = {}
+    for kind in ("subject sweep", "hyper sweep"):
+        m = re.search(re.escape(kind) + r"[^\n]*WG 256 x 2/CU[^\n]*work   0 ahead 1 \|\s+([0-9.]+) us/launch", txt)
+        if not m:
+            return None
+        us[kind] = float(m.group(1))
+    return (us["subject sweep"] + us["hyper sweep"]) / 2.0 * 1e-3
+
+
 LAST_PROFILE_REC = {}  # the `dominant` record measured_traffic() read last (FETCH / WRITE split for the rows that quote it)
 
 
@@ -500,6 +516,14 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
                   launch_ms=t_s / n_launch * 1e3, launches=n_launch, updates_per_launch=sweeps * P * k_iters / n_launch,
                   traffic=traffic, traffic_source=src,
                   wasted_traffic_ratio=None if traffic is None else traffic / (necessary_bytes / n_launch))
+        # what a bare kernel of this traffic shape reaches on this chip (tools/longrow_traffic_probe.hip: the kernel's row traffic and
+        # occupancy, no arithmetic; profiles/<round>/longrow_traffic_probe.txt, measured at the whole cfg4's size): the average of
+        # a subject-sweep and a hyper-parameter-sweep launch is the roof of the SHAPE -- quoted next to the 8 TB/s fraction
+        roof = longrow_shape_roof_ms() if (a.partners == "current" and w["G"] == 128 and w["Np"] == 32 and S == 10000 and sweeps == 2) else None
+        if roof is not None:
+            rf["shape_roof_launch_ms"] = roof
+            rf["shape_frac"] = roof / (t_s / n_launch * 1e3)
+            rf["shape_roof_source"] = f"profiles/{PROFILE_ROUND}/longrow_traffic_probe.txt (subject sweep + hyper-parameter sweep) / 2"
         if a.partners == "history":
             rf["gather_bytes_per_update"] = gather_bytes / (sweeps * P * k_iters)
             fb = LAST_PROFILE_REC.get("fetch_bytes_per_launch")
@@ -804,7 +828,8 @@ def measure_row(name, a, w, demc_amd, local):
     rf = roofline_of(a, w, tm, a.steps, P, dt / a.steps)
     keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "launch_ms", "launches", "traffic", "traffic_source",
             "wasted_traffic_ratio", "flop_counted", "bytes_counted", "counter_frac", "necessary_frac", "survey_formula_frac",
-            "valu_busy_frac", "lds_busy_frac", "device_ms_per_iter", "gather_bytes_per_update", "fetch_bytes_per_update")
+            "valu_busy_frac", "lds_busy_frac", "device_ms_per_iter", "gather_bytes_per_update", "fetch_bytes_per_update", "shape_frac",
+            "shape_roof_launch_ms", "shape_roof_source", "necessary_gbs")
     value = P * sweeps * a.steps / dt
     return dict(name=name, workload=describe(a, w, 1), value=value, unit="particle-updates/s",
                 particle_parameter_updates_per_s=value * w["D"], ms_per_step=dt / a.steps * 1e3, steps=a.steps, warmup=a.warmup,
@@ -941,6 +966,8 @@ def compact_row(r):
     c.update({k: rf.get(k) for k in ROW_KEYS})
     if rf.get("counter_frac") is not None:  # (HBM-bound rows that quote the formula in `frac`: the counters' fraction beside it)
         c["counter_frac"] = rf["counter_frac"]
+    if rf.get("shape_frac") is not None:  # (cfg4: against what a bare kernel of this traffic shape reaches)
+        c["shape_frac"] = rf["shape_frac"]
     return sig(c)
 
 

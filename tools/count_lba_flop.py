@@ -15,6 +15,8 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BATCH = int(re.search(r"constexpr int kLbaBatch = (\d+);", open(os.path.join(ROOT, "differentialevolutionmcmc.jl_amd/csrc/demc_kernels.hpp")).read()).group(1))
+DEG = int(re.search(r"constexpr int kPhiDeg = (\d+);", open(os.path.join(ROOT, "differentialevolutionmcmc.jl_amd/csrc/demc_phi_table.hpp")).read()).group(1))
+READS = (DEG + 2) // 2  # sixteen-byte LDS reads per table look-up: deg + 1 coefficients, two per read
 src = '#include "%s"\n' % os.path.join(ROOT, "differentialevolutionmcmc.jl_amd/csrc/demc_kernels.hpp")
 with tempfile.TemporaryDirectory() as td:
     hip, asm = os.path.join(td, "k.hip"), os.path.join(td, "k.s")
@@ -24,7 +26,7 @@ with tempfile.TemporaryDirectory() as td:
     text = open(asm).read()
 body = re.search(r"^_ZN4demc13k_obs_loglikeENS_7KParamsEi:(.*?)s_endpgm", text, re.S | re.M).group(1)
 # the batch loop of the 3-accumulator instance: the loop (header label .. last branch back to it) whose body holds exactly
-# 3 accumulators x 2 look-ups x 5 sixteen-byte table reads per trial
+# 3 accumulators x 2 look-ups x READS sixteen-byte table reads per trial
 lines = body.splitlines()
 labels = {m.group(1): i for i, ln in enumerate(lines) if (m := re.match(r"^(\.LBB\d+_\d+):", ln))}
 loops = {}
@@ -38,7 +40,7 @@ for lab, (a, b) in loops.items():
     # trial per trip, compiled inside the batch loop) is not part of what an evaluation executes: cut nested loops out
     inner = [(x, y) for l2, (x, y) in loops.items() if l2 != lab and x > a and y <= b]
     blk = [ln for i, ln in enumerate(lines[a:b], start=a) if not any(x <= i < y for x, y in inner)]
-    if sum(x.strip().startswith("ds_read_b128") for x in blk) == 30 * BATCH and (best is None or len(blk) < len(best)):
+    if sum(x.strip().startswith("ds_read_b128") for x in blk) == 3 * 2 * READS * BATCH and (best is None or len(blk) < len(best)):
         best = blk
 assert best, "batch loop not found"
 ins = [x.split()[0] for x in best if x.startswith("\t") and not x.strip().startswith((";", "."))]
