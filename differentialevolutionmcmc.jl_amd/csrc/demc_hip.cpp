@@ -854,8 +854,8 @@ void plan_lean(demc_handle* h) {
             const int wgh = (c.Np - c.Np / 2) * 4 > 256 ? 512 : 256;
             h->lean_hist_ok = true; h->lean_wg = wgh;
             // cdf | chunk offsets | centred rows | A^-1 fragments [2][8][64]
-            // ... | held-back rows [wg][8] | current rows [wg][8] | xbar [32] (+ alignment slack): demc_resmvn.hpp, pend_l / t8_l / xb_l
-            h->lean_hist_lds = ((size_t)c.Np + 16 + (size_t)(wgh / 4) * ((size_t)c.D + 2) + 16 * 64 + 2 + (size_t)wgh * 16 + 32) * sizeof(double);
+            // ... | the first half's held-back rows [wg][8] (+ alignment slack; the snooker instance parks them): demc_resmvn.hpp, pend_l
+            h->lean_hist_lds = ((size_t)c.Np + 16 + (size_t)(wgh / 4) * ((size_t)c.D + 2) + 16 * 64 + 2 + (size_t)wgh * 8) * sizeof(double);
         }
         return;
     }
