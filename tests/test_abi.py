@@ -123,7 +123,7 @@ def test_every_kernel_fits_the_registers_of_its_workgroup(demc, tmp_path):
     dispatch dies with HSA_STATUS_ERROR_INVALID_ISA whatever the kernel would have done (tools/vgpr_budget_probe.hip: an empty
     kernel behind a 376-register descriptor, 512 threads).  hipcc wrote exactly that for k_propose<512,...,STREAM> with the
     one-statement MFMA loop -- 247 VGPRs beside the 128 AGPRs of its "+a" operands, `Occupancy: 1` -- and neither
-    __launch_bounds__(512, 2) nor the workgroup size made it spill instead.  So the library is
+    __launch_bounds__(512, 2) nor the workgroup size made it spill instead (profiles/r04/NOTES.md).  So the library is
     checked, not trusted: every kernel it ships, here, without a GPU."""
     if not os.path.exists("/opt/rocm/lib/llvm/bin/clang-offload-bundler"):
         pytest.skip("no ROCm LLVM tools")

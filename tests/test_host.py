@@ -447,3 +447,17 @@ def test_bench_rank_files_merge_into_one_short_line():
     assert abs(line["value"] / (8 * 65536 * 200 / 1.19) - 1) < 1e-4  # whole job / MAX over ranks
     assert line["config"]["ms_per_step_min_over_ranks"] == 5.6 and line["config"]["ms_per_step_max_over_ranks"] == 5.95
     assert bench.merge_rank_files(recs[:7], "x") is None  # a rank without a file: no line is made up
+
+
+def test_bench_reads_the_traffic_shape_roof_of_the_long_row_kernel():
+    """cfg4's rows are also quoted against what a bare kernel of the long-row kernel's traffic shape reaches
+    (tools/longrow_traffic_probe.hip; the committed output of its run on the box): the average of a subject-sweep and a
+    hyper-parameter-sweep launch at the whole cfg4's size, tens of microseconds -- parsed from the file, not typed into bench.py"""
+    bench = _bench_module()
+    path = os.path.join(ROOT, "profiles", bench.PROFILE_ROUND, "longrow_traffic_probe.txt")
+    if not os.path.exists(path):
+        pytest.skip("no probe output committed for this round")
+    roof = bench.longrow_shape_roof_ms()
+    assert roof is not None and 0.03 < roof < 0.2, roof
+    txt = open(path).read()
+    assert "hipMemcpy D2D" in txt and "subject sweep" in txt and "hyper sweep" in txt

@@ -11,7 +11,7 @@
 // likelihood.  Forms (all persistent, particle -> workgroup -> XCD mapping as launch_phase / k_longrow):
 //   WG 256 (two workgroups per CU) or 512 (one), theta' parked in LDS or not (not: the stores re-form theta' from re-read rows),
 //   subject-sweep shape (own + 2 partner rows in; accepted row + history row out) or hyper-sweep shape (own row in, nothing out),
-//   `work` dependent FP64 FMAs per scalar (0: pure traffic; ~126: the span loops' instruction count),
+//   `work` dependent FP64 FMAs per scalar (0: pure traffic; ~126: the span loops' instruction count, profiles/r04/NOTES.md),
 //   `ahead` blocks requested before the one being worked on (k_longrow: 1).
 // Build / run (GPU box):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/longrow_traffic_probe.hip -o /tmp/lrprobe && /tmp/lrprobe
