@@ -313,6 +313,44 @@ def test_long_row_kernel_every_sweep_kind_trace_free(demc, orc, extra):
     free_run(demc, orc, w, 5, ["k_longrow<256>"], 40, 32, theta_exact=False, **extra)
 
 
+def _de_mc_z_family_cases(n, seed=20261007):
+    """DE-MC_Z over the OTHER families and row shapes (round 5): MvNormal(mu, sigma^2 I) with sigma a parameter at random
+    dimensions (the lean iso instances: D = 31 and the general row length, odd and even rows), short hierarchical rows with and
+    without blocks, the Gaussian example -- inside burn-in (the sweep-start snapshot), leaving it, and past it."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        fam = str(rng.choice(["iso", "iso", "iso30", "hier", "gauss"]))
+        c = dict(fam=fam, d=int(rng.integers(2, 31)), Np=int(rng.integers(6, 70)), G=int(rng.integers(1, 7)), S=int(rng.integers(8, 60)),
+                 burnin=int(rng.choice([0, 4, 100])), theta_snooker=float(rng.choice([0.0, 0.1, 0.3])), beta=float(rng.choice([0.0, 0.3])),
+                 n_initial=int(rng.integers(1, 6)), blocks=bool(rng.random() < 0.5), seed=int(rng.integers(1, 2**31)))
+        out.append(pytest.param(c, id=f"{i}-{fam}-d{c['d']}-Np{c['Np']}-b{c['burnin']}-s{c['theta_snooker']:g}"))
+    return out
+
+
+def run_de_mc_z_family_case(demc, orc, c):
+    from demc_amd import workloads as W
+    c = dict(c)
+    fam, d, Np, G, S, blocks, n_init = c.pop("fam"), c.pop("d"), c.pop("Np"), c.pop("G"), c.pop("S"), c.pop("blocks"), c["n_initial"]
+    if fam in ("iso", "iso30"):
+        w = W.mvn30(N=60, d=30 if fam == "iso30" else d, G=G, Np=Np)
+        c.update(loglike_mode=1)
+    elif fam == "hier":
+        w = W.cfg4(S=S, G=G, Np=Np)
+        if not blocks:
+            w["masks"] = None
+    else:
+        w = dict(W.cfg1(), G=G, Np=Np)
+    return free_run(demc, orc, w, n_init + 10, [], G, Np, theta_exact=False, schedule=1, partner_kind=1, lp_rtol=1e-8, **c)
+
+
+@pytest.mark.parametrize("c", _de_mc_z_family_cases(10))
+def test_de_mc_z_randomised_free_runs_over_the_other_families(demc, orc, c):
+    """the generator above against the oracle: every accept decision and particle id equal, theta to 1e-10 (tests/free_run_sweep.py
+    de_mc_z_families N runs the long form)"""
+    run_de_mc_z_family_case(demc, orc, c)
+
+
 def _long_row_cases(n, seed=20261006):
     rng = np.random.default_rng(seed)
     out = []

@@ -50,12 +50,14 @@ def main(d):
             ctr.append(f"{g(rf['counter_frac'], 3)} of HBM by counter bytes")
         if rf.get("fetch_bytes_per_update") is not None:
             ctr.append(f"FETCH {g(rf['fetch_bytes_per_update'])} B/update (gather {g(rf.get('gather_bytes_per_update'))})")
-        pp = os.path.join(d, f"bench_{row}_pipe_pmc.json")
+        pp, pm = os.path.join(d, f"bench_{row}_pipe_pmc.json"), os.path.join(d, f"bench_{row}_pmc.json")
         if os.path.exists(pp):
-            best = None
-            for k, v in json.load(open(pp)).items():
-                if isinstance(v, dict) and ("SQ_WAVE_CYCLES_mean" in v) and (best is None or v["SQ_WAVE_CYCLES_mean"] > best["SQ_WAVE_CYCLES_mean"]):
-                    best = v
+            # the pipe counters of the row's DOMINANT kernel (named by the traffic passes; else the kernel with the most launches x cycles)
+            dom = (json.load(open(pm)).get("dominant") or {}).get("kernel") if os.path.exists(pm) else None
+            pipes = {k: v for k, v in json.load(open(pp)).items() if isinstance(v, dict)}
+            best = pipes.get(dom) or pipes.get("demc::" + str(dom))
+            if best is None and pipes:
+                best = max(pipes.values(), key=lambda v: v.get("SQ_WAVE_CYCLES_mean", 0.0) * v.get("launches", 1))
             if best:
                 for key, label in (("mfma_busy_frac", "MFMA busy"), ("valu_busy_frac", "VALU busy"), ("lds_busy_frac", "LDS busy")):
                     if best.get(key) is not None:
