@@ -854,8 +854,9 @@ void plan_lean(demc_handle* h) {
             const int wgh = (c.Np - c.Np / 2) * 4 > 256 ? 512 : 256;
             h->lean_hist_ok = true; h->lean_wg = wgh;
             // cdf | chunk offsets | centred rows | A^-1 fragments [2][8][64]
-            // ... | the first half's held-back rows [wg][8] (+ alignment slack; the snooker instance parks them): demc_resmvn.hpp, pend_l
-            h->lean_hist_lds = ((size_t)c.Np + 16 + (size_t)(wgh / 4) * ((size_t)c.D + 2) + 16 * 64 + 2 + (size_t)wgh * 8) * sizeof(double);
+            // ... | the first half's held-back rows [wg][8] (+ alignment slack; the snooker instance parks them) | ISO: xbar and
+            // sum_i x~_i [2][32]: demc_resmvn.hpp, pend_l / iso_l
+            h->lean_hist_lds = ((size_t)c.Np + 16 + (size_t)(wgh / 4) * ((size_t)c.D + 2) + 16 * 64 + 2 + (size_t)wgh * 8 + 64) * sizeof(double);
         }
         return;
     }
@@ -979,8 +980,8 @@ int launch_lean_hist(demc_handle* h, long long iter, bool snooker) {
     else if (h->lean_wg == 512) fn = dt == 8 ? k_res_mvn<512, false, 8, 2> : dt == 32 ? k_res_mvn<512, false, 32, 2> : k_res_mvn<512, false, 0, 2>;
     else if (!base) fn = dt == 8 ? k_res_mvn<256, false, 8, 1> : dt == 32 ? k_res_mvn<256, false, 32, 1> : k_res_mvn<256, false, 0, 1>;
     else fn = dt == 8 ? k_res_mvn<256, false, 8, 2> : dt == 32 ? k_res_mvn<256, false, 32, 2> : k_res_mvn<256, false, 0, 2>;
-    // (the HIST instances hold back the first half's stores for ONE iteration's store_row and form the cdf once per launch;
-    // the kernel itself carries no guard -- demc_resmvn.hpp says why -- so the launcher is where the precondition is checked)
+    // (the HIST instances hold back the first half's stores for ONE iteration's store_row and form the cdf once per launch: the
+    // precondition is checked here, and again by the kernel -- its phase loop runs no trip for any other count)
     if (k.n_iters != 1) return fail(h, DEMC_EINVAL, "lean DE-MC_Z kernel: one iteration per launch");
     LAUNCH_T(h, fn, dim3((unsigned)k.n_groups), dim3(h->lean_wg), h->lean_hist_lds, k);
     tick(h, 0, false);

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
     for (int e = 0; e < 8; ++e) {
         const int j = (e < 4 ? jA : jB - 4) + e;
         const int jj = j < D ? j : 0;
-        xb[e] = (!ISO || jj < d) ? p.xbar[jj] : 0.0;  // (ISO: scalar d is sigma -- xbar has d entries)
+        xb[e] = ISO ? 0.0 : p.xbar[jj];  // (ISO: from the LDS copy, iso_l)
         unsigned sg = 0;
         for (int i = 1; i < p.n_seg; ++i) sg += (jj >= p.dimseg[i].start) ? 1u : 0u;
         segs |= sg << (4 * e);
@@ -200,12 +200,13 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
         sx8[0] = p.sx ? p.sx[2 * sl] : 0.0;
         sx8[1] = p.sx ? p.sx[2 * sl + 1] : 0.0;
     }
-    double sxl[8];  // ISO: sum_i x~_i at the lane's eight scalars (zero at sigma's and past the row)
+    // ISO: xbar and sum_i x~_i are read from an LDS copy [2][32] where the quadratic form is formed (behind the held-back rows'
+    // slot): 32 registers per lane held across the proposal stage were what made these instances spill 44 - 60 registers
+    double* const iso_l = pend_l + (size_t)WG * 8;
     if constexpr (ISO) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int j = (e < 4 ? jA : jB - 4) + e;
-            sxl[e] = (p.sx && j < d) ? p.sx[j] : 0.0;
+        if (tid < 64) {
+            const int j = tid & 31;
+            iso_l[tid] = j < d ? (tid < 32 ? p.xbar[j] : (p.sx ? p.sx[j] : 0.0)) : 0.0;  // (visible after the barrier below)
         }
     }
     const int mc0 = lane & 15, mc1 = mc0 + 16;  // the two columns this lane sees of every MFMA result
@@ -601,10 +602,11 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int j = (e < 4 ? jA : jB - 4) + e;
-                const double c = v8[e] - xb[e];
+                const int jl = j < 32 ? j : 0;
+                const double c = v8[e] - iso_l[jl];
                 if (j < d) {
                     a_ = fma(c, c, a_);
-                    s_ = fma(c, sxl[e], s_);
+                    s_ = fma(c, iso_l[32 + jl], s_);
                 }
                 if (j == d) sg_ = v8[e];
             }
