@@ -54,6 +54,7 @@ def parse(argv=None):
     ap.add_argument("--burnin", type=int, default=1000, help="DE burnin (reference default 1000)")
     ap.add_argument("--snooker", type=float, default=None, help="override theta_snooker (crossover.jl:31; the reference's multivariate "
                                                                  "and hierarchical examples use 0.1): runs the snooker instances of the kernels")
+    ap.add_argument("--beta", type=float, default=None, help="override beta, the probability of a mutation sweep (main.jl:199-207; default 0.1)")
     ap.add_argument("--fuse", type=int, default=0, help="demc_config.fuse (0 auto, 1 never, 2 per phase)")
     ap.add_argument("--accuracy-iters", type=int, default=1500, help="length of the untimed accuracy leg (0: skip)")
     ap.add_argument("--async-migration", action="store_true",
@@ -261,6 +262,8 @@ def build_workload(a):
     w = W.BUILDERS[a.config](**kw)
     if a.snooker is not None:
         w["engine"] = dict(w["engine"], theta_snooker=a.snooker)
+    if getattr(a, "beta", None) is not None:
+        w["engine"] = dict(w["engine"], beta=a.beta)
     return w
 
 
@@ -501,6 +504,8 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
         LAST_PROFILE_REC.clear()
         traffic, src = measured_traffic(a, n_launch, k_iters)
         inst = "k_longrow<256>, two workgroups per CU" if P // 2 >= 512 else "k_longrow<512>"  # (launch_phase's rule, 256 CUs)
+        if P // 2 >= 512 and a.partners == "current" and not (a.snooker or w["engine"].get("theta_snooker")) and w["masks"] is not None:
+            inst += " for the subject sweep + k_frozen_sweep<256> for the hyper-parameter sweep (the row frozen: one pass over the own row)"
         ach_survey = survey_bytes / t_s / 1e9
         ach_traffic = None if traffic is None else traffic * n_launch / t_s / 1e9
         rf = dict(bound="hbm", kernel=inst + " (a workgroup per particle, one pass: proposal, prior, subject terms, accept, store)",

@@ -1,0 +1,444 @@
+// demc_frozen.hpp -- K1 for the block sweeps of a LONG row in which the row itself is frozen (round 5).
+//
+// block_update! (main.jl:169-179) sweeps the group once per block; in a hierarchical model the first block is the handful of
+// hyper-parameters (Examples/Hierarchical_Example.jl:88-92: [true, true, fill(false, n_subj), true]) and reset!
+// (crossover.jl:336-352) puts every other scalar of a crossover proposal back.  Such a sweep still costs a full evaluation --
+// every subject term depends on the hyper-parameters -- but it moves nothing: no partner rows (two or three scalars of each),
+// no theta' to park, no row to write.  k_longrow (demc_longrow.hpp) runs it with its subject-sweep machinery: 183 registers,
+// an 80 KB LDS row per workgroup, hence 8 waves per CU -- and at 8 waves the span rounds wait for latency (0.28 of the vector
+// pipe over the launch; profiles/r05/NOTES.md: 30 - 37 us per particle where its row needs 9).  This kernel is the sweep
+// reduced to what it is: ONE workgroup per particle streams the particle's own row once, one softplus (hier. Binomial) or
+// p.d residuals (hier. Gaussian) and one prior term per scalar, no LDS row, ~100 registers -- five 256-thread workgroups per
+// CU, so one particle's prologue (Philox, base pick, hyper-parameter proposals: dependent round trips) runs under the
+// arithmetic of four others.
+//
+// Same addressed draws and the same arithmetic per scalar as k_longrow / k_propose (proposals bit for bit); the sums of the prior
+// and likelihood terms run in another order (tests compare log-posteriors to 1e-9 and every decision).  Mutation sweeps
+// (mutate_or_crossover!, main.jl:199-207: the group's coin; mutation! ignores the block, main.jl:205) move the whole row:
+// v = theta + sigma z per scalar in the same pass, and an ACCEPTED mutation forms the row again to store it (no LDS copy to
+// keep it in: the second pass is paid by the accepted particles of one group in ten).
+//
+// Taken by launch_phase for: hierarchical families, rows long enough for a workgroup per particle, a block mask with at most
+// kFrozenMax scalars inside the block, the reference's default crossover or its fixed / variable gamma forms, no snooker
+// (theta_snooker = 0: as in the PLAIN instances the 2^-53 event of crossover.jl:31 is not taken), kappa = 1, partners from the
+// current population, pools of at most 256, no trace, no replay.  Everything else stays with k_longrow.
+#pragma once
+#include "demc_kernels.hpp"
+
+namespace demc {
+
+constexpr int kFrozenMax = 8;  // scalars a block may move for this kernel
+
+// MINW = waves per SIMD the register budget is cut for (3: 168 registers, no spill at two dim pairs per round; 4: 128).
+// PAIRS = dim pairs of a thread per round of the frozen loop (2: four independent softplus chains; 1: two).
+template <int WG, int MINW = 3, int PAIRS = 2>
+__global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
+    __shared__ double s_red[3][WG / 64];
+    __shared__ int s_redi[WG / 64];
+    __shared__ DimSeg s_seg[kMaxDimSeg];
+    __shared__ int s_base;
+    __shared__ double s_new[kFrozenMax + 2];   // theta' at the block's scalars | theta'[0] | the observation sd (hier. Gaussian)
+    __shared__ double s_ref[2][kMaxDimSeg];    // 1 / theta'[ref], log theta'[ref] per table segment (Normal(a, theta[ref]) priors)
+    __shared__ int s_acc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = p.D, Np = p.Np;
+    constexpr int kSegDoubles = (int)(sizeof(DimSeg) / sizeof(double));
+    for (int i = tid; i < p.n_seg * kSegDoubles; i += WG) reinterpret_cast<double*>(s_seg)[i] = reinterpret_cast<const double*>(p.dimseg)[i];
+    // particle of this workgroup; the particles of a group share an XCD
+    const int vb = blockIdx.x;
+    int g, qg;
+    if ((p.n_groups & 7) == 0) {
+        const int xcd = vb & 7, j = vb >> 3;
+        qg = j % p.n_act;
+        g = (j / p.n_act) * 8 + xcd;
+    } else {
+        g = vb / p.n_act;
+        qg = vb % p.n_act;
+    }
+    if (p.glist) g = p.glist[g];
+    const int pl = p.a_lo + qg;
+    const size_t slot = (size_t)g * Np + pl;
+    const int g_glob = p.group_offset + g;
+    const uint32_t eslot = (uint32_t)g_glob * (uint32_t)Np + (uint32_t)pl;
+    const double* grows = p.theta + (size_t)g * Np * D;
+    const double* gw = p.weight + (size_t)g * Np;
+    const double* pt = grows + (size_t)pl * D;
+    const double w_cur = gw[pl];
+    const bool maybe_base = p.proposal_kind == 0 && p.iter <= p.burnin && wave == 0;
+    double pw_r[4] = {0.0, 0.0, 0.0, 0.0};
+    if (maybe_base) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (lane + 64 * r < p.pool_n) pw_r[r] = gw[p.pool_lo + lane + 64 * r];
+    }
+    // ---- per-particle scalars (k_longrow's addressing: PART blocks 0..3 by lanes 0..3, the group's block by lane 6) ----
+    const bool glane = lane == 6;
+    const U4 mine = draw_block(p.seed, glane ? S_GROUP : S_PART, p.sweep, (uint64_t)p.iter, glane ? (uint32_t)g_glob : eslot,
+                               (uint32_t)(lane < 6 ? lane : 0));
+    auto get = [&](uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); };
+    const bool is_mut = u53(get(mine.x, 6), get(mine.y, 6)) <= p.beta;  // main.jl:199-207
+    const double u_base = u53(get(mine.z, 0), get(mine.w, 0));
+    const uint32_t ri0 = get(mine.x, 1), ri1 = get(mine.y, 1);
+    const double u_g1 = u53(get(mine.x, 2), get(mine.y, 2)), u_g2 = u53(get(mine.z, 2), get(mine.w, 2));
+    const double u_acc = u53(get(mine.x, 3), get(mine.y, 3));
+    const int kind = is_mut ? 2 : 0;  // 0 DE crossover, 2 mutation
+    int i0 = -1, i1 = -1;
+    const double *Pa = pt, *Pb2 = pt, *Pbase = pt;
+    double g1 = 0.0, g2 = 0.0;
+    bool use_base = false;
+    if (!is_mut) {
+        uint32_t a, b;
+        if (p.exclude_self) {  // setdiff(group, [Pt]) crossover.jl:158
+            pick_pair(ri0, ri1, (uint32_t)p.pool_n - 1, a, b);
+            const uint32_t t = (uint32_t)(pl - p.pool_lo);
+            a += (a >= t); b += (b >= t);
+        } else
+            pick_pair(ri0, ri1, (uint32_t)p.pool_n, a, b);
+        i0 = (int)a + p.pool_lo; i1 = (int)b + p.pool_lo;
+        Pa = grows + (size_t)i0 * D; Pb2 = grows + (size_t)i1 * D;
+        if (p.proposal_kind == 0) {
+            g1 = 0.5 + (1.0 - 0.5) * u_g1;  // crossover.jl:162
+            use_base = p.iter <= p.burnin;  // crossover.jl:164
+            if (use_base) g2 = 0.5 + (1.0 - 0.5) * u_g2;
+        } else if (p.proposal_kind == 1)
+            g1 = 2.38;  // crossover.jl:191
+        else
+            g1 = 2.38 / sqrt(2.0 * (double)D);  // crossover.jl:218
+    }
+    // ---- the few scalars every term depends on (theta'[0]; the observation sd; the scale a Normal(a, theta[ref]) prior points at):
+    // one lane each.  What their proposals read -- the lane's scalar of the own row and of the two partner rows, the noise block --
+    // is asked for NOW, before the base pick and its barrier: only the base row's scalar has to wait for those ----
+    const long long S = p.N;
+    const bool hier_b = p.family == FAM_HIER_BINOMIAL, hier_g = p.family == FAM_HIER_GAUSSIAN;
+    int need = -1;
+    if (tid == 0) need = 0;                                  // theta'[0]: the population mean of the subject effects
+    else if (tid == 1) need = hier_g ? 2 + (int)S : -1;      // the observation sd (hier. Gaussian)
+    else if (tid < 2 + p.n_seg && p.dimseg[tid - 2].t.kind == PR_NORMAL_REF) need = p.dimseg[tid - 2].t.ref;
+    double n_t = 0.0, n_a = 0.0, n_b = 0.0;
+    bool n_moves = false;
+    U4 n_nb = {0, 0, 0, 0};
+    if (need >= 0) {
+        n_t = pt[need];
+        n_moves = kind == 2 || p.mask[need] != 0;  // reset! (crossover.jl:336-352); mutation ignores the block
+        if (n_moves) {
+            n_nb = draw_block(p.seed, S_NOISE, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)(need >> 2));
+            if (kind == 0) { n_a = Pa[need]; n_b = Pb2[need]; }
+        }
+    }
+    // ---- select_base (crossover.jl:282-289): stabilised softmax, the fixed three-level order (wave_cdf); wave 0, in registers ----
+    const int n_cdf = p.pool_n;
+    if (use_base && wave == 0) {
+        double m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (lane + 64 * r < n_cdf) m = fmax(m, pw_r[r]);
+        m = wave_max(m);
+        double e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = (lane + 64 * r < n_cdf) ? exp(pw_r[r] - m) : 0.0;
+        if (n_cdf <= 64) {
+            double e1[1] = {e[0]};
+            wave_cdf<1>(e1, n_cdf);
+            e[0] = e1[0];
+        } else
+            wave_cdf<4>(e, n_cdf);
+        const int last = n_cdf - 1;
+        const double lastv = (last >> 6) == 0 ? e[0] : (last >> 6) == 1 ? e[1] : (last >> 6) == 2 ? e[2] : e[3];
+        const double total = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lastv), last & 63),
+                                              __builtin_amdgcn_readlane(__double2loint(lastv), last & 63));
+        int b;
+        if (!(total > 0.0) || !(total < INFINITY)) {
+            b = (int)(u_base * n_cdf);
+            b = b < n_cdf ? b : n_cdf - 1;
+        } else {
+            const double t = u_base * total;
+            int cnt = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cnt += __popcll(__ballot(lane + 64 * r < n_cdf && e[r] < t));
+            b = cnt < n_cdf ? cnt : n_cdf - 1;
+        }
+        if (lane == 0) s_base = b + p.pool_lo;
+    }
+    if (p.proposal_kind == 0 && p.iter <= p.burnin) {  // (wave-uniform: inside burn-in every workgroup passes here)
+        __syncthreads();  // base pick
+        if (use_base) Pbase = grows + (size_t)s_base * D;
+    }
+
+    // ---- theta' of one scalar, by whoever asks (the block's scalars, and the few every term depends on) ----
+    const double eps = p.eps, eps2 = p.eps - (-p.eps);
+    auto in_block = [&](int j) -> bool { return p.mask[j] != 0; };
+    auto theta_new = [&](int j) -> double {
+        const double tj = pt[j];
+        if (kind == 0 && !in_block(j)) return tj;  // reset! (crossover.jl:336-352)
+        const U4 nb = draw_block(p.seed, S_NOISE, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)(j >> 2));
+        if (kind == 2) {  // pt + Normal(0, sigma): mutation.jl:15-18 (pair j >> 1 of the block: words x, y or z, w)
+            const double2 z = box_muller_outofline((j & 2) ? nb.z : nb.x, (j & 2) ? nb.w : nb.y);
+            return tj + p.sigma * ((j & 1) ? z.y : z.x);
+        }
+        const uint32_t wj = (j & 2) ? ((j & 1) ? nb.w : nb.z) : ((j & 1) ? nb.y : nb.x);
+        const double bj = -eps + eps2 * u32unit(wj);  // b = Uniform(-eps, eps) crossover.jl:166
+        const double t1 = Pa[j] - Pb2[j];              // ((Pt + g1*(Pm-Pn)) + g2*(Pb-Pt)) + b  crossover.jl:168
+        double t6 = tj + t1 * g1;
+        if (use_base) {
+            const double t4 = Pbase[j] - tj;
+            t6 = t6 + t4 * g2;
+        }
+        return t6 + bj;
+    };
+    if (need >= 0) {
+        double val = n_t;
+        if (n_moves && kind == 2) {
+            const double2 z = box_muller_outofline((need & 2) ? n_nb.z : n_nb.x, (need & 2) ? n_nb.w : n_nb.y);
+            val = n_t + p.sigma * ((need & 1) ? z.y : z.x);
+        } else if (n_moves) {
+            const uint32_t wj = (need & 2) ? ((need & 1) ? n_nb.w : n_nb.z) : ((need & 1) ? n_nb.y : n_nb.x);
+            const double bj = -eps + eps2 * u32unit(wj);
+            const double t1 = n_a - n_b;
+            double t6 = n_t + t1 * g1;
+            if (use_base) {
+                const double t4 = Pbase[need] - n_t;
+                t6 = t6 + t4 * g2;
+            }
+            val = t6 + bj;
+        }
+        if (tid < 2)
+            s_new[kFrozenMax + tid] = val;
+        else {
+            s_ref[0][tid - 2] = 1.0 / val;
+            s_ref[1][tid - 2] = log(val);
+        }
+    }
+    __syncthreads();
+    const double mu0 = s_new[kFrozenMax];
+    double sg_obs = 1.0, lsg_obs = 0.0, isg_obs = 1.0;
+    if (hier_g) {
+        sg_obs = s_new[kFrozenMax + 1];
+        lsg_obs = log(sg_obs);
+        isg_obs = 1.0 / sg_obs;
+    }
+    const double n_bin = p.c0;
+    const bool prior_on = p.fitness_kind == 0;
+    // ---- the pass: scalar j by thread j mod WG (consecutive lanes, consecutive scalars: 8-byte accesses, 512 B per wave) ----
+    int oob = 0;
+    double prior = 0.0, like = 0.0;
+    auto term = [&](int j, double v) {
+        int q = 0;
+        for (int i = 1; i < p.n_seg; ++i) q += (j >= s_seg[i].start) ? 1 : 0;
+        const DimTab* tb = &s_seg[q].t;
+        oob |= !(v >= tb->lo && v <= tb->hi);  // in_bounds utilities.jl:70-78 (NaN fails)
+        if (prior_on && tb->kind != PR_FLAT) {
+            if (tb->kind == PR_NORMAL_REF) {
+                const double z = (v - tb->a) * s_ref[0][q];
+                prior += -(z * z + kLog2Pi) / 2.0 - s_ref[1][q];
+            } else if (tb->kind == PR_NORMAL) {
+                const double z = (v - tb->a) * tb->b;
+                prior += tb->c - 0.5 * (z * z);
+            } else
+                prior += prior_term_ref_outofline(tb, v, s_ref[0][q], s_ref[1][q]);
+        }
+        const long long s = (long long)j - 2;  // the subject behind the scalar
+        if (s >= 0 && s < S) {
+            if (hier_b) {  // k log p + (n-k) log(1-p), p = logistic(eta): one softplus per subject
+                const double eta = mu0 + v;
+                like += -n_bin * softplus_fast(-eta) - (n_bin - p.data[s]) * eta;
+            } else {  // Hierarchical_Example.jl:36-44: p.d observations per subject
+                const double mu = mu0 + v;
+                const int n = p.d;
+                double l = 0.0;
+                for (int o = 0; o < n; ++o) {
+                    const double z = (p.data[s * n + o] - mu) * isg_obs;
+                    l += -(z * z + kLog2Pi) / 2.0 - lsg_obs;
+                }
+                like += l;
+            }
+        }
+    };
+    auto uni = [](double x) {  // a wave-uniform value, held in SGPRs
+        return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+    };
+    // a piece of the row inside ONE table segment with a plain prior and a subject behind every scalar (all of a hierarchical
+    // row but its two ends): bounds and prior entry wave-uniform (SGPRs), the body is the subject's term and nothing else
+    struct SegC { double lo, hi, a, b, c, r_inv, r_log; int kd; };
+    auto seg_consts = [&](int q) -> SegC {
+        const DimTab tb = s_seg[q].t;
+        SegC sc;
+        sc.lo = uni(tb.lo); sc.hi = uni(tb.hi); sc.a = uni(tb.a); sc.b = uni(tb.b); sc.c = uni(tb.c);
+        sc.r_inv = s_ref[0][q]; sc.r_log = s_ref[1][q];
+        sc.kd = __builtin_amdgcn_readfirstlane(tb.kind);
+        return sc;
+    };
+    auto seg_fast = [&](const SegC& sc, int a_, int b_) -> bool {
+        return (sc.kd == PR_FLAT || sc.kd == PR_NORMAL || sc.kd == PR_NORMAL_REF) && a_ >= 2 && (long long)b_ <= S + 2 && hier_b && (D & 1) == 0;
+    };
+    auto subject = [&](const SegC& sc, double v, double kk, bool on) {  // one scalar's terms (off: a lane past the end adds nothing)
+        const int ob = !(v >= sc.lo && v <= sc.hi);
+        double pr = 0.0;
+        if (prior_on && sc.kd != PR_FLAT) {
+            if (sc.kd == PR_NORMAL_REF) {
+                const double z = (v - sc.a) * sc.r_inv;
+                pr = -(z * z + kLog2Pi) / 2.0 - sc.r_log;
+            } else {
+                const double z = (v - sc.a) * sc.b;
+                pr = sc.c - 0.5 * (z * z);
+            }
+        }
+        const double eta = mu0 + v;
+        const double lk = -n_bin * softplus_fast(-eta) - (n_bin - kk) * eta;
+        oob |= on ? ob : 0;
+        prior += on ? pr : 0.0;
+        like += on ? lk : 0.0;
+    };
+    // the runs of the block mask (run-length table in the kernarg: scalar loads, wave-uniform): scalars of runs OUTSIDE the block
+    // are taken as they are, the block's few scalars are proposed by the first threads
+    auto run_lo = [&](int r) { return p.mrun_start[r]; };
+    auto run_hi = [&](int r) { return r + 1 < p.n_mrun ? p.mrun_start[r + 1] : D; };
+    if (kind == 0) {
+        for (int r = 0; r < p.n_mrun; ++r) {
+            const int lo = run_lo(r), hi = run_hi(r);
+            if ((p.mrun_in >> r) & 1u) {  // inside the block: at most kFrozenMax scalars over all such runs
+                if (tid < hi - lo) term(lo + tid, theta_new(lo + tid));
+                continue;
+            }
+            // ... cut at the table's segment borders
+            for (int q = 0; q < p.n_seg; ++q) {
+                const int s_lo = p.seg_start[q], s_hi = q + 1 < p.n_seg ? p.seg_start[q + 1] : D;
+                const int a_ = lo > s_lo ? lo : s_lo, b_ = hi < s_hi ? hi : s_hi;
+                if (a_ >= b_) continue;
+                const SegC sc = seg_consts(q);
+                if (!seg_fast(sc, a_, b_)) {
+                    for (int j = a_ + tid; j < b_; j += WG) term(j, pt[j]);
+                    continue;
+                }
+                if (((a_ | b_) & 1) == 0) {
+                    // whole dim pairs: 16-byte loads, PAIRS pairs of a thread per round (independent softplus chains), the NEXT
+                    // round's rows and counts asked for before this round's arithmetic -- without that every round waits out a
+                    // full HBM latency (the first form of this loop: 168 us per launch where k_longrow takes 137)
+                    const int P_lo = a_ >> 1, P_hi = b_ >> 1, last = P_hi - 1;
+                    // (pair k = scalars 2k, 2k + 1; their subjects' counts sit two doubles earlier in p.data: off = -2)
+                    auto ldp = [&](const double* base, int k, int off = 0) {
+                        return *reinterpret_cast<const double2*>(base + (2 * (long long)(k < last ? k : last) + off));
+                    };
+                    int k = P_lo + tid;
+                    if constexpr (PAIRS == 2) {
+                        double2 v0 = ldp(pt, k), v1 = ldp(pt, k + WG), c0 = ldp(p.data, k, -2), c1 = ldp(p.data, k + WG, -2);
+                        for (; k < P_hi; k += 2 * WG) {
+                            const double2 nv0 = ldp(pt, k + 2 * WG), nv1 = ldp(pt, k + 3 * WG);
+                            const double2 nc0 = ldp(p.data, k + 2 * WG, -2), nc1 = ldp(p.data, k + 3 * WG, -2);
+                            const bool on1 = k + WG < P_hi;
+                            subject(sc, v0.x, c0.x, true); subject(sc, v0.y, c0.y, true);
+                            subject(sc, v1.x, c1.x, on1); subject(sc, v1.y, c1.y, on1);
+                            v0 = nv0; v1 = nv1; c0 = nc0; c1 = nc1;
+                        }
+                    } else {
+                        double2 v0 = ldp(pt, k), c0 = ldp(p.data, k, -2);
+                        for (; k < P_hi; k += WG) {
+                            const double2 nv0 = ldp(pt, k + WG), nc0 = ldp(p.data, k + WG, -2);
+                            subject(sc, v0.x, c0.x, true); subject(sc, v0.y, c0.y, true);
+                            v0 = nv0; c0 = nc0;
+                        }
+                    }
+                } else {
+                    for (int j = a_ + tid; j < b_; j += WG) subject(sc, pt[j], p.data[j - 2], true);
+                }
+            }
+        }
+    } else {
+        // mutation: every scalar moves (mutation! ignores the block).  Inside a fast segment a thread takes whole noise blocks --
+        // four scalars: one Philox block, two Box-Muller pairs, 16-byte loads -- and the segment's ragged ends (and every other
+        // segment) go scalar by scalar
+        for (int q = 0; q < p.n_seg; ++q) {
+            const int s_lo = p.seg_start[q], s_hi = q + 1 < p.n_seg ? p.seg_start[q + 1] : D;
+            const SegC sc = seg_consts(q);
+            const int m_lo = (s_lo + 3) >> 2, m_hi = s_hi >> 2;  // noise blocks wholly inside the segment
+            if (!seg_fast(sc, s_lo, s_hi) || m_lo >= m_hi) {
+                for (int j = s_lo + tid; j < s_hi; j += WG) term(j, theta_new(j));
+                continue;
+            }
+            const int n_edge = (4 * m_lo - s_lo) + (s_hi - 4 * m_hi);
+            if (tid < n_edge) {
+                const int j = tid < 4 * m_lo - s_lo ? s_lo + tid : 4 * m_hi + (tid - (4 * m_lo - s_lo));
+                term(j, theta_new(j));
+            }
+            for (int m = m_lo + tid; m < m_hi; m += WG) {
+                const double2 ta = *reinterpret_cast<const double2*>(pt + 4 * (size_t)m), tb2 = *reinterpret_cast<const double2*>(pt + 4 * (size_t)m + 2);
+                const double2 ca = *reinterpret_cast<const double2*>(p.data + 4 * (size_t)m - 2), cb = *reinterpret_cast<const double2*>(p.data + 4 * (size_t)m);
+                const U4 nb = draw_block(p.seed, S_NOISE, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)m);
+                const double2 za = box_muller_outofline(nb.x, nb.y), zb = box_muller_outofline(nb.z, nb.w);
+                subject(sc, ta.x + p.sigma * za.x, ca.x, true); subject(sc, ta.y + p.sigma * za.y, ca.y, true);
+                subject(sc, tb2.x + p.sigma * zb.x, cb.x, true); subject(sc, tb2.y + p.sigma * zb.y, cb.y, true);
+            }
+        }
+    }
+    // ---- one reduction: waves on the DPP network, then a fixed tree over the waves ----
+    prior = subgroup_sum(prior, 64); like = subgroup_sum(like, 64); oob = subgroup_sum(oob, 64);
+    if (lane == 0) {
+        s_red[0][wave] = prior; s_red[1][wave] = like;
+        s_redi[wave] = oob;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        auto tree = [&](const double* s) {
+            double r = 0.0;
+            for (int i = 0; i < WG / 64; i += 2) r += s[i] + (i + 1 < WG / 64 ? s[i + 1] : 0.0);
+            return r;
+        };
+        double pr = tree(s_red[0]), lk = tree(s_red[1]);
+        if (hier_b) lk = p.c2 + lk;  // + sum_s log C(n, k_s): data-only, summed once at demc_set_model
+        int ob = 0;
+        for (int i = 0; i < WG / 64; ++i) ob |= s_redi[i];
+        // ---- compute_posterior! + mh_update! (utilities.jl:92-99, 55-58, 201-210) ----
+        double wp;
+        if (p.fitness_kind == 1)
+            wp = ob ? (p.update_kind == 1 ? -INFINITY : INFINITY) : lk;
+        else
+            wp = ob ? -INFINITY : pr + lk;
+        const int acc = decide_mh(p.mode, p.update_kind, u_acc, wp, w_cur, 0.0);
+        if (acc) p.weight[slot] = wp;
+        if (p.store_row >= 0) {
+            const size_t hrow = (size_t)p.store_row * p.P + slot;
+            if (p.update_kind == 0 && p.mode == MODE_STEP) {  // utilities.jl:207-208
+                p.acc_hist[hrow] = (unsigned char)acc;
+                p.lp_hist[hrow] = acc ? wp : w_cur;
+            }
+            p.id_hist[hrow] = (int)p.id[slot];
+        }
+        s_acc = acc;
+    }
+    __syncthreads();
+    const int acc = s_acc;
+    // ---- the row moves: an accepted crossover writes the block's scalars, an accepted mutation the row (formed again); the
+    // history row (a sweep that is the iteration's last) is the row as it stands after the decision ----
+    double* trow = p.theta + slot * D;
+    double* hrow = (p.store_row >= 0) ? p.hist + ((size_t)p.store_row * p.P + slot) * D : nullptr;
+    if (acc && kind == 0) {
+        for (int r = 0; r < p.n_mrun; ++r) {
+            const int lo = run_lo(r), hi = run_hi(r);
+            if ((p.mrun_in >> r) & 1u) {
+                if (tid < hi - lo) {
+                    const double v = theta_new(lo + tid);
+                    trow[lo + tid] = v;  // utilities.jl:204
+                    if (hrow) hrow[lo + tid] = v;
+                }
+            } else if (hrow)
+                for (int j = lo + tid; j < hi; j += WG) hrow[j] = pt[j];
+        }
+    } else if (acc) {
+        const int n_blocks = (D + 3) >> 2;
+        for (int m = tid; m < n_blocks; m += WG) {
+            const U4 nb = draw_block(p.seed, S_NOISE, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)m);
+            const double2 za = box_muller_outofline(nb.x, nb.y), zb = box_muller_outofline(nb.z, nb.w);
+            const double zz[4] = {za.x, za.y, zb.x, zb.y};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * m + e < D) {
+                    const double v = pt[4 * m + e] + p.sigma * zz[e];
+                    trow[4 * m + e] = v;
+                    if (hrow) hrow[4 * m + e] = v;
+                }
+        }
+    } else if (hrow) {
+        for (int j = tid; j < D; j += WG) hrow[j] = pt[j];  // utilities.jl:170-180
+    }
+}
+
+}  // namespace demc

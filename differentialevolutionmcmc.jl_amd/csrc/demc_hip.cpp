@@ -27,6 +27,7 @@
 #include "demc_kernels.hpp"
 #define DEMC_LONGROW_EXTERN  // k_longrow<256 / 512> are instantiated in demc_longrow.cpp
 #include "demc_longrow.hpp"
+#include "demc_frozen.hpp"
 #include "demc_resmvn.hpp"
 
 using namespace demc;
@@ -99,6 +100,13 @@ struct demc_handle {
     // streaming-resident form (plan_stream): the MvNormal observation stream inside the resident kernel
     bool st_ok = false;
     bool tf_cheap_obs = false;  // set_tail_flags' "the likelihood is cheap enough for K1" of the last call (launch_phase reads it)
+    // k_frozen_sweep: launch order of the groups per (iteration, block sweep) of the current demc_step call -- groups whose
+    // mutation coin fires (main.jl:199-207) first: their workgroups move the whole row and take twice as long, and a slow
+    // workgroup that starts last ends the launch.  A hint only: any order gives the same results.
+    int* frozen_order_d = nullptr;
+    size_t frozen_order_cap = 0;
+    long long frozen_iter0 = 0;
+    int frozen_iters = 0;
     int st_C = 0, st_nact_max = 0, st_rows = 0, st_x_lds = 0, st_chunk_tiles = 0, st_lpp = 0, st_scr_doubles = 0, st_wg = 512;
     // the lean streaming kernel's own cut of the observation tiles (plan_lean): st_C, or twice that with two workgroups per CU
     int lean_st_C = 0, lean_st_chunk_tiles = 0, lean_st_x_lds = 0, lean_st_occ = 1;
@@ -149,7 +157,7 @@ struct demc_handle {
     bool multi_sealed = false;  // the set is built: demc_set_stream is refused from here on
     // which kernel instances the last update launched (demc_last_kernels: lets a test name the instance it compared)
     struct LastPlan {
-        int k1 = -1;  // 0 k_propose per phase, 1 k_longrow, 2 k_propose resident, 3 k_propose streaming-resident, 4 k_res_mvn
+        int k1 = -1;  // 0 k_propose per phase, 1 k_longrow, 2 k_propose resident, 3 k_propose streaming-resident, 4 k_res_mvn, 5 k_frozen_sweep
         int wg = 0, tile = 0, tail = 0, plain = 0, dt = 0, stream = 0, hist = 0, iso = 0;
         int k2 = 0;   // 0 none (fused into K1), 1 k_cross_mfma, 2 k_obs_loglike, 3 k_hier_loglike, 4 user plug-in
         int ks = 0, k3 = 0;
@@ -688,6 +696,53 @@ int launch_phase(demc_handle* h, KParams& k) {
             HIPCHK(hipMemcpyAsync(h->prop_prior, h->weight, sizeof(double) * (size_t)h->P, hipMemcpyDeviceToDevice, h->stream));
             k.base_theta = h->prop; k.base_weight = h->prop_prior;
             k.fuse_obs = h->tf_cheap_obs ? 1 : 0; k.fuse_accept = 1; k.write_prop = 0;
+        }
+    }
+    // A block sweep that FREEZES the row (the block holds a few hyper-parameters, no snooker, partners from the population): the
+    // sweep reduced to what it is -- one pass over the particle's own row, no partner rows, no LDS row, five workgroups per CU
+    // (demc_frozen.hpp) -- instead of the subject-sweep machinery of k_longrow at eight waves per CU.
+    if (lr_shape && k.fuse_obs && k.fuse_accept && k.mask && k.n_mrun > 0 && !k.base_theta && !k.trace &&
+        (h->family == FAM_HIER_BINOMIAL || h->family == FAM_HIER_GAUSSIAN) && c.theta_snooker == 0.0 && c.kappa == 1.0 &&
+        c.partner_kind == DEMC_PARTNER_CURRENT && k.pool_n <= 256) {
+        int inside = 0;
+        for (int r = 0; r < k.n_mrun; ++r)
+            if ((k.mrun_in >> r) & 1u) inside += (r + 1 < k.n_mrun ? k.mrun_start[r + 1] : c.D) - k.mrun_start[r];
+        // (enough moving particles for several workgroups per CU, counted on the geometry's groups so that a shard takes the form
+        // of the whole run: with one particle per CU the launch is that particle's dependent prologue whatever follows it --
+        // measured on cfg4's share: no form of this kernel beats k_longrow<512> there, profiles/r05/NOTES.md)
+        bool on = inside >= 1 && inside <= kFrozenMax && (long long)h->geo_groups * k.n_act >= 2LL * h->n_cus;
+        if (const char* e = experiment("DEMC_FROZEN")) on = on && e[0] == '1';  // A/B experiments
+        if (on) {
+            int wg_f = 256;
+            if (const char* e = experiment("DEMC_FROZEN_WG")) wg_f = std::atoi(e);  // A/B experiments
+            if (!k.glist && h->frozen_order_d && k.iter >= h->frozen_iter0 && k.iter < h->frozen_iter0 + h->frozen_iters &&
+                (int)k.sweep < c.n_blocks)
+                k.glist = h->frozen_order_d + ((size_t)(k.iter - h->frozen_iter0) * c.n_blocks + k.sweep) * (size_t)c.n_groups;
+            h->last = demc_handle::LastPlan();
+            h->last.k1 = 5; h->last.wg = wg_f;
+            tick(h, 0, true);
+            if (wg_f == 64)
+                LAUNCH_T(h, k_frozen_sweep<64>, dim3((unsigned)n_prop), dim3(64), 0, k);
+            else if (wg_f == 128)
+                LAUNCH_T(h, k_frozen_sweep<128>, dim3((unsigned)n_prop), dim3(128), 0, k);
+            else if (wg_f == 512)
+                LAUNCH_T(h, k_frozen_sweep<512>, dim3((unsigned)n_prop), dim3(512), 0, k);
+            else if (wg_f == 768)
+                LAUNCH_T(h, k_frozen_sweep<768>, dim3((unsigned)n_prop), dim3(768), 0, k);
+            else if (wg_f == 1024)
+                LAUNCH_T(h, (k_frozen_sweep<1024, 4>), dim3((unsigned)n_prop), dim3(1024), 0, k);
+            else if (wg_f == 2564)  // 256 threads, four waves per SIMD, two pairs per round
+                LAUNCH_T(h, (k_frozen_sweep<256, 4, 2>), dim3((unsigned)n_prop), dim3(256), 0, k);
+            else if (wg_f == 2541)  // ... one pair per round
+                LAUNCH_T(h, (k_frozen_sweep<256, 4, 1>), dim3((unsigned)n_prop), dim3(256), 0, k);
+            else if (wg_f == 2531)  // three waves per SIMD, one pair per round
+                LAUNCH_T(h, (k_frozen_sweep<256, 3, 1>), dim3((unsigned)n_prop), dim3(256), 0, k);
+            else if (wg_f == 2551)  // five waves per SIMD (96 registers), one pair per round
+                LAUNCH_T(h, (k_frozen_sweep<256, 5, 1>), dim3((unsigned)n_prop), dim3(256), 0, k);
+            else
+                LAUNCH_T(h, k_frozen_sweep<256>, dim3((unsigned)n_prop), dim3(256), 0, k);
+            tick(h, 0, false);
+            return DEMC_OK;
         }
     }
     if (lr_shape && k.fuse_obs && k.fuse_accept) {
@@ -1398,6 +1453,7 @@ int32_t demc_destroy(demc_handle* h) {
         if (h->glist_ev[i]) hipEventDestroy(h->glist_ev[i]);
     }
     if (h->st_gran) hipFree(h->st_gran);
+    if (h->frozen_order_d) hipFree(h->frozen_order_d);
     if (h->st_err) hipHostFree(h->st_err);
     if (h->side) hipStreamSynchronize(h->side);
     if (h->comm && h->own_comm) ncclCommDestroy(h->comm);
@@ -1959,9 +2015,57 @@ static int exchange_overlapped(demc_handle* h, int64_t iter, int run) {
 }
 
 // iterations [iter0, iter0 + n_iters) enqueued on the handle's stream; nothing is drained
+// launch order of the groups for the frozen-row sweeps of iterations [iter0, iter0 + n_iters): mutating groups first (the
+// group's coin is addressed Philox -- the host draws what the kernel will draw)
+static void plan_frozen_order(demc_handle* h, int64_t iter0, int32_t n_iters) {
+    const demc_config& c = h->c;
+    h->frozen_iters = 0;
+    const bool hier = h->family == FAM_HIER_BINOMIAL || h->family == FAM_HIER_GAUSSIAN;
+    if (!hier || c.n_blocks < 1 || h->lpp <= 64 || h->cur_glist || c.beta <= 0.0 || h->rp_active || n_iters < 1) return;
+    bool any = false;
+    std::vector<char> frozen((size_t)c.n_blocks, 0);
+    for (int b = 0; b < c.n_blocks && (size_t)b < h->mask_runs.size(); ++b) {
+        const auto& mr = h->mask_runs[(size_t)b];
+        int inside = 0;
+        for (int r = 0; r < mr.n; ++r)
+            if ((mr.in >> r) & 1u) inside += (r + 1 < mr.n ? mr.start[r + 1] : c.D) - mr.start[r];
+        frozen[(size_t)b] = mr.n > 0 && inside >= 1 && inside <= kFrozenMax;
+        any = any || frozen[(size_t)b];
+    }
+    const size_t need = (size_t)n_iters * c.n_blocks * c.n_groups;
+    if (!any || need > ((size_t)1 << 24)) return;
+    if (need > h->frozen_order_cap) {
+        if (h->frozen_order_d) hipFree(h->frozen_order_d);
+        h->frozen_order_d = nullptr; h->frozen_order_cap = 0;
+        if (hipMalloc((void**)&h->frozen_order_d, need * sizeof(int)) != hipSuccess) return;
+        h->frozen_order_cap = need;
+    }
+    std::vector<int> order(need);
+    for (int32_t t = 0; t < n_iters; ++t)
+        for (int b = 0; b < c.n_blocks; ++b) {
+            int* o = order.data() + ((size_t)t * c.n_blocks + b) * c.n_groups;
+            int n_front = 0;
+            std::vector<int> rest;
+            for (int g = 0; g < c.n_groups; ++g) {
+                bool mut = false;
+                if (frozen[(size_t)b]) {
+                    const U4 r = draw_block(c.seed, S_GROUP, (uint32_t)b, (uint64_t)(iter0 + t), (uint32_t)(c.group_offset + g), 0u);
+                    mut = u53(r.x, r.y) <= c.beta;
+                }
+                if (mut) o[n_front++] = g; else rest.push_back(g);
+            }
+            for (size_t i = 0; i < rest.size(); ++i) o[n_front + (int)i] = rest[i];
+        }
+    // (pageable source: the runtime stages it before the call returns, so `order` may go out of scope; the copy is ordered on
+    // the handle's stream behind every kernel that still reads the previous call's table)
+    if (hipMemcpyAsync(h->frozen_order_d, order.data(), need * sizeof(int), hipMemcpyHostToDevice, h->stream) != hipSuccess) return;
+    h->frozen_iter0 = iter0; h->frozen_iters = n_iters;
+}
+
 static int step_body(demc_handle* h, int64_t iter0, int32_t n_iters, bool with_migration) {
     const demc_config& c = h->c;
     const int n_sweeps = c.n_blocks > 0 ? c.n_blocks : 1;  // block_update! main.jl:174-179
+    plan_frozen_order(h, iter0, n_iters);
     for (int64_t iter = iter0; iter < iter0 + n_iters; ++iter) {
         if (with_migration && migration_due_h(h, iter)) {  // main.jl:85
             if (c.n_groups_total != c.n_groups || (h->comm && h->own_comm)) {  // (a communicator of one rank takes the same path)
@@ -2632,6 +2736,7 @@ int32_t demc_last_kernels(demc_handle* h, char* out, int32_t nbytes) {
             std::snprintf(buf, sizeof buf, "k_propose<%d,%s,%s,false,%s>", L.wg, tf[L.tile != 0], tails[L.tail & 3], tf[L.plain]);
             break;
         case 1: std::snprintf(buf, sizeof buf, "k_longrow<%d>", L.wg); break;
+        case 5: std::snprintf(buf, sizeof buf, "k_frozen_sweep<%d>", L.wg); break;
         case 2:
             std::snprintf(buf, sizeof buf, "k_propose<%d,true,%s,true,%s>", L.wg, tails[L.tail & 3], tf[L.plain]);
             break;

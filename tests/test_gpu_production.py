@@ -351,6 +351,31 @@ def test_de_mc_z_randomised_free_runs_over_the_other_families(demc, orc, c):
     run_de_mc_z_family_case(demc, orc, c)
 
 
+@pytest.mark.parametrize("family,S,beta,burnin", [
+    ("hier_binomial", 2100, 0.0, 100),   # inside burn-in: random_gamma's base particle (select_base over the resting colour)
+    ("hier_binomial", 2100, 0.3, 0),     # mutation sweeps: the whole row moves, an accepted one is formed again for its stores
+    ("hier_binomial", 2101, 0.1, 3),     # an odd row: the scalar-per-lane form of the frozen loop
+    ("hier_gaussian", 2100, 0.1, 100),   # three runs inside the block (mu, sd of the effects ... the observation sd at the end)
+])
+def test_frozen_row_sweep_kernel(demc, orc, family, S, beta, burnin):
+    """k_frozen_sweep (demc_frozen.hpp): a block sweep whose block holds only the hyper-parameters freezes the row -- the sweep is
+    one pass over the particle's own row, no partner rows, no LDS row.  Here the ONLY block is the hyper-parameter block of
+    Examples/Hierarchical_Example.jl:88-92, so it is also the iteration's last sweep and writes the history rows the comparison
+    reads: free-running against the oracle, every decision and id equal, theta to 1e-10 (mutation's device log), the kernel by
+    name.  40 x 32 particles: enough for the form to be taken (two workgroups' worth of particles per CU)."""
+    from conftest import make_problem
+    G, Np = 40, 32
+    prob = make_problem(family, np.random.default_rng(97), S=S)
+    m0 = np.zeros(prob["D"], np.uint8)
+    m0[:2] = 1
+    if family == "hier_gaussian":
+        m0[-1] = 1
+    rng = np.random.default_rng(98)
+    w = dict(prob, G=G, Np=Np, masks=m0[None, :], engine={}, init=lambda P, rng_: prob["init"](P))
+    ran = free_run(demc, orc, w, 6, [], G, Np, theta_exact=False, exact_kernels="k_frozen_sweep<256>", beta=beta, burnin=burnin, lp_rtol=1e-8)
+    assert ran == "k_frozen_sweep<256>"
+
+
 def _long_row_cases(n, seed=20261006):
     rng = np.random.default_rng(seed)
     out = []

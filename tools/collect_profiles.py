@@ -155,6 +155,16 @@ def main():
                 rec["bytes_per_launch"] = (2.0 * e["FETCH_SIZE_KB_mean"] + e["WRITE_SIZE_KB_mean"]) * 1024.0
                 rec["fetch_bytes_per_launch"] = 2.0 * e["FETCH_SIZE_KB_mean"] * 1024.0
             rec["launches"] = e["launches_total"]
+            also = [n for n in totals if "k_frozen_sweep" in n and n != dom]
+            if cfg == "cfg4" and also:
+                # the hyper-parameter sweep of a blocked long-row run is k_frozen_sweep, the subject sweep k_longrow: the row's
+                # traffic is both kernels' -- reduced to bytes per iteration over the whole run, like the resident rows
+                rec.pop("bytes_per_launch", None)
+                rec.pop("fetch_bytes_per_launch", None)
+                rec["bytes_per_iteration"] = (totals[dom] + sum(totals[n] for n in also)) / n_iters
+                rec["iterations"] = n_iters
+                rec["also"] = also
+                rec["launches"] = e["launches_total"] + sum(res[n]["launches_total"] for n in also)
             res["dominant"] = rec
         res["source_sha16"] = fingerprint
         res["command"] = "python3 bench.py " + " ".join(prof)
