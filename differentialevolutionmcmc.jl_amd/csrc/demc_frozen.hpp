@@ -29,6 +29,58 @@ namespace demc {
 
 constexpr int kFrozenMax = 8;  // scalars a block may move for this kernel
 
+// softplus_fast (demc_device.hpp) with its 35 polynomial and range-reduction constants handed in as wave-uniform values: the
+// same operations in the same order -- the same bits -- but the compiler keeps a uniform value in an SGPR pair and feeds it to
+// v_fma_f64 as the addend, where a literal costs a v_mov_b64 into the accumulator in front of every v_fmac (31 of ~95 vector
+// instructions per scalar in the first form of the frozen loop).
+struct SoftplusC {
+    double magic, log2e, ln2hi, ln2lo, e[12], a[16];
+};
+__device__ __forceinline__ SoftplusC softplus_consts() {
+    auto u = [](double x) {
+        return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+    };
+    SoftplusC c;
+    c.magic = u(6755399441055744.0); c.log2e = u(1.4426950408889634074);
+    c.ln2hi = u(-6.93147180369123816490e-01); c.ln2lo = u(-1.90821492927058770002e-10);
+    const double ef[12] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0,
+                           1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5};
+    const double af[16] = {1.0 / 33.0, 1.0 / 31.0, 1.0 / 29.0, 1.0 / 27.0, 1.0 / 25.0, 1.0 / 23.0, 1.0 / 21.0, 1.0 / 19.0,
+                           1.0 / 17.0, 1.0 / 15.0, 1.0 / 13.0, 1.0 / 11.0, 1.0 / 9.0, 1.0 / 7.0, 1.0 / 5.0, 1.0 / 3.0};
+#pragma unroll
+    for (int i = 0; i < 12; ++i) c.e[i] = u(ef[i]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c.a[i] = u(af[i]);
+    return c;
+}
+__device__ __forceinline__ double softplus_fast_u(double x, const SoftplusC& c) {
+    // exp_nonpos(-|x|)
+    const double a = fmax(-fabs(x), -700.0);
+    const double tn = fma(a, c.log2e, c.magic);
+    const double nf = tn - c.magic;
+    const int n = __double2loint(tn);
+    double r = fma(nf, c.ln2hi, a);
+    r = fma(nf, c.ln2lo, r);
+    double p = c.e[0];
+#pragma unroll
+    for (int i = 1; i < 12; ++i) p = fma(p, r, c.e[i]);
+    p = fma(p, r, 1.0); p = fma(p, r, 1.0);
+    const double t = p * __hiloint2double((n + 1023) << 20, 0);
+    // log1p(t) = 2 atanh(t / (2 + t))
+    const double den = 2.0 + t;
+    double q = __builtin_amdgcn_rcp(den);
+    q = fma(fma(-den, q, 1.0), q, q);
+    q = fma(fma(-den, q, 1.0), q, q);
+    double z = t * q;
+    z = fma(fma(-den, z, t), q, z);
+    const double w = z * z;
+    double s = c.a[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) s = fma(s, w, c.a[i]);
+    s = fma(s, w, 1.0);
+    return fmax(x, 0.0) + 2.0 * z * s;
+}
+
 // MINW = waves per SIMD the register budget is cut for (3: 168 registers, no spill at two dim pairs per round; 4: 128).
 // PAIRS = dim pairs of a thread per round of the frozen loop (2: four independent softplus chains; 1: two).
 template <int WG, int MINW = 3, int PAIRS = 2>
@@ -258,6 +310,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
     };
     // a piece of the row inside ONE table segment with a plain prior and a subject behind every scalar (all of a hierarchical
     // row but its two ends): bounds and prior entry wave-uniform (SGPRs), the body is the subject's term and nothing else
+    const SoftplusC spc = softplus_consts();
     struct SegC { double lo, hi, a, b, c, r_inv, r_log; int kd; };
     auto seg_consts = [&](int q) -> SegC {
         const DimTab tb = s_seg[q].t;
@@ -283,7 +336,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
             }
         }
         const double eta = mu0 + v;
-        const double lk = -n_bin * softplus_fast(-eta) - (n_bin - kk) * eta;
+        const double lk = -n_bin * softplus_fast_u(-eta, spc) - (n_bin - kk) * eta;
         oob |= on ? ob : 0;
         prior += on ? pr : 0.0;
         like += on ? lk : 0.0;
