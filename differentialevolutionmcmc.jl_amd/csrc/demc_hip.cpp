@@ -721,6 +721,7 @@ int launch_phase(demc_handle* h, KParams& k) {
             h->last = demc_handle::LastPlan();
             h->last.k1 = 5; h->last.wg = wg_f;
             tick(h, 0, true);
+#ifdef DEMC_EXPERIMENTS  // (A/B builds: other workgroup sizes, register budgets and pairs per round -- profiles/r05/NOTES.md section 8)
             if (wg_f == 64)
                 LAUNCH_T(h, k_frozen_sweep<64>, dim3((unsigned)n_prop), dim3(64), 0, k);
             else if (wg_f == 128)
@@ -740,6 +741,7 @@ int launch_phase(demc_handle* h, KParams& k) {
             else if (wg_f == 2551)  // five waves per SIMD (96 registers), one pair per round
                 LAUNCH_T(h, (k_frozen_sweep<256, 5, 1>), dim3((unsigned)n_prop), dim3(256), 0, k);
             else
+#endif
                 LAUNCH_T(h, k_frozen_sweep<256>, dim3((unsigned)n_prop), dim3(256), 0, k);
             tick(h, 0, false);
             return DEMC_OK;
