@@ -86,6 +86,7 @@ __device__ __forceinline__ double softplus_fast_u(double x, const SoftplusC& c) 
 template <int WG, int MINW = 3, int PAIRS = 2>
 __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
     __shared__ double s_red[3][WG / 64];
+    __shared__ double s_snk[3];  // snooker: <Pm, Pd>, <Pn, Pd>, <Pd, Pd> over the whole row (utilities.jl:239-246)
     __shared__ int s_redi[WG / 64];
     __shared__ DimSeg s_seg[kMaxDimSeg];
     __shared__ int s_base;
@@ -114,6 +115,10 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
     const uint32_t eslot = (uint32_t)g_glob * (uint32_t)Np + (uint32_t)pl;
     const double* grows = p.theta + (size_t)g * Np * D;
     const double* gw = p.weight + (size_t)g * Np;
+    // (the weights select_base reads and the base row: the sweep-start snapshot when the launch has one -- KParams::base_theta:
+    // DE-MC_Z inside burn-in on the synchronous schedule)
+    const double* gwb = p.base_weight ? p.base_weight + (size_t)g * Np : gw;
+    const double* grows_b = p.base_theta ? p.base_theta + (size_t)g * Np * D : grows;
     const double* pt = grows + (size_t)pl * D;
     const double w_cur = gw[pl];
     const bool maybe_base = p.proposal_kind == 0 && p.iter <= p.burnin && wave == 0;
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
     if (maybe_base) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (lane + 64 * r < p.pool_n) pw_r[r] = gw[p.pool_lo + lane + 64 * r];
+            if (lane + 64 * r < p.pool_n) pw_r[r] = gwb[p.pool_lo + lane + 64 * r];
     }
     // ---- per-particle scalars (k_longrow's addressing: PART blocks 0..3 by lanes 0..3, the group's block by lane 6) ----
     const bool glane = lane == 6;
@@ -129,26 +134,50 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
                                (uint32_t)(lane < 6 ? lane : 0));
     auto get = [&](uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); };
     const bool is_mut = u53(get(mine.x, 6), get(mine.y, 6)) <= p.beta;  // main.jl:199-207
-    const double u_base = u53(get(mine.z, 0), get(mine.w, 0));
-    const uint32_t ri0 = get(mine.x, 1), ri1 = get(mine.y, 1);
+    const double u_snk = u53(get(mine.x, 0), get(mine.y, 0)), u_base = u53(get(mine.z, 0), get(mine.w, 0));
+    const uint32_t ri0 = get(mine.x, 1), ri1 = get(mine.y, 1), ri2 = get(mine.z, 1);
     const double u_g1 = u53(get(mine.x, 2), get(mine.y, 2)), u_g2 = u53(get(mine.z, 2), get(mine.w, 2));
     const double u_acc = u53(get(mine.x, 3), get(mine.y, 3));
-    const int kind = is_mut ? 2 : 0;  // 0 DE crossover, 2 mutation
-    int i0 = -1, i1 = -1;
-    const double *Pa = pt, *Pb2 = pt, *Pbase = pt;
+    // 0 DE crossover, 1 snooker (theta_snooker > 0 only: with 0 the 2^-53 event of crossover.jl:31 is not taken, as in the PLAIN
+    // instances), 2 mutation
+    const bool snooker = !is_mut && p.theta_snooker > 0.0 && u_snk <= p.theta_snooker;
+    const int kind = is_mut ? 2 : snooker ? 1 : 0;
+    const double *Pa = pt, *Pb2 = pt, *Pc = pt, *Pbase = pt;
     double g1 = 0.0, g2 = 0.0;
     bool use_base = false;
     if (!is_mut) {
-        uint32_t a, b;
-        if (p.exclude_self) {  // setdiff(group, [Pt]) crossover.jl:158
-            pick_pair(ri0, ri1, (uint32_t)p.pool_n - 1, a, b);
-            const uint32_t t = (uint32_t)(pl - p.pool_lo);
-            a += (a >= t); b += (b >= t);
-        } else
-            pick_pair(ri0, ri1, (uint32_t)p.pool_n, a, b);
-        i0 = (int)a + p.pool_lo; i1 = (int)b + p.pool_lo;
-        Pa = grows + (size_t)i0 * D; Pb2 = grows + (size_t)i1 * D;
-        if (p.proposal_kind == 0) {
+        if (p.partner_kind == 1) {  // resample (crossover.jl:113-124): distinct cells of rows 1:(iter-1) x local particles (k_longrow's draws)
+            const uint64_t hd0 = ((uint64_t)get(mine.y, 4) << 32) | get(mine.x, 4), hd1 = ((uint64_t)get(mine.w, 4) << 32) | get(mine.z, 4),
+                           hd2 = ((uint64_t)get(mine.y, 5) << 32) | get(mine.x, 5);
+            const uint64_t ub = (uint64_t)(p.iter - 1), M = ub * (uint64_t)p.P;
+            uint64_t a = mulhi64(hd0, M), b = mulhi64(hd1, M - 1), c = 0;
+            if (b >= a) ++b;
+            if (snooker) {
+                c = mulhi64(hd2, M - 2);
+                const uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
+                if (c >= lo) ++c;
+                if (c >= hi) ++c;
+            }
+            Pa = p.hist + ((a % ub) * (uint64_t)p.P + a / ub) * (uint64_t)D;
+            Pb2 = p.hist + ((b % ub) * (uint64_t)p.P + b / ub) * (uint64_t)D;
+            Pc = p.hist + ((c % ub) * (uint64_t)p.P + c / ub) * (uint64_t)D;
+        } else if (snooker) {
+            uint32_t a, b, c;  // snooker_update! draws 3 from the whole pool (crossover.jl:241)
+            pick_triple(ri0, ri1, ri2, (uint32_t)p.pool_n, a, b, c);
+            Pa = grows + (size_t)((int)a + p.pool_lo) * D; Pb2 = grows + (size_t)((int)b + p.pool_lo) * D; Pc = grows + (size_t)((int)c + p.pool_lo) * D;
+        } else {
+            uint32_t a, b;
+            if (p.exclude_self) {  // setdiff(group, [Pt]) crossover.jl:158
+                pick_pair(ri0, ri1, (uint32_t)p.pool_n - 1, a, b);
+                const uint32_t t = (uint32_t)(pl - p.pool_lo);
+                a += (a >= t); b += (b >= t);
+            } else
+                pick_pair(ri0, ri1, (uint32_t)p.pool_n, a, b);
+            Pa = grows + (size_t)((int)a + p.pool_lo) * D; Pb2 = grows + (size_t)((int)b + p.pool_lo) * D;
+        }
+        if (snooker)
+            g1 = 1.2 + (2.2 - 1.2) * u_g1;  // crossover.jl:249
+        else if (p.proposal_kind == 0) {
             g1 = 0.5 + (1.0 - 0.5) * u_g1;  // crossover.jl:162
             use_base = p.iter <= p.burnin;  // crossover.jl:164
             if (use_base) g2 = 0.5 + (1.0 - 0.5) * u_g2;
@@ -175,6 +204,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
         if (n_moves) {
             n_nb = draw_block(p.seed, S_NOISE, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)(need >> 2));
             if (kind == 0) { n_a = Pa[need]; n_b = Pb2[need]; }
+            if (kind == 1) n_a = Pa[need];  // Pz (snooker_update!, crossover.jl:241-253)
         }
     }
     // ---- select_base (crossover.jl:282-289): stabilised softmax, the fixed three-level order (wave_cdf); wave 0, in registers ----
@@ -213,7 +243,28 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
     }
     if (p.proposal_kind == 0 && p.iter <= p.burnin) {  // (wave-uniform: inside burn-in every workgroup passes here)
         __syncthreads();  // base pick
-        if (use_base) Pbase = grows + (size_t)s_base * D;
+        if (use_base) Pbase = grows_b + (size_t)s_base * D;
+    }
+    // ---- snooker: project(Pm, Pd), project(Pn, Pd) with Pd = Pt - Pz need whole-row dot products first (utilities.jl:239-246): the
+    // one pass over the three partner rows a frozen sweep makes, by the particles whose snooker coin fired (one in ten) ----
+    double cm = 0.0, cn = 0.0, s2_snk = 0.0;
+    if (p.theta_snooker > 0.0) {  // (wave-uniform: the barriers below are passed by every workgroup of such a run)
+        double vm = 0.0, vn = 0.0, vd = 0.0;
+        if (kind == 1)
+            for (int j = tid; j < D; j += WG) {
+                const double dj = pt[j] - Pa[j];
+                vm += Pb2[j] * dj; vn += Pc[j] * dj; vd += dj * dj;
+            }
+        vm = subgroup_sum(vm, 64); vn = subgroup_sum(vn, 64); vd = subgroup_sum(vd, 64);
+        if (lane == 0) { s_red[0][wave] = vm; s_red[1][wave] = vn; s_red[2][wave] = vd; }
+        __syncthreads();
+        if (tid == 0) {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+            for (int i = 0; i < WG / 64; ++i) { a0 += s_red[0][i]; a1 += s_red[1][i]; a2 += s_red[2][i]; }
+            s_snk[0] = a0; s_snk[1] = a1; s_snk[2] = a2;
+        }
+        __syncthreads();
+        if (kind == 1) { cm = s_snk[0] / s_snk[2]; cn = s_snk[1] / s_snk[2]; s2_snk = s_snk[2]; }
     }
 
     // ---- theta' of one scalar, by whoever asks (the block's scalars, and the few every term depends on) ----
@@ -221,7 +272,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
     auto in_block = [&](int j) -> bool { return p.mask[j] != 0; };
     auto theta_new = [&](int j) -> double {
         const double tj = pt[j];
-        if (kind == 0 && !in_block(j)) return tj;  // reset! (crossover.jl:336-352)
+        if (kind != 2 && !in_block(j)) return tj;  // reset! (crossover.jl:336-352)
         const U4 nb = draw_block(p.seed, S_NOISE, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)(j >> 2));
         if (kind == 2) {  // pt + Normal(0, sigma): mutation.jl:15-18 (pair j >> 1 of the block: words x, y or z, w)
             const double2 z = box_muller_outofline((j & 2) ? nb.z : nb.x, (j & 2) ? nb.w : nb.y);
@@ -229,6 +280,11 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
         }
         const uint32_t wj = (j & 2) ? ((j & 1) ? nb.w : nb.z) : ((j & 1) ? nb.y : nb.x);
         const double bj = -eps + eps2 * u32unit(wj);  // b = Uniform(-eps, eps) crossover.jl:166
+        if (kind == 1) {  // (Pt + gamma*(Pr1 - Pr2)) + b  crossover.jl:253
+            const double dj = tj - Pa[j];
+            const double t1 = dj * cm - dj * cn;
+            return (tj + t1 * g1) + bj;
+        }
         const double t1 = Pa[j] - Pb2[j];              // ((Pt + g1*(Pm-Pn)) + g2*(Pb-Pt)) + b  crossover.jl:168
         double t6 = tj + t1 * g1;
         if (use_base) {
@@ -242,6 +298,11 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
         if (n_moves && kind == 2) {
             const double2 z = box_muller_outofline((need & 2) ? n_nb.z : n_nb.x, (need & 2) ? n_nb.w : n_nb.y);
             val = n_t + p.sigma * ((need & 1) ? z.y : z.x);
+        } else if (n_moves && kind == 1) {
+            const uint32_t wj = (need & 2) ? ((need & 1) ? n_nb.w : n_nb.z) : ((need & 1) ? n_nb.y : n_nb.x);
+            const double dj = n_t - n_a;
+            const double t1 = dj * cm - dj * cn;
+            val = (n_t + t1 * g1) + (-eps + eps2 * u32unit(wj));
         } else if (n_moves) {
             const uint32_t wj = (need & 2) ? ((need & 1) ? n_nb.w : n_nb.z) : ((need & 1) ? n_nb.y : n_nb.x);
             const double bj = -eps + eps2 * u32unit(wj);
@@ -345,11 +406,19 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
     // are taken as they are, the block's few scalars are proposed by the first threads
     auto run_lo = [&](int r) { return p.mrun_start[r]; };
     auto run_hi = [&](int r) { return r + 1 < p.n_mrun ? p.mrun_start[r + 1] : D; };
-    if (kind == 0) {
+    double ds1 = 0.0;  // snooker: |Pt' - Pz|^2 - |Pt - Pz|^2, which only the block's scalars contribute to
+    if (kind != 2) {
         for (int r = 0; r < p.n_mrun; ++r) {
             const int lo = run_lo(r), hi = run_hi(r);
             if ((p.mrun_in >> r) & 1u) {  // inside the block: at most kFrozenMax scalars over all such runs
-                if (tid < hi - lo) term(lo + tid, theta_new(lo + tid));
+                if (tid < hi - lo) {
+                    const double v = theta_new(lo + tid);
+                    term(lo + tid, v);
+                    if (kind == 1) {  // adjust_loglike norms (crossover.jl:268-273)
+                        const double z = Pa[lo + tid], a1 = v - z, a0 = pt[lo + tid] - z;
+                        ds1 += a1 * a1 - a0 * a0;
+                    }
+                }
                 continue;
             }
             // ... cut at the table's segment borders
@@ -424,8 +493,9 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
     }
     // ---- one reduction: waves on the DPP network, then a fixed tree over the waves ----
     prior = subgroup_sum(prior, 64); like = subgroup_sum(like, 64); oob = subgroup_sum(oob, 64);
+    if (p.theta_snooker > 0.0) ds1 = subgroup_sum(ds1, 64);
     if (lane == 0) {
-        s_red[0][wave] = prior; s_red[1][wave] = like;
+        s_red[0][wave] = prior; s_red[1][wave] = like; s_red[2][wave] = ds1;
         s_redi[wave] = oob;
     }
     __syncthreads();
@@ -445,7 +515,9 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
             wp = ob ? (p.update_kind == 1 ? -INFINITY : INFINITY) : lk;
         else
             wp = ob ? -INFINITY : pr + lk;
-        const int acc = decide_mh(p.mode, p.update_kind, u_acc, wp, w_cur, 0.0);
+        double adj = 0.0;  // adjust_loglike (crossover.jl:268-273): (d - 1) (log |Pt' - Pz| - log |Pt - Pz|)
+        if (kind == 1) adj = (double)(D - 1) * (0.5 * log(s2_snk + tree(s_red[2])) - 0.5 * log(s2_snk));
+        const int acc = decide_mh(p.mode, p.update_kind, u_acc, wp, w_cur, adj);
         if (acc) p.weight[slot] = wp;
         if (p.store_row >= 0) {
             const size_t hrow = (size_t)p.store_row * p.P + slot;
@@ -463,7 +535,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
     // history row (a sweep that is the iteration's last) is the row as it stands after the decision ----
     double* trow = p.theta + slot * D;
     double* hrow = (p.store_row >= 0) ? p.hist + ((size_t)p.store_row * p.P + slot) * D : nullptr;
-    if (acc && kind == 0) {
+    if (acc && kind != 2) {
         for (int r = 0; r < p.n_mrun; ++r) {
             const int lo = run_lo(r), hi = run_hi(r);
             if ((p.mrun_in >> r) & 1u) {

@@ -698,12 +698,13 @@ int launch_phase(demc_handle* h, KParams& k) {
             k.fuse_obs = h->tf_cheap_obs ? 1 : 0; k.fuse_accept = 1; k.write_prop = 0;
         }
     }
-    // A block sweep that FREEZES the row (the block holds a few hyper-parameters, no snooker, partners from the population): the
-    // sweep reduced to what it is -- one pass over the particle's own row, no partner rows, no LDS row, five workgroups per CU
-    // (demc_frozen.hpp) -- instead of the subject-sweep machinery of k_longrow at eight waves per CU.
-    if (lr_shape && k.fuse_obs && k.fuse_accept && k.mask && k.n_mrun > 0 && !k.base_theta && !k.trace &&
-        (h->family == FAM_HIER_BINOMIAL || h->family == FAM_HIER_GAUSSIAN) && c.theta_snooker == 0.0 && c.kappa == 1.0 &&
-        c.partner_kind == DEMC_PARTNER_CURRENT && k.pool_n <= 256) {
+    // A block sweep that FREEZES the row (the block holds a few hyper-parameters): the sweep reduced to what it is -- one pass
+    // over the particle's own row, partner rows read at the block's scalars only (whole only by the one particle in ten whose
+    // snooker coin fired: its projections run over the row), no LDS row, five workgroups per CU (demc_frozen.hpp) -- instead of
+    // the subject-sweep machinery of k_longrow at eight waves per CU.  Partners from the population or from the history, the
+    // base row from the sweep-start snapshot when there is one.
+    if (lr_shape && k.fuse_obs && k.fuse_accept && k.mask && k.n_mrun > 0 && !k.trace &&
+        (h->family == FAM_HIER_BINOMIAL || h->family == FAM_HIER_GAUSSIAN) && c.kappa == 1.0 && k.pool_n <= 256) {
         int inside = 0;
         for (int r = 0; r < k.n_mrun; ++r)
             if ((k.mrun_in >> r) & 1u) inside += (r + 1 < k.n_mrun ? k.mrun_start[r + 1] : c.D) - k.mrun_start[r];
@@ -712,6 +713,8 @@ int launch_phase(demc_handle* h, KParams& k) {
         // measured on cfg4's share: no form of this kernel beats k_longrow<512> there, profiles/r05/NOTES.md)
         bool on = inside >= 1 && inside <= kFrozenMax && (long long)h->geo_groups * k.n_act >= 2LL * h->n_cus;
         if (const char* e = experiment("DEMC_FROZEN")) on = on && e[0] == '1';  // A/B experiments
+        if (const char* e = experiment("DEMC_FROZEN_EXT"))  // A/B experiments: only what round 5's first form of the kernel served
+            if (e[0] == '0') on = on && !k.base_theta && c.theta_snooker == 0.0 && c.partner_kind == DEMC_PARTNER_CURRENT;
         if (on) {
             int wg_f = 256;
             if (const char* e = experiment("DEMC_FROZEN_WG")) wg_f = std::atoi(e);  // A/B experiments

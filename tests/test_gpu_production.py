@@ -351,13 +351,21 @@ def test_de_mc_z_randomised_free_runs_over_the_other_families(demc, orc, c):
     run_de_mc_z_family_case(demc, orc, c)
 
 
-@pytest.mark.parametrize("family,S,beta,burnin", [
-    ("hier_binomial", 2100, 0.0, 100),   # inside burn-in: random_gamma's base particle (select_base over the resting colour)
-    ("hier_binomial", 2100, 0.3, 0),     # mutation sweeps: the whole row moves, an accepted one is formed again for its stores
-    ("hier_binomial", 2101, 0.1, 3),     # an odd row: the scalar-per-lane form of the frozen loop
-    ("hier_gaussian", 2100, 0.1, 100),   # three runs inside the block (mu, sd of the effects ... the observation sd at the end)
+_Z = dict(schedule=1, partner_kind=1, n_initial=4)  # DE-MC_Z: partners from the history, the synchronous schedule
+
+
+@pytest.mark.parametrize("family,S,beta,burnin,extra", [
+    ("hier_binomial", 2100, 0.0, 100, {}),   # inside burn-in: random_gamma's base particle (select_base over the resting colour)
+    ("hier_binomial", 2100, 0.3, 0, {}),     # mutation sweeps: the whole row moves, an accepted one is formed again for its stores
+    ("hier_binomial", 2101, 0.1, 3, {}),     # an odd row: the scalar-per-lane form of the frozen loop
+    ("hier_gaussian", 2100, 0.1, 100, {}),   # three runs inside the block (mu, sd of the effects ... the observation sd at the end)
+    ("hier_binomial", 2100, 0.1, 0, dict(theta_snooker=0.3)),          # snooker: projections over three whole partner rows
+    ("hier_binomial", 2100, 0.1, 0, dict(_Z, theta_snooker=0.3)),      # DE-MC_Z past burn-in: partner cells of the history
+    ("hier_binomial", 2101, 0.1, 100, dict(_Z, theta_snooker=0.3)),    # ... inside it: base row and weights from the sweep-start snapshot
+    ("hier_gaussian", 2100, 0.1, 6, dict(_Z, theta_snooker=0.1)),      # ... leaving it on the way; Examples/Hierarchical_Example.jl's snooker
+    ("hier_binomial", 2100, 0.0, 100, dict(_Z)),                       # DE-MC_Z without snooker
 ])
-def test_frozen_row_sweep_kernel(demc, orc, family, S, beta, burnin):
+def test_frozen_row_sweep_kernel(demc, orc, family, S, beta, burnin, extra):
     """k_frozen_sweep (demc_frozen.hpp): a block sweep whose block holds only the hyper-parameters freezes the row -- the sweep is
     one pass over the particle's own row, no partner rows, no LDS row.  Here the ONLY block is the hyper-parameter block of
     Examples/Hierarchical_Example.jl:88-92, so it is also the iteration's last sweep and writes the history rows the comparison
@@ -372,8 +380,20 @@ def test_frozen_row_sweep_kernel(demc, orc, family, S, beta, burnin):
         m0[-1] = 1
     rng = np.random.default_rng(98)
     w = dict(prob, G=G, Np=Np, masks=m0[None, :], engine={}, init=lambda P, rng_: prob["init"](P))
-    ran = free_run(demc, orc, w, 6, [], G, Np, theta_exact=False, exact_kernels="k_frozen_sweep<256>", beta=beta, burnin=burnin, lp_rtol=1e-8)
+    ran = free_run(demc, orc, w, extra.get("n_initial", 0) + 6, [], G, Np, theta_exact=False, exact_kernels="k_frozen_sweep<256>", beta=beta,
+                   burnin=burnin, lp_rtol=1e-8, **extra)
     assert ran == "k_frozen_sweep<256>"
+
+
+@pytest.mark.parametrize("burnin", [0, 100, 6])
+def test_hierarchical_example_configuration_with_enough_particles_for_the_frozen_sweep(demc, orc, burnin):
+    """Examples/Hierarchical_Example.jl:88-114 again (DE-MC_Z, theta_snooker = 0.1, blocks [hyper ; subject]) with 40 x 16 particles:
+    the hyper-parameter sweep is k_frozen_sweep (not the iteration's last sweep: no history row to write, the row it leaves is
+    what the subject sweep reads), the subject sweep k_longrow -- two kernels alternating on one stream, against the oracle."""
+    from demc_amd import workloads as W
+    w = W.cfg4(S=2100, G=40, Np=16)
+    ran = free_run(demc, orc, w, 4 + 6, [], 40, 16, theta_exact=False, beta=0.1, burnin=burnin, theta_snooker=0.1, lp_rtol=1e-8, **_Z)
+    assert ran.startswith("k_longrow<"), ran
 
 
 def _long_row_cases(n, seed=20261006):
