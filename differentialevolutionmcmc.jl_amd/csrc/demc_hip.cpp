@@ -686,18 +686,32 @@ int launch_phase(demc_handle* h, KParams& k) {
     // The same holds for every family whose update fuses into K1 past burn-in (the general kernel's no-tile form reads its base
     // rows through the same two pointers): with the snapshot, DE-MC_Z is one launch per sweep inside burn-in as well as past it.
     const bool suff_mvn = k.fuse_prep && c.loglike_mode == DEMC_LOGLIKE_SUFFSTAT;
+    bool snapshot = false;
     if (!k.fuse_accept && k.mode == MODE_STEP && c.schedule == DEMC_SCHED_SYNCHRONOUS && c.partner_kind == DEMC_PARTNER_HISTORY &&
         c.proposal_kind == 0 && k.iter <= c.burnin && (h->tf_cheap_obs || suff_mvn) && c.fuse == 0 && !k.trace && !h->rp_active &&
         k.theta == h->theta) {
         bool on = true;
         if (const char* e = experiment("DEMC_LR_SNAPSHOT")) on = e[0] == '1';  // A/B experiments
-        if (on) {
-            HIPCHK(hipMemcpyAsync(h->prop, h->theta, sizeof(double) * (size_t)h->P * c.D, hipMemcpyDeviceToDevice, h->stream));
-            HIPCHK(hipMemcpyAsync(h->prop_prior, h->weight, sizeof(double) * (size_t)h->P, hipMemcpyDeviceToDevice, h->stream));
+        if (on) {  // (the copies follow the choice of the kernel: a frozen sweep reads its base row at the block's scalars only)
+            snapshot = true;
             k.base_theta = h->prop; k.base_weight = h->prop_prior;
             k.fuse_obs = h->tf_cheap_obs ? 1 : 0; k.fuse_accept = 1; k.write_prop = 0;
         }
     }
+    auto take_snapshot = [&](bool block_only) -> int {
+        HIPCHK(hipMemcpyAsync(h->prop_prior, h->weight, sizeof(double) * (size_t)h->P, hipMemcpyDeviceToDevice, h->stream));
+        if (!block_only) {
+            HIPCHK(hipMemcpyAsync(h->prop, h->theta, sizeof(double) * (size_t)h->P * c.D, hipMemcpyDeviceToDevice, h->stream));
+            return DEMC_OK;
+        }
+        for (int r = 0; r < k.n_mrun; ++r)  // the columns of the block: a strided copy per run of the mask (a few doubles per row)
+            if ((k.mrun_in >> r) & 1u) {
+                const int lo = k.mrun_start[r], hi = r + 1 < k.n_mrun ? k.mrun_start[r + 1] : c.D;
+                HIPCHK(hipMemcpy2DAsync(h->prop + lo, sizeof(double) * (size_t)c.D, h->theta + lo, sizeof(double) * (size_t)c.D,
+                                        sizeof(double) * (size_t)(hi - lo), (size_t)h->P, hipMemcpyDeviceToDevice, h->stream));
+            }
+        return DEMC_OK;
+    };
     // A block sweep that FREEZES the row (the block holds a few hyper-parameters): the sweep reduced to what it is -- one pass
     // over the particle's own row, partner rows read at the block's scalars only (whole only by the one particle in ten whose
     // snooker coin fired: its projections run over the row), no LDS row, five workgroups per CU (demc_frozen.hpp) -- instead of
@@ -716,6 +730,11 @@ int launch_phase(demc_handle* h, KParams& k) {
         if (const char* e = experiment("DEMC_FROZEN_EXT"))  // A/B experiments: only what round 5's first form of the kernel served
             if (e[0] == '0') on = on && !k.base_theta && c.theta_snooker == 0.0 && c.partner_kind == DEMC_PARTNER_CURRENT;
         if (on) {
+            if (snapshot) {
+                bool cols = true;
+                if (const char* e = experiment("DEMC_FROZEN_SNAP_COLS")) cols = e[0] == '1';  // A/B experiments
+                if (int rc = take_snapshot(cols)) return rc;
+            }
             int wg_f = 256;
             if (const char* e = experiment("DEMC_FROZEN_WG")) wg_f = std::atoi(e);  // A/B experiments
             if (!k.glist && h->frozen_order_d && k.iter >= h->frozen_iter0 && k.iter < h->frozen_iter0 + h->frozen_iters &&
@@ -750,6 +769,8 @@ int launch_phase(demc_handle* h, KParams& k) {
             return DEMC_OK;
         }
     }
+    if (snapshot)
+        if (int rc = take_snapshot(false)) return rc;
     if (lr_shape && k.fuse_obs && k.fuse_accept) {
         {
             if (const char* e = experiment("DEMC_LR_EXIT")) k.n_split = -std::atoi(e);  // A/B experiments
