@@ -16,6 +16,7 @@
 
 #include "demc_logphi_table.hpp"
 #include "demc_phi_table.hpp"
+#include "demc_softplus_table.hpp"
 
 namespace demc {
 
@@ -141,6 +142,65 @@ __device__ inline double softplus_fast(double x) {
     s = fma(s, w, 1.0 / 15.0); s = fma(s, w, 1.0 / 13.0); s = fma(s, w, 1.0 / 11.0); s = fma(s, w, 1.0 / 9.0);
     s = fma(s, w, 1.0 / 7.0); s = fma(s, w, 1.0 / 5.0); s = fma(s, w, 1.0 / 3.0); s = fma(s, w, 1.0);
     return fmax(x, 0.0) + 2.0 * z * s;
+}
+
+// softplus from two small LDS tables (tools/gen_softplus_table.py: 2 576 bytes, copied in by load_softplus_table): about a third of
+// the instructions of softplus_fast -- a hierarchical Binomial sweep is bound by the vector pipe's issue rate and spends most of its
+// instructions here (profiles/r05/NOTES.md: the frozen loop ran 106 instructions a scalar, 66 of them FP64).
+//   exp(a), a = -|x|:  a = k ln2/64 + r (k by adding 1.5 * 2^52: no quarter-rate conversion), e^r by its degree-5 polynomial
+//                      (|r| <= ln2/128: truncation 3e-17), times E[k & 63] = 2^((k & 63)/64), times 2^(k >> 6) built in the exponent field
+//   log1p(t):          j = round(128 t), f = (t - j/128) / c_j with c_j = 1 + j/128 (the difference is exact, 1/c_j from the table),
+//                      log1p(t) = log c_j + f Q6(f), |f| <= 2^-8 (truncation f^7/8: 2e-18 relative to f)
+// Relative error < 6e-16 (the generator checks a dense grid against 50-digit arithmetic); not bit-identical to softplus_fast.
+__device__ __forceinline__ void load_softplus_table(double* s_tab, int tid, int n_threads) {
+    for (int i = tid; i < kSpDoubles; i += n_threads) s_tab[i] = kSpTable[i];
+}
+// (the constants as wave-uniform values: the compiler keeps them in SGPR pairs and feeds v_fma_f64 directly, where a literal costs a
+// v_mov_b64 into the accumulator in front of every v_fmac)
+struct SoftplusTab {
+    const double* tab;
+    double magic, magic7, c, ln2hi, ln2lo, e5, e4, e3, q7, q6, q5, q4, q3, floor_;
+};
+__device__ __forceinline__ SoftplusTab softplus_tab_consts(const double* s_tab) {
+    auto u = [](double x) {
+        asm volatile("" : "+s"(x));
+        return x;
+    };
+    // (an FMA takes ONE scalar operand: where a step has two constants the multiplicand lives in a vector register pair and the
+    // addend in a scalar one -- left alone the compiler parks the ADDEND in vector registers and copies it in front of a v_fmac)
+    auto v = [](double x) {
+        asm volatile("" : "+v"(x));
+        return x;
+    };
+    SoftplusTab c;
+    c.tab = s_tab;
+    c.magic = u(6755399441055744.0);   // 1.5 * 2^52: the sum's last place is 1
+    c.magic7 = u(52776558133248.0);    // 1.5 * 2^45: the sum's last place is 2^-7
+    c.c = v(kSpC); c.ln2hi = u(-kSpLn2Hi); c.ln2lo = u(-kSpLn2Lo);
+    c.e5 = v(1.0 / 120.0); c.e4 = u(1.0 / 24.0); c.e3 = u(1.0 / 6.0);
+    c.q7 = v(1.0 / 7.0); c.q6 = u(-1.0 / 6.0); c.q5 = u(1.0 / 5.0); c.q4 = u(-1.0 / 4.0); c.q3 = u(1.0 / 3.0);
+    c.floor_ = u(-700.0);
+    return c;
+}
+__device__ __forceinline__ double softplus_tab(double x, const SoftplusTab& c) {
+    const double a = fmax(-fabs(x), c.floor_);
+    const double tk = fma(a, c.c, c.magic);
+    const double kf = tk - c.magic;
+    const int k = __double2loint(tk);  // low word of the sum = k (two's complement, -64 700 <= k <= 0)
+    double r = fma(kf, c.ln2hi, a);
+    r = fma(kf, c.ln2lo, r);
+    double pe = fma(c.e5, r, c.e4);
+    pe = fma(pe, r, c.e3); pe = fma(pe, r, 0.5); pe = fma(pe, r, 1.0); pe = fma(pe, r, 1.0);
+    const double tp = c.tab[k & (kSpExpN - 1)] * pe;  // in [0.99, 2): times 2^(k >> 6), k >> 6 >= -1011, by an add in the exponent field
+    const double t = __hiloint2double(__double2hiint(tp) + ((k << 14) & (int)0xfff00000), __double2loint(tp));
+    const double tj = t + c.magic7;
+    const double jd = tj - c.magic7;   // round(128 t) / 128
+    const int j = __double2loint(tj);  // round(128 t): 0 .. 128
+    const double2 row = *reinterpret_cast<const double2*>(c.tab + kSpExpN + 2 * j);  // (log c_j, 1 / c_j)
+    const double f = (t - jd) * row.y;
+    double q = fma(c.q7, f, c.q6);
+    q = fma(q, f, c.q5); q = fma(q, f, c.q4); q = fma(q, f, c.q3); q = fma(q, f, -0.5); q = fma(q, f, 1.0);
+    return fmax(x, 0.0) + fma(f, q, row.x);
 }
 
 enum Prior : int {

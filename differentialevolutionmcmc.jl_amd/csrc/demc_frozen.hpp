@@ -83,7 +83,13 @@ __device__ __forceinline__ double softplus_fast_u(double x, const SoftplusC& c) 
 
 // MINW = waves per SIMD the register budget is cut for (3: 168 registers, no spill at two dim pairs per round; 4: 128).
 // PAIRS = dim pairs of a thread per round of the frozen loop (2: four independent softplus chains; 1: two).
-template <int WG, int MINW = 3, int PAIRS = 2>
+// BIG = the block may hold long runs (the subject block of Examples/Hierarchical_Example.jl:88-92: every scalar but two moves):
+// their proposals are formed on the fly, a noise block per thread and round.  (An instance of its own: the rows in flight take
+// registers the frozen loop does not need.)
+#ifndef DEMC_SOFTPLUS_TAB
+#define DEMC_SOFTPLUS_TAB 1  // (0: the table-free softplus_fast_u, for A/B builds -- make EXTRA=-DDEMC_SOFTPLUS_TAB=0)
+#endif
+template <int WG, int MINW = 3, int PAIRS = 2, bool BIG = false>
 __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
     __shared__ double s_red[3][WG / 64];
     __shared__ double s_snk[3];  // snooker: <Pm, Pd>, <Pn, Pd>, <Pd, Pd> over the whole row (utilities.jl:239-246)
@@ -93,10 +99,24 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
     __shared__ double s_new[kFrozenMax + 2];   // theta' at the block's scalars | theta'[0] | the observation sd (hier. Gaussian)
     __shared__ double s_ref[2][kMaxDimSeg];    // 1 / theta'[ref], log theta'[ref] per table segment (Normal(a, theta[ref]) priors)
     __shared__ int s_acc;
+    __shared__ __attribute__((aligned(16))) double s_sp[kSpDoubles];  // softplus_tab's tables
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D = p.D, Np = p.Np;
+#ifdef DEMC_STAMPS  // (diagnostic build, tools/frozen_stamps.py: shader cycles of wave 0 at the kernel's stages, 8 slots a workgroup in the
+                    // trace's weight array; start and end of every workgroup on the 100 MHz clock in its adjustment array)
+    const unsigned long long t0s = __builtin_amdgcn_s_memtime();
+    auto stamp = [&](int i) {
+        if (tid == 0 && ((long long)blockIdx.x + 1) * 8 <= p.P) p.tr_w[blockIdx.x * 8 + i] = (double)(__builtin_amdgcn_s_memtime() - t0s);
+    };
+    if (tid == 0 && 2 * ((long long)blockIdx.x + 1) <= p.P) p.prop_adj[2 * blockIdx.x] = (double)__builtin_amdgcn_s_memrealtime();
+#else
+    auto stamp = [](int) {};
+#endif
     constexpr int kSegDoubles = (int)(sizeof(DimSeg) / sizeof(double));
     for (int i = tid; i < p.n_seg * kSegDoubles; i += WG) reinterpret_cast<double*>(s_seg)[i] = reinterpret_cast<const double*>(p.dimseg)[i];
+#if DEMC_SOFTPLUS_TAB
+    load_softplus_table(s_sp, tid, WG);  // (visible behind the barrier every workgroup passes before its pass)
+#endif
     // particle of this workgroup; the particles of a group share an XCD
     const int vb = blockIdx.x;
     int g, qg;
@@ -186,6 +206,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
         else
             g1 = 2.38 / sqrt(2.0 * (double)D);  // crossover.jl:218
     }
+    stamp(0);  // per-particle scalars drawn, partner rows known
     // ---- the few scalars every term depends on (theta'[0]; the observation sd; the scale a Normal(a, theta[ref]) prior points at):
     // one lane each.  What their proposals read -- the lane's scalar of the own row and of the two partner rows, the noise block --
     // is asked for NOW, before the base pick and its barrier: only the base row's scalar has to wait for those ----
@@ -245,6 +266,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
         __syncthreads();  // base pick
         if (use_base) Pbase = grows_b + (size_t)s_base * D;
     }
+    stamp(1);  // base picked
     // ---- snooker: project(Pm, Pd), project(Pn, Pd) with Pd = Pt - Pz need whole-row dot products first (utilities.jl:239-246): the
     // one pass over the three partner rows a frozen sweep makes, by the particles whose snooker coin fired (one in ten) ----
     double cm = 0.0, cn = 0.0, s2_snk = 0.0;
@@ -267,6 +289,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
         if (kind == 1) { cm = s_snk[0] / s_snk[2]; cn = s_snk[1] / s_snk[2]; s2_snk = s_snk[2]; }
     }
 
+    stamp(2);  // snooker projections
     // ---- theta' of one scalar, by whoever asks (the block's scalars, and the few every term depends on) ----
     const double eps = p.eps, eps2 = p.eps - (-p.eps);
     auto in_block = [&](int j) -> bool { return p.mask[j] != 0; };
@@ -322,6 +345,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
         }
     }
     __syncthreads();
+    stamp(3);  // theta'[0] and the reference scalars known to every wave
     const double mu0 = s_new[kFrozenMax];
     double sg_obs = 1.0, lsg_obs = 0.0, isg_obs = 1.0;
     if (hier_g) {
@@ -331,6 +355,13 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
     }
     const double n_bin = p.c0;
     const bool prior_on = p.fitness_kind == 0;
+#if DEMC_SOFTPLUS_TAB
+    const SoftplusTab spt = softplus_tab_consts(s_sp);
+    auto sp_of = [&](double x) { return softplus_tab(x, spt); };
+#else
+    const SoftplusC spc = softplus_consts();
+    auto sp_of = [&](double x) { return softplus_fast_u(x, spc); };
+#endif
     // ---- the pass: scalar j by thread j mod WG (consecutive lanes, consecutive scalars: 8-byte accesses, 512 B per wave) ----
     int oob = 0;
     double prior = 0.0, like = 0.0;
@@ -353,7 +384,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
         if (s >= 0 && s < S) {
             if (hier_b) {  // k log p + (n-k) log(1-p), p = logistic(eta): one softplus per subject
                 const double eta = mu0 + v;
-                like += -n_bin * softplus_fast(-eta) - (n_bin - p.data[s]) * eta;
+                like += -n_bin * sp_of(-eta) - (n_bin - p.data[s]) * eta;
             } else {  // Hierarchical_Example.jl:36-44: p.d observations per subject
                 const double mu = mu0 + v;
                 const int n = p.d;
@@ -371,7 +402,6 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
     };
     // a piece of the row inside ONE table segment with a plain prior and a subject behind every scalar (all of a hierarchical
     // row but its two ends): bounds and prior entry wave-uniform (SGPRs), the body is the subject's term and nothing else
-    const SoftplusC spc = softplus_consts();
     struct SegC { double lo, hi, a, b, c, r_inv, r_log; int kd; };
     auto seg_consts = [&](int q) -> SegC {
         const DimTab tb = s_seg[q].t;
@@ -397,7 +427,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
             }
         }
         const double eta = mu0 + v;
-        const double lk = -n_bin * softplus_fast_u(-eta, spc) - (n_bin - kk) * eta;
+        const double lk = -n_bin * sp_of(-eta) - (n_bin - kk) * eta;
         oob |= on ? ob : 0;
         prior += on ? pr : 0.0;
         like += on ? lk : 0.0;
@@ -410,13 +440,76 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
     if (kind != 2) {
         for (int r = 0; r < p.n_mrun; ++r) {
             const int lo = run_lo(r), hi = run_hi(r);
-            if ((p.mrun_in >> r) & 1u) {  // inside the block: at most kFrozenMax scalars over all such runs
-                if (tid < hi - lo) {
-                    const double v = theta_new(lo + tid);
-                    term(lo + tid, v);
+            if ((p.mrun_in >> r) & 1u) {  // inside the block
+                auto moved = [&](int j) {
+                    const double v = theta_new(j);
+                    term(j, v);
                     if (kind == 1) {  // adjust_loglike norms (crossover.jl:268-273)
-                        const double z = Pa[lo + tid], a1 = v - z, a0 = pt[lo + tid] - z;
+                        const double z = Pa[j], a1 = v - z, a0 = pt[j] - z;
                         ds1 += a1 * a1 - a0 * a0;
+                    }
+                };
+                if (!BIG || hi - lo <= WG) {  // a few hyper-parameters: one scalar per thread (the host sends longer runs to BIG)
+                    if (tid < hi - lo) moved(lo + tid);
+                    continue;
+                }
+                if constexpr (BIG)
+                // a long run (the subject block): the proposal of every scalar formed on the fly from the own row and the partner
+                // rows -- no LDS row; an accepted particle forms it again for its stores -- a noise block (four scalars) per thread
+                // and round, the next round's rows asked for before this round's arithmetic
+                for (int q = 0; q < p.n_seg; ++q) {
+                    const int s_lo = p.seg_start[q], s_hi = q + 1 < p.n_seg ? p.seg_start[q + 1] : D;
+                    const int a_ = lo > s_lo ? lo : s_lo, b_ = hi < s_hi ? hi : s_hi;
+                    if (a_ >= b_) continue;
+                    const SegC sc = seg_consts(q);
+                    const int m_lo = (a_ + 3) >> 2, m_hi = b_ >> 2;  // noise blocks wholly inside the piece
+                    if (!seg_fast(sc, a_, b_) || m_lo >= m_hi) {
+                        for (int j = a_ + tid; j < b_; j += WG) moved(j);
+                        continue;
+                    }
+                    const int n_edge = (4 * m_lo - a_) + (b_ - 4 * m_hi);
+                    if (tid < n_edge) moved(tid < 4 * m_lo - a_ ? a_ + tid : 4 * m_hi + (tid - (4 * m_lo - a_)));
+                    const int m_last = m_hi - 1;
+                    auto ld = [&](const double* base, int m, int off) {
+                        return *reinterpret_cast<const double2*>(base + (4 * (long long)(m < m_last ? m : m_last) + off));
+                    };
+                    const bool two = kind == 0;  // (wave-uniform: the second partner row; the base row inside burn-in)
+                    const double2 zero2 = make_double2(0.0, 0.0);
+                    int m = m_lo + tid;
+                    double2 t0 = ld(pt, m, 0), t1 = ld(pt, m, 2), a0 = ld(Pa, m, 0), a1 = ld(Pa, m, 2);
+                    double2 b0 = two ? ld(Pb2, m, 0) : zero2, b1 = two ? ld(Pb2, m, 2) : zero2;
+                    double2 e0 = use_base ? ld(Pbase, m, 0) : zero2, e1 = use_base ? ld(Pbase, m, 2) : zero2;
+                    double2 c0 = ld(p.data, m, -2), c1 = ld(p.data, m, 0);
+                    for (; m < m_hi; m += WG) {
+                        const int mn = m + WG;
+                        const double2 nt0 = ld(pt, mn, 0), nt1 = ld(pt, mn, 2), na0 = ld(Pa, mn, 0), na1 = ld(Pa, mn, 2);
+                        const double2 nb0 = two ? ld(Pb2, mn, 0) : zero2, nb1 = two ? ld(Pb2, mn, 2) : zero2;
+                        const double2 ne0 = use_base ? ld(Pbase, mn, 0) : zero2, ne1 = use_base ? ld(Pbase, mn, 2) : zero2;
+                        const double2 nc0 = ld(p.data, mn, -2), nc1 = ld(p.data, mn, 0);
+                        const U4 nb = draw_block(p.seed, S_NOISE, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)m);
+                        auto one = [&](double tj, double aj, double bj2, double ej, uint32_t wj, double kk) {
+                            const double bj = -eps + eps2 * u32unit(wj);
+                            double v;
+                            if (kind == 1) {
+                                const double dj = tj - aj;
+                                const double t1_ = dj * cm - dj * cn;
+                                v = (tj + t1_ * g1) + bj;
+                                const double a1_ = v - aj;
+                                ds1 += a1_ * a1_ - dj * dj;
+                            } else {
+                                const double t1_ = aj - bj2;
+                                double t6 = tj + t1_ * g1;
+                                if (use_base) {
+                                    const double t4 = ej - tj;
+                                    t6 = t6 + t4 * g2;
+                                }
+                                v = t6 + bj;
+                            }
+                            subject(sc, v, kk, true);
+                        };
+                        one(t0.x, a0.x, b0.x, e0.x, nb.x, c0.x); one(t0.y, a0.y, b0.y, e0.y, nb.y, c0.y);
+                        one(t1.x, a1.x, b1.x, e1.x, nb.z, c1.x); one(t1.y, a1.y, b1.y, e1.y, nb.w, c1.y);
+                        t0 = nt0; t1 = nt1; a0 = na0; a1 = na1; b0 = nb0; b1 = nb1; e0 = ne0; e1 = ne1; c0 = nc0; c1 = nc1;
                     }
                 }
                 continue;
@@ -491,6 +584,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
             }
         }
     }
+    stamp(4);  // the pass (wave 0's share)
     // ---- one reduction: waves on the DPP network, then a fixed tree over the waves ----
     prior = subgroup_sum(prior, 64); like = subgroup_sum(like, 64); oob = subgroup_sum(oob, 64);
     if (p.theta_snooker > 0.0) ds1 = subgroup_sum(ds1, 64);
@@ -531,6 +625,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
     }
     __syncthreads();
     const int acc = s_acc;
+    stamp(5);  // reduced, decided (the slowest wave in)
     // ---- the row moves: an accepted crossover writes the block's scalars, an accepted mutation the row (formed again); the
     // history row (a sweep that is the iteration's last) is the row as it stands after the decision ----
     double* trow = p.theta + slot * D;
@@ -539,10 +634,51 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
         for (int r = 0; r < p.n_mrun; ++r) {
             const int lo = run_lo(r), hi = run_hi(r);
             if ((p.mrun_in >> r) & 1u) {
-                if (tid < hi - lo) {
-                    const double v = theta_new(lo + tid);
-                    trow[lo + tid] = v;  // utilities.jl:204
-                    if (hrow) hrow[lo + tid] = v;
+                auto put = [&](int j) {
+                    const double v = theta_new(j);
+                    trow[j] = v;  // utilities.jl:204
+                    if (hrow) hrow[j] = v;
+                };
+                if (!BIG || hi - lo <= WG) {
+                    if (tid < hi - lo) put(lo + tid);
+                    continue;
+                }
+                if constexpr (BIG) {
+                const int m_lo = (lo + 3) >> 2, m_hi = hi >> 2;
+                if ((D & 1) != 0 || m_lo >= m_hi) {
+                    for (int j = lo + tid; j < hi; j += WG) put(j);
+                    continue;
+                }
+                const int n_edge = (4 * m_lo - lo) + (hi - 4 * m_hi);
+                if (tid < n_edge) put(tid < 4 * m_lo - lo ? lo + tid : 4 * m_hi + (tid - (4 * m_lo - lo)));
+                auto ld = [&](const double* base, int m, int off) { return *reinterpret_cast<const double2*>(base + (4 * (long long)m + off)); };
+                const bool two = kind == 0;
+                const double2 zero2 = make_double2(0.0, 0.0);
+                for (int m = m_lo + tid; m < m_hi; m += WG) {
+                    const double2 t0 = ld(pt, m, 0), t1 = ld(pt, m, 2), a0 = ld(Pa, m, 0), a1 = ld(Pa, m, 2);
+                    const double2 b0 = two ? ld(Pb2, m, 0) : zero2, b1 = two ? ld(Pb2, m, 2) : zero2;
+                    const double2 e0 = use_base ? ld(Pbase, m, 0) : zero2, e1 = use_base ? ld(Pbase, m, 2) : zero2;
+                    const U4 nb = draw_block(p.seed, S_NOISE, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)m);
+                    auto one = [&](double tj, double aj, double bj2, double ej, uint32_t wj) -> double {
+                        const double bj = -eps + eps2 * u32unit(wj);
+                        if (kind == 1) {
+                            const double dj = tj - aj;
+                            const double t1_ = dj * cm - dj * cn;
+                            return (tj + t1_ * g1) + bj;
+                        }
+                        const double t1_ = aj - bj2;
+                        double t6 = tj + t1_ * g1;
+                        if (use_base) {
+                            const double t4 = ej - tj;
+                            t6 = t6 + t4 * g2;
+                        }
+                        return t6 + bj;
+                    };
+                    const double2 v0 = make_double2(one(t0.x, a0.x, b0.x, e0.x, nb.x), one(t0.y, a0.y, b0.y, e0.y, nb.y));
+                    const double2 v1 = make_double2(one(t1.x, a1.x, b1.x, e1.x, nb.z), one(t1.y, a1.y, b1.y, e1.y, nb.w));
+                    *reinterpret_cast<double2*>(trow + 4 * (size_t)m) = v0; *reinterpret_cast<double2*>(trow + 4 * (size_t)m + 2) = v1;
+                    if (hrow) { *reinterpret_cast<double2*>(hrow + 4 * (size_t)m) = v0; *reinterpret_cast<double2*>(hrow + 4 * (size_t)m + 2) = v1; }
+                }
                 }
             } else if (hrow)
                 for (int j = lo + tid; j < hi; j += WG) hrow[j] = pt[j];
@@ -564,6 +700,11 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
     } else if (hrow) {
         for (int j = tid; j < D; j += WG) hrow[j] = pt[j];  // utilities.jl:170-180
     }
+    stamp(6);
+#ifdef DEMC_STAMPS
+    if (tid == 0 && 2 * ((long long)blockIdx.x + 1) <= p.P)
+        p.prop_adj[2 * blockIdx.x + 1] = (double)__builtin_amdgcn_s_memrealtime() + 0.25 * kind + 0.125 * acc;
+#endif
 }
 
 }  // namespace demc

@@ -158,7 +158,7 @@ struct demc_handle {
     // which kernel instances the last update launched (demc_last_kernels: lets a test name the instance it compared)
     struct LastPlan {
         int k1 = -1;  // 0 k_propose per phase, 1 k_longrow, 2 k_propose resident, 3 k_propose streaming-resident, 4 k_res_mvn, 5 k_frozen_sweep
-        int wg = 0, tile = 0, tail = 0, plain = 0, dt = 0, stream = 0, hist = 0, iso = 0;
+        int wg = 0, tile = 0, tail = 0, plain = 0, dt = 0, stream = 0, hist = 0, iso = 0, big = 0;
         int k2 = 0;   // 0 none (fused into K1), 1 k_cross_mfma, 2 k_obs_loglike, 3 k_hier_loglike, 4 user plug-in
         int ks = 0, k3 = 0;
     } last;
@@ -725,7 +725,18 @@ int launch_phase(demc_handle* h, KParams& k) {
         // (enough moving particles for several workgroups per CU, counted on the geometry's groups so that a shard takes the form
         // of the whole run: with one particle per CU the launch is that particle's dependent prologue whatever follows it --
         // measured on cfg4's share: no form of this kernel beats k_longrow<512> there, profiles/r05/NOTES.md)
-        bool on = inside >= 1 && inside <= kFrozenMax && (long long)h->geo_groups * k.n_act >= 2LL * h->n_cus;
+        int longest = 0;
+        for (int r = 0; r < k.n_mrun; ++r)
+            if ((k.mrun_in >> r) & 1u) longest = std::max(longest, (r + 1 < k.n_mrun ? k.mrun_start[r + 1] : c.D) - k.mrun_start[r]);
+        // (a long run inside the block -- the subject block -- takes the BIG instance: proposals formed on the fly, four scalars
+        // per thread and round behind 16-byte loads, which the hierarchical Binomial family's even rows allow)
+        bool big = longest > 256;
+        bool on = inside >= 1 && (long long)h->geo_groups * k.n_act >= 2LL * h->n_cus;
+        if (big) {
+            on = on && h->family == FAM_HIER_BINOMIAL && (c.D & 1) == 0;
+            if (const char* e = experiment("DEMC_FROZEN_BIG")) on = on && e[0] == '1';  // A/B experiments
+        } else
+            on = on && inside <= kFrozenMax;
         if (const char* e = experiment("DEMC_FROZEN")) on = on && e[0] == '1';  // A/B experiments
         if (const char* e = experiment("DEMC_FROZEN_EXT"))  // A/B experiments: only what round 5's first form of the kernel served
             if (e[0] == '0') on = on && !k.base_theta && c.theta_snooker == 0.0 && c.partner_kind == DEMC_PARTNER_CURRENT;
@@ -741,8 +752,20 @@ int launch_phase(demc_handle* h, KParams& k) {
                 (int)k.sweep < c.n_blocks)
                 k.glist = h->frozen_order_d + ((size_t)(k.iter - h->frozen_iter0) * c.n_blocks + k.sweep) * (size_t)c.n_groups;
             h->last = demc_handle::LastPlan();
-            h->last.k1 = 5; h->last.wg = wg_f;
+            h->last.k1 = 5; h->last.wg = wg_f; h->last.big = big;
             tick(h, 0, true);
+            if (big) {
+#ifdef DEMC_EXPERIMENTS
+                if (wg_f == 512)
+                    LAUNCH_T(h, (k_frozen_sweep<512, 2, 2, true>), dim3((unsigned)n_prop), dim3(512), 0, k);
+                else if (wg_f == 2562)
+                    LAUNCH_T(h, (k_frozen_sweep<256, 2, 2, true>), dim3((unsigned)n_prop), dim3(256), 0, k);
+                else
+#endif
+                    LAUNCH_T(h, (k_frozen_sweep<256, 3, 2, true>), dim3((unsigned)n_prop), dim3(256), 0, k);
+                tick(h, 0, false);
+                return DEMC_OK;
+            }
 #ifdef DEMC_EXPERIMENTS  // (A/B builds: other workgroup sizes, register budgets and pairs per round -- profiles/r05/NOTES.md section 8)
             if (wg_f == 64)
                 LAUNCH_T(h, k_frozen_sweep<64>, dim3((unsigned)n_prop), dim3(64), 0, k);
@@ -2055,7 +2078,7 @@ static void plan_frozen_order(demc_handle* h, int64_t iter0, int32_t n_iters) {
         int inside = 0;
         for (int r = 0; r < mr.n; ++r)
             if ((mr.in >> r) & 1u) inside += (r + 1 < mr.n ? mr.start[r + 1] : c.D) - mr.start[r];
-        frozen[(size_t)b] = mr.n > 0 && inside >= 1 && inside <= kFrozenMax;
+        frozen[(size_t)b] = mr.n > 0 && inside >= 1;
         any = any || frozen[(size_t)b];
     }
     const size_t need = (size_t)n_iters * c.n_blocks * c.n_groups;
@@ -2762,7 +2785,7 @@ int32_t demc_last_kernels(demc_handle* h, char* out, int32_t nbytes) {
             std::snprintf(buf, sizeof buf, "k_propose<%d,%s,%s,false,%s>", L.wg, tf[L.tile != 0], tails[L.tail & 3], tf[L.plain]);
             break;
         case 1: std::snprintf(buf, sizeof buf, "k_longrow<%d>", L.wg); break;
-        case 5: std::snprintf(buf, sizeof buf, "k_frozen_sweep<%d>", L.wg); break;
+        case 5: std::snprintf(buf, sizeof buf, "k_frozen_sweep<%d%s>", L.wg, L.big ? ",big" : ""); break;
         case 2:
             std::snprintf(buf, sizeof buf, "k_propose<%d,true,%s,true,%s>", L.wg, tails[L.tail & 3], tf[L.plain]);
             break;

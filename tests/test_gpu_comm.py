@@ -183,7 +183,7 @@ def test_eight_shards_of_256_groups_equal_one_handle(D):
 def test_cfg4_sharded_over_eight_equals_one_handle(D):
     """BASELINE cfg4 as it is meant to run -- 128 groups of the hierarchical Binomial model over 8 GPUs, 16 groups each, two block
     sweeps per iteration, migration all-gathers in between -- as an 8-shard set on one device (rows of 2 102 scalars) against
-    the single handle: the long-row kernel takes the lane geometry and workgroup form of the WHOLE population in every shard
+    the single handle: the row-streaming kernel is chosen (over k_longrow) on the particle count of the WHOLE population in every shard
     (geometry_groups), so state and history agree bit for bit."""
     from demc_amd import workloads as W
     w = W.cfg4(S=2100, G=128, Np=32)
@@ -203,7 +203,7 @@ def test_cfg4_sharded_over_eight_equals_one_handle(D):
 
     ref, k1 = run(lambda: D.HipEngine(n_groups=G, Np=Np, D=w["D"], n_rows=n_it, schedule=2, geometry_groups=G, **cfg))
     out, k8 = run(lambda: D.MultiEngine(8, device_ids=[0] * 8, n_groups=G, Np=Np, D=w["D"], n_rows=n_it, schedule=2, **cfg))
-    assert k1 == k8 == "k_longrow<256>"
+    assert k1 == k8 == "k_frozen_sweep<256,big>"  # (the last sweep: the subject block; the hyper-parameter sweep before it is k_frozen_sweep<256>)
     for i, (x, y) in enumerate(zip(ref, out)):
         assert np.array_equal(x, y), f"array {i}"
 

@@ -254,14 +254,15 @@ def test_longrow_repeat_runs_agree_bit_for_bit(demc):
 
 
 
-@pytest.mark.parametrize("extra", [dict(), dict(theta_snooker=0.3, beta=0.3), dict(kappa=0.8)])
+@pytest.mark.parametrize("extra", [dict(kappa=0.999), dict(theta_snooker=0.3, beta=0.3, kappa=0.999), dict(kappa=0.8)])
 def test_persistent_longrow_repeat_runs_agree_bit_for_bit(demc, extra):
     """the PERSISTENT form of the long-row kernel (round 4): 96 x 32 particles of 2 102 scalars are 1 536 moving particles per
     colour phase for 512 resident workgroups -- three each, every row move but the last one of a workgroup issued from inside
     the next particle's span loops (LDS copy reused across particles, parity-buffered partial sums, LDS-only barriers).  Four
     runs on fresh handles must agree bit for bit in state, history and chain export: a hazard between consecutive particles of
     a workgroup would show as a run that differs.  Snooker / mutation / recombination variants take the other span forms and
-    the general body (no deferral)."""
+    the general body (no deferral).  (kappa < 1: with kappa = 1 this population is served by the row-streaming kernel,
+    k_frozen_sweep -- one particle per workgroup, nothing carried between particles; its repeat runs are the next test.)"""
     import hashlib
     from demc_amd import workloads as W
     w = W.cfg4(S=2100, G=96, Np=32)
@@ -276,6 +277,35 @@ def test_persistent_longrow_repeat_runs_agree_bit_for_bit(demc, extra):
         e.step(1, 6)
         assert e.last_kernels() == "k_longrow<256>"
         parts = list(e.get_state()) + list(e.get_history(0, 6)) + [e.export_chains(0, 6)]
+        e.close()
+        sigs.add(hashlib.md5(b"".join(np.ascontiguousarray(q).tobytes() for q in parts)).hexdigest())
+    assert len(sigs) == 1, extra
+
+
+@pytest.mark.parametrize("extra", [dict(), dict(theta_snooker=0.3, beta=0.3), dict(schedule=1, partner_kind=1, n_initial=3, theta_snooker=0.1, burnin=100)])
+def test_row_streaming_kernel_repeat_runs_agree_bit_for_bit(demc, extra):
+    """k_frozen_sweep in both instances (hyper-parameter block, subject block) on the same population: four runs on fresh handles
+    agree bit for bit -- partners from the population and from the history (inside burn-in: the base row from the sweep-start
+    snapshot, whole for the subject sweep, the block's columns for the hyper-parameter sweep)."""
+    import hashlib
+    from demc_amd import workloads as W
+    w = W.cfg4(S=2100, G=96, Np=32)
+    rng = np.random.default_rng(9)
+    n_init = extra.get("n_initial", 0)
+    rows0 = np.stack([w["init"](96 * 32, rng) for _ in range(n_init)]) if n_init else None
+    th0 = w["init"](96 * 32, rng)
+    sigs = set()
+    for _ in range(4):
+        cfg = dict(n_groups=96, Np=32, D=w["D"], n_rows=n_init + 5, schedule=2, seed=123, burnin=3, trace=0, alpha=0.4)
+        cfg.update(extra)
+        e = demc.HipEngine(**cfg)
+        W.configure(e, w)
+        if n_init:
+            e.set_history_rows(0, rows0)
+        e.set_state(th0)
+        e.step(1 + n_init, 5)
+        assert e.last_kernels() == "k_frozen_sweep<256,big>"
+        parts = list(e.get_state()) + list(e.get_history(n_init, n_init + 5)) + [e.export_chains(n_init, n_init + 5)]
         e.close()
         sigs.add(hashlib.md5(b"".join(np.ascontiguousarray(q).tobytes() for q in parts)).hexdigest())
     assert len(sigs) == 1, extra

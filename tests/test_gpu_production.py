@@ -285,32 +285,38 @@ def test_default_sampler_randomised_free_runs(demc, orc, cfg):
     free_run(demc, orc, w, 12, [], G, Np, theta_exact=False, **cfg)
 
 
-@pytest.mark.parametrize("wg,G,Np", [(512, 4, 8), (256, 40, 32), (256, 128, 32)])
-def test_cfg4_shape_long_row_span_loops(demc, orc, wg, G, Np):
+@pytest.mark.parametrize("kernel,G,Np,extra", [("k_longrow<512>", 4, 8, {}), ("k_frozen_sweep<256,big>", 40, 32, {}), ("k_frozen_sweep<256,big>", 128, 32, {}),
+                                               ("k_longrow<256>", 40, 32, dict(kappa=0.9)), ("k_longrow<256>", 128, 32, dict(kappa=0.9))])
+def test_cfg4_shape_long_row_span_loops(demc, orc, kernel, G, Np, extra):
     """hierarchical Binomial with the two blocks [hyper; subject] of Examples/Hierarchical_Example.jl:88-92 at S = 2100
-    (rows long enough for a workgroup per particle): k_longrow<512>, and k_longrow<256> (two workgroups per CU) once the
-    moving particles outnumber twice the CUs.  Mutation sweeps (beta = 0.1) included: theta to 1e-10.
-    The kernel is PERSISTENT (round 4): 40 x 32 gives 640 moving particles per colour phase to 512 resident workgroups (some
+    (rows long enough for a workgroup per particle): k_longrow<512> (one particle per CU), and once the moving particles
+    outnumber twice the CUs the row-streaming kernel (k_frozen_sweep: no LDS row, three or four workgroups per CU; the name
+    checked is the LAST sweep's, the subject block's) -- or, where that kernel has no form (recombination, kappa < 1),
+    k_longrow<256>, two workgroups per CU.  Mutation sweeps (beta = 0.1) included: theta to 1e-10.
+    k_longrow is PERSISTENT (round 4): 40 x 32 gives 640 moving particles per colour phase to 512 resident workgroups (some
     take two), 128 x 32 -- BASELINE's whole cfg4 population -- four each: the row of one particle (accepted proposal, or the
     current row of a rejected one) is written from inside the span loops of the next, block by block; the history compared
     here is what those deferred stores wrote."""
     from demc_amd import workloads as W
     w = W.cfg4(S=2100, G=G, Np=Np)
-    free_run(demc, orc, w, 6, [f"k_longrow<{wg}>"], G, Np, theta_exact=False)
+    free_run(demc, orc, w, 6, [kernel], G, Np, theta_exact=False, **extra)
 
 
-@pytest.mark.parametrize("extra", [dict(theta_snooker=0.3), dict(kappa=0.8), dict(beta=0.5), dict(theta_snooker=0.3, kappa=0.7, beta=0.3),
-                                   dict(masks=None), dict(S=2101)])
-def test_long_row_kernel_every_sweep_kind_trace_free(demc, orc, extra):
-    """k_longrow<256> WITHOUT the trace (the form that ships) through snooker sweeps (moving and frozen spans), recombination
-    (the general per-pair body), mutation-heavy runs, an unblocked row and an odd row length (no span loops at all) --
-    history against the oracle, free-running"""
+@pytest.mark.parametrize("kernel,extra", [("k_frozen_sweep<256,big>", dict(theta_snooker=0.3)), ("k_longrow<256>", dict(kappa=0.8)),
+                                          ("k_frozen_sweep<256,big>", dict(beta=0.5)), ("k_longrow<256>", dict(theta_snooker=0.3, kappa=0.7, beta=0.3)),
+                                          ("k_longrow<256>", dict(masks=None)), ("k_longrow<256>", dict(S=2101)),
+                                          ("k_longrow<256>", dict(theta_snooker=0.3, kappa=0.999)), ("k_longrow<256>", dict(beta=0.5, kappa=0.999))])
+def test_long_row_kernel_every_sweep_kind_trace_free(demc, orc, kernel, extra):
+    """the long-row kernels WITHOUT the trace (the forms that ship) through snooker sweeps (moving and frozen spans), recombination
+    (k_longrow's general per-pair body), mutation-heavy runs, an unblocked row and an odd row length (no span loops at all) --
+    history against the oracle, free-running.  (kappa = 0.999 keeps k_longrow<256> on the sweep kinds the row-streaming kernel
+    has taken over: it remains the kernel of every configuration with recombination.)"""
     from demc_amd import workloads as W
     extra = dict(extra)
     w = W.cfg4(S=extra.pop("S", 2100), G=40, Np=32)
     if "masks" in extra:
         w["masks"] = extra.pop("masks")
-    free_run(demc, orc, w, 5, ["k_longrow<256>"], 40, 32, theta_exact=False, **extra)
+    free_run(demc, orc, w, 5, [kernel], 40, 32, theta_exact=False, **extra)
 
 
 def _de_mc_z_family_cases(n, seed=20261007):
@@ -393,7 +399,7 @@ def test_hierarchical_example_configuration_with_enough_particles_for_the_frozen
     from demc_amd import workloads as W
     w = W.cfg4(S=2100, G=40, Np=16)
     ran = free_run(demc, orc, w, 4 + 6, [], 40, 16, theta_exact=False, beta=0.1, burnin=burnin, theta_snooker=0.1, lp_rtol=1e-8, **_Z)
-    assert ran.startswith("k_longrow<"), ran
+    assert ran == "k_frozen_sweep<256,big>", ran
 
 
 def _long_row_cases(n, seed=20261006):
