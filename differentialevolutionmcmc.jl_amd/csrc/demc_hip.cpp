@@ -731,7 +731,9 @@ int launch_phase(demc_handle* h, KParams& k) {
         // (a long run inside the block -- the subject block -- takes the BIG instance: proposals formed on the fly, four scalars
         // per thread and round behind 16-byte loads, which the hierarchical Binomial family's even rows allow)
         bool big = longest > 256;
-        bool on = inside >= 1 && (long long)h->geo_groups * k.n_act >= 2LL * h->n_cus;
+        long long min_particles = 2LL * h->n_cus;
+        if (const char* e = experiment("DEMC_FROZEN_MIN")) min_particles = std::atoll(e);  // A/B experiments
+        bool on = inside >= 1 && (long long)h->geo_groups * k.n_act >= min_particles;
         if (big) {
             on = on && h->family == FAM_HIER_BINOMIAL && (c.D & 1) == 0;
             if (const char* e = experiment("DEMC_FROZEN_BIG")) on = on && e[0] == '1';  // A/B experiments
@@ -758,6 +760,8 @@ int launch_phase(demc_handle* h, KParams& k) {
 #ifdef DEMC_EXPERIMENTS
                 if (wg_f == 512)
                     LAUNCH_T(h, (k_frozen_sweep<512, 2, 2, true>), dim3((unsigned)n_prop), dim3(512), 0, k);
+                else if (wg_f == 1024)
+                    LAUNCH_T(h, (k_frozen_sweep<1024, 4, 2, true>), dim3((unsigned)n_prop), dim3(1024), 0, k);
                 else if (wg_f == 2562)
                     LAUNCH_T(h, (k_frozen_sweep<256, 2, 2, true>), dim3((unsigned)n_prop), dim3(256), 0, k);
                 else

@@ -81,6 +81,10 @@ __global__ __launch_bounds__(WG, (WG / 64 * PER_CU + 3) / 4) void k_longrow(KPar
     __shared__ int s_base;
     __shared__ double s_ref[2][kMaxDimSeg];
     __shared__ double s_hyp[2];
+    // softplus_tab's tables (2 576 bytes): where the CU's LDS has room for them -- one workgroup per CU; two rows of cfg4's length
+    // leave 496 bytes, and those instances keep the table-free softplus_fast
+    constexpr bool kSpTab = PER_CU == 1;
+    __shared__ __attribute__((aligned(16))) double s_sp[kSpTab ? kSpDoubles : 2];
     DEMC_STAMP_INIT();
 #ifdef DEMC_STAMPS
     const unsigned long long t_real0__ = __builtin_amdgcn_s_memrealtime();  // (100 MHz: the shader clock of the run = stamp 10 / stamp 18 x 100 MHz)
@@ -94,6 +98,15 @@ __global__ __launch_bounds__(WG, (WG / 64 * PER_CU + 3) / 4) void k_longrow(KPar
     const bool seg_lane = tid < p.n_seg * kSegDoubles;
     const double seg_word = seg_lane ? reinterpret_cast<const double*>(p.dimseg)[tid] : 0.0;
 
+    SoftplusTab spt{};
+    if constexpr (kSpTab) {
+        load_softplus_table(s_sp, tid, WG);  // (visible behind the first particle's first barrier)
+        spt = softplus_tab_consts(s_sp);
+    }
+    auto sp_of = [&](double x) -> double {
+        if constexpr (kSpTab) return softplus_tab(x, spt);
+        else return softplus_fast(x);
+    };
     double* scr = lds;
     double* cdf = lds + ((D + 1) & ~1);
     const bool even = (D & 1) == 0;
@@ -640,7 +653,7 @@ __global__ __launch_bounds__(WG, (WG / 64 * PER_CU + 3) / 4) void k_longrow(KPar
             if (s >= 0 && s < S) {
                 if (hier_b) {  // k log p + (n-k) log(1-p), p = logistic(eta): one softplus per subject
                     const double eta = mu0 + v, kk = e ? k1 : k0;
-                    like += -n_bin * softplus_fast(-eta) - (n_bin - kk) * eta;
+                    like += -n_bin * sp_of(-eta) - (n_bin - kk) * eta;
                 } else if (hier_g) {  // Hierarchical_Example.jl:36-44: p.d observations per subject
                     const double mu = mu0 + v;
                     const int n = p.d;
@@ -823,10 +836,10 @@ __global__ __launch_bounds__(WG, (WG / 64 * PER_CU + 3) / 4) void k_longrow(KPar
             }
             if constexpr (HB) {  // k log p + (n-k) log(1-p), p = logistic(eta): four independent softplus chains
                 const double e0 = mu0 + v0, e1 = mu0 + v1, e2 = mu0 + v2, e3 = mu0 + v3;
-                const double l0 = -n_bin * softplus_fast(-e0) - (n_bin - cur.k0.x) * e0;
-                const double l1 = -n_bin * softplus_fast(-e1) - (n_bin - cur.k0.y) * e1;
-                const double l2 = -n_bin * softplus_fast(-e2) - (n_bin - cur.k1.x) * e2;
-                const double l3 = -n_bin * softplus_fast(-e3) - (n_bin - cur.k1.y) * e3;
+                const double l0 = -n_bin * sp_of(-e0) - (n_bin - cur.k0.x) * e0;
+                const double l1 = -n_bin * sp_of(-e1) - (n_bin - cur.k0.y) * e1;
+                const double l2 = -n_bin * sp_of(-e2) - (n_bin - cur.k1.x) * e2;
+                const double l3 = -n_bin * sp_of(-e3) - (n_bin - cur.k1.y) * e3;
                 if constexpr (MASKED) {
                     like += vp0 ? l0 : 0.0; like += vp0 ? l1 : 0.0; like += vp1 ? l2 : 0.0; like += vp1 ? l3 : 0.0;
                 } else {
@@ -980,7 +993,7 @@ __global__ __launch_bounds__(WG, (WG / 64 * PER_CU + 3) / 4) void k_longrow(KPar
                     if (subj) {
                         if (hier_b) {
                             const double eta = mu0 + v;
-                            like += -n_bin * softplus_fast(-eta) - (n_bin - kj) * eta;
+                            like += -n_bin * sp_of(-eta) - (n_bin - kj) * eta;
                         } else {
                             const double mu = mu0 + v;
                             const int n = p.d;
