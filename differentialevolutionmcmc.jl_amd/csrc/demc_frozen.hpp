@@ -414,23 +414,31 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
     auto seg_fast = [&](const SegC& sc, int a_, int b_) -> bool {
         return (sc.kd == PR_FLAT || sc.kd == PR_NORMAL || sc.kd == PR_NORMAL_REF) && a_ >= 2 && (long long)b_ <= S + 2 && hier_b && (D & 1) == 0;
     };
-    auto subject = [&](const SegC& sc, double v, double kk, bool on) {  // one scalar's terms (off: a lane past the end adds nothing)
+    // one scalar's terms (off: a lane past the end adds nothing).  What is linear in the piece is summed raw -- z^2, softplus,
+    // (n - k) eta: an FMA or an addition a scalar -- and scaled once per piece by flush(): the constants of the Normal densities
+    // times the piece's length by thread 0, -1/2 and -n on every thread's sums
+    double az2 = 0.0, asp = 0.0, ace = 0.0;
+    auto subject = [&](const SegC& sc, double v, double kk, bool on) {
         const int ob = !(v >= sc.lo && v <= sc.hi);
-        double pr = 0.0;
         if (prior_on && sc.kd != PR_FLAT) {
-            if (sc.kd == PR_NORMAL_REF) {
-                const double z = (v - sc.a) * sc.r_inv;
-                pr = -(z * z + kLog2Pi) / 2.0 - sc.r_log;
-            } else {
-                const double z = (v - sc.a) * sc.b;
-                pr = sc.c - 0.5 * (z * z);
-            }
+            const double z = (v - sc.a) * (sc.kd == PR_NORMAL_REF ? sc.r_inv : sc.b);
+            const double zm = on ? z : 0.0;
+            az2 = fma(zm, zm, az2);
         }
         const double eta = mu0 + v;
-        const double lk = -n_bin * sp_of(-eta) - (n_bin - kk) * eta;
+        const double sp = sp_of(-eta);
+        const double cm = on ? n_bin - kk : 0.0;
+        asp += on ? sp : 0.0;
+        ace = fma(cm, eta, ace);
         oob |= on ? ob : 0;
-        prior += on ? pr : 0.0;
-        like += on ? lk : 0.0;
+    };
+    auto flush = [&](const SegC& sc, int n) {  // n = the scalars subject() saw in this piece, over all threads
+        if (prior_on && sc.kd != PR_FLAT) {
+            prior += -0.5 * az2;
+            if (tid == 0) prior += (double)n * (sc.kd == PR_NORMAL_REF ? -0.5 * kLog2Pi - sc.r_log : sc.c);
+        }
+        like += -n_bin * asp - ace;
+        az2 = 0.0; asp = 0.0; ace = 0.0;
     };
     // the runs of the block mask (run-length table in the kernarg: scalar loads, wave-uniform): scalars of runs OUTSIDE the block
     // are taken as they are, the block's few scalars are proposed by the first threads
@@ -511,6 +519,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
                         one(t1.x, a1.x, b1.x, e1.x, nb.z, c1.x); one(t1.y, a1.y, b1.y, e1.y, nb.w, c1.y);
                         t0 = nt0; t1 = nt1; a0 = na0; a1 = na1; b0 = nb0; b1 = nb1; e0 = ne0; e1 = ne1; c0 = nc0; c1 = nc1;
                     }
+                    flush(sc, 4 * (m_hi - m_lo));
                 }
                 continue;
             }
@@ -555,6 +564,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
                 } else {
                     for (int j = a_ + tid; j < b_; j += WG) subject(sc, pt[j], p.data[j - 2], true);
                 }
+                flush(sc, b_ - a_);
             }
         }
     } else {
@@ -582,6 +592,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
                 subject(sc, ta.x + p.sigma * za.x, ca.x, true); subject(sc, ta.y + p.sigma * za.y, ca.y, true);
                 subject(sc, tb2.x + p.sigma * zb.x, cb.x, true); subject(sc, tb2.y + p.sigma * zb.y, cb.y, true);
             }
+            flush(sc, 4 * (m_hi - m_lo));
         }
     }
     stamp(4);  // the pass (wave 0's share)
