@@ -141,6 +141,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
     const double* grows_b = p.base_theta ? p.base_theta + (size_t)g * Np * D : grows;
     const double* pt = grows + (size_t)pl * D;
     const double w_cur = gw[pl];
+    double* srow = (!BIG && p.snap_theta) ? p.snap_theta + slot * D : nullptr;  // the row as this sweep leaves it (by-product snapshot)
     const bool maybe_base = p.proposal_kind == 0 && p.iter <= p.burnin && wave == 0;
     double pw_r[4] = {0.0, 0.0, 0.0, 0.0};
     if (maybe_base) {
@@ -530,7 +531,11 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
                 if (a_ >= b_) continue;
                 const SegC sc = seg_consts(q);
                 if (!seg_fast(sc, a_, b_)) {
-                    for (int j = a_ + tid; j < b_; j += WG) term(j, pt[j]);
+                    for (int j = a_ + tid; j < b_; j += WG) {
+                        const double v = pt[j];
+                        term(j, v);
+                        if (srow) srow[j] = v;
+                    }
                     continue;
                 }
                 if (((a_ | b_) & 1) == 0) {
@@ -549,6 +554,10 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
                             const double2 nv0 = ldp(pt, k + 2 * WG), nv1 = ldp(pt, k + 3 * WG);
                             const double2 nc0 = ldp(p.data, k + 2 * WG, -2), nc1 = ldp(p.data, k + 3 * WG, -2);
                             const bool on1 = k + WG < P_hi;
+                            if (srow) {
+                                *reinterpret_cast<double2*>(srow + 2 * (long long)k) = v0;
+                                if (on1) *reinterpret_cast<double2*>(srow + 2 * (long long)(k + WG)) = v1;
+                            }
                             subject(sc, v0.x, c0.x, true); subject(sc, v0.y, c0.y, true);
                             subject(sc, v1.x, c1.x, on1); subject(sc, v1.y, c1.y, on1);
                             v0 = nv0; v1 = nv1; c0 = nc0; c1 = nc1;
@@ -557,12 +566,17 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
                         double2 v0 = ldp(pt, k), c0 = ldp(p.data, k, -2);
                         for (; k < P_hi; k += WG) {
                             const double2 nv0 = ldp(pt, k + WG), nc0 = ldp(p.data, k + WG, -2);
+                            if (srow) *reinterpret_cast<double2*>(srow + 2 * (long long)k) = v0;
                             subject(sc, v0.x, c0.x, true); subject(sc, v0.y, c0.y, true);
                             v0 = nv0; c0 = nc0;
                         }
                     }
                 } else {
-                    for (int j = a_ + tid; j < b_; j += WG) subject(sc, pt[j], p.data[j - 2], true);
+                    for (int j = a_ + tid; j < b_; j += WG) {
+                        const double v = pt[j];
+                        subject(sc, v, p.data[j - 2], true);
+                        if (srow) srow[j] = v;
+                    }
                 }
                 flush(sc, b_ - a_);
             }
@@ -624,6 +638,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
         if (kind == 1) adj = (double)(D - 1) * (0.5 * log(s2_snk + tree(s_red[2])) - 0.5 * log(s2_snk));
         const int acc = decide_mh(p.mode, p.update_kind, u_acc, wp, w_cur, adj);
         if (acc) p.weight[slot] = wp;
+        if (!BIG && p.snap_weight) p.snap_weight[slot] = acc ? wp : w_cur;
         if (p.store_row >= 0) {
             const size_t hrow = (size_t)p.store_row * p.P + slot;
             if (p.update_kind == 0 && p.mode == MODE_STEP) {  // utilities.jl:207-208
@@ -649,6 +664,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
                     const double v = theta_new(j);
                     trow[j] = v;  // utilities.jl:204
                     if (hrow) hrow[j] = v;
+                    if (srow) srow[j] = v;
                 };
                 if (!BIG || hi - lo <= WG) {
                     if (tid < hi - lo) put(lo + tid);
@@ -706,10 +722,24 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
                     const double v = pt[4 * m + e] + p.sigma * zz[e];
                     trow[4 * m + e] = v;
                     if (hrow) hrow[4 * m + e] = v;
+                    if (srow) srow[4 * m + e] = v;
                 }
         }
     } else if (hrow) {
         for (int j = tid; j < D; j += WG) hrow[j] = pt[j];  // utilities.jl:170-180
+    }
+    // (by-product snapshot: the frozen scalars of a crossover / snooker sweep went out in the pass; what is left is the block's
+    // scalars of a rejected proposal and the whole row of a rejected mutation)
+    if (srow && !acc) {
+        if (kind == 2) {
+            for (int j = tid; j < D; j += WG) srow[j] = pt[j];
+        } else {
+            for (int r = 0; r < p.n_mrun; ++r)
+                if ((p.mrun_in >> r) & 1u) {
+                    const int lo = run_lo(r), hi = run_hi(r);
+                    if (tid < hi - lo) srow[lo + tid] = pt[lo + tid];
+                }
+        }
     }
     stamp(6);
 #ifdef DEMC_STAMPS

@@ -103,6 +103,11 @@ struct demc_handle {
     // k_frozen_sweep: launch order of the groups per (iteration, block sweep) of the current demc_step call -- groups whose
     // mutation coin fires (main.jl:199-207) first: their workgroups move the whole row and take twice as long, and a slow
     // workgroup that starts last ends the launch.  A hint only: any order gives the same results.
+    // by-product snapshot (KParams::snap_theta / snap_weight): the rows and weights a frozen sweep over the whole population ended
+    // with, valid as the sweep-start snapshot of sweep `snap2_sweep` of iteration `snap2_iter` (and of nothing else)
+    double *snap2 = nullptr, *snap2_w = nullptr;
+    int64_t snap2_iter = -1;
+    int snap2_sweep = -1;
     int* frozen_order_d = nullptr;
     size_t frozen_order_cap = 0;
     long long frozen_iter0 = 0;
@@ -686,7 +691,7 @@ int launch_phase(demc_handle* h, KParams& k) {
     // The same holds for every family whose update fuses into K1 past burn-in (the general kernel's no-tile form reads its base
     // rows through the same two pointers): with the snapshot, DE-MC_Z is one launch per sweep inside burn-in as well as past it.
     const bool suff_mvn = k.fuse_prep && c.loglike_mode == DEMC_LOGLIKE_SUFFSTAT;
-    bool snapshot = false;
+    bool snapshot = false, have_snap2 = false;
     if (!k.fuse_accept && k.mode == MODE_STEP && c.schedule == DEMC_SCHED_SYNCHRONOUS && c.partner_kind == DEMC_PARTNER_HISTORY &&
         c.proposal_kind == 0 && k.iter <= c.burnin && (h->tf_cheap_obs || suff_mvn) && c.fuse == 0 && !k.trace && !h->rp_active &&
         k.theta == h->theta) {
@@ -696,6 +701,13 @@ int launch_phase(demc_handle* h, KParams& k) {
             snapshot = true;
             k.base_theta = h->prop; k.base_weight = h->prop_prior;
             k.fuse_obs = h->tf_cheap_obs ? 1 : 0; k.fuse_accept = 1; k.write_prop = 0;
+            // ... and when the sweep before this one was a frozen sweep over the whole population, it left this snapshot behind
+            if (h->snap2 && h->snap2_iter == (int64_t)k.iter && h->snap2_sweep == (int)k.sweep && !h->cur_glist) {
+                h->snap2_iter = -1;  // (used once: by the sweep it was written for, in the demc_step call that wrote it)
+                snapshot = false;
+                have_snap2 = true;
+                k.base_theta = h->snap2; k.base_weight = h->snap2_w;
+            }
         }
     }
     auto take_snapshot = [&](bool block_only) -> int {
@@ -753,6 +765,24 @@ int launch_phase(demc_handle* h, KParams& k) {
             if (!k.glist && h->frozen_order_d && k.iter >= h->frozen_iter0 && k.iter < h->frozen_iter0 + h->frozen_iters &&
                 (int)k.sweep < c.n_blocks)
                 k.glist = h->frozen_order_d + ((size_t)(k.iter - h->frozen_iter0) * c.n_blocks + k.sweep) * (size_t)c.n_groups;
+            // the next sweep of this iteration will want a snapshot of its start as well: this sweep writes it on its way (every
+            // row passes through the kernel once) -- when it moves the whole population and does not itself read the buffer
+            const int n_sweeps = c.n_blocks > 0 ? c.n_blocks : 1;
+            if (!big && snapshot && !have_snap2 && (int)k.sweep + 1 < n_sweeps && !h->cur_glist && k.a_lo == 0 && k.n_act == c.Np &&
+                k.n_groups == c.n_groups) {
+                bool on2 = true;
+                if (const char* e = experiment("DEMC_FROZEN_SNAP2")) on2 = e[0] == '1';  // A/B experiments
+                if (on2 && !h->snap2) {
+                    if (hipMalloc((void**)&h->snap2, sizeof(double) * (size_t)h->P * c.D) != hipSuccess) { h->snap2 = nullptr; (void)hipGetLastError(); }
+                    if (h->snap2 && hipMalloc((void**)&h->snap2_w, sizeof(double) * (size_t)h->P) != hipSuccess) {
+                        hipFree(h->snap2); h->snap2 = nullptr; h->snap2_w = nullptr; (void)hipGetLastError();
+                    }
+                }
+                if (on2 && h->snap2) {
+                    k.snap_theta = h->snap2; k.snap_weight = h->snap2_w;
+                    h->snap2_iter = (int64_t)k.iter; h->snap2_sweep = (int)k.sweep + 1;
+                }
+            }
             h->last = demc_handle::LastPlan();
             h->last.k1 = 5; h->last.wg = wg_f; h->last.big = big;
             tick(h, 0, true);
@@ -1507,6 +1537,8 @@ int32_t demc_destroy(demc_handle* h) {
     }
     if (h->st_gran) hipFree(h->st_gran);
     if (h->frozen_order_d) hipFree(h->frozen_order_d);
+    if (h->snap2) hipFree(h->snap2);
+    if (h->snap2_w) hipFree(h->snap2_w);
     if (h->st_err) hipHostFree(h->st_err);
     if (h->side) hipStreamSynchronize(h->side);
     if (h->comm && h->own_comm) ncclCommDestroy(h->comm);
@@ -2119,6 +2151,7 @@ static int step_body(demc_handle* h, int64_t iter0, int32_t n_iters, bool with_m
     const demc_config& c = h->c;
     const int n_sweeps = c.n_blocks > 0 ? c.n_blocks : 1;  // block_update! main.jl:174-179
     plan_frozen_order(h, iter0, n_iters);
+    h->snap2_iter = -1;  // (a by-product snapshot lives inside one call)
     for (int64_t iter = iter0; iter < iter0 + n_iters; ++iter) {
         if (with_migration && migration_due_h(h, iter)) {  // main.jl:85
             if (c.n_groups_total != c.n_groups || (h->comm && h->own_comm)) {  // (a communicator of one rank takes the same path)

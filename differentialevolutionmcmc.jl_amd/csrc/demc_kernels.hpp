@@ -149,6 +149,10 @@ struct KParams {
     // weights select_base reads come from a SNAPSHOT of the sweep's start (null: the live arrays)
     const double* base_theta;       // [P][D]
     const double* base_weight;      // [P]
+    // ... and a frozen sweep over the whole population, which streams every row anyway, leaves the rows and weights it ENDS with
+    // in these (null: it does not): the next sweep's snapshot without a copy (k_frozen_sweep, launch_phase)
+    double* snap_theta;             // [P][D]
+    double* snap_weight;            // [P]
     // run-length tables IN the kernarg (scalar loads, no memory behind them) for wave-uniform look-ups (demc_longrow.hpp):
     // first scalars of the table segments; first scalars of the runs of the sweep's block mask, bit r of mrun_in = run r
     // lies inside the block (no blocks: one run, inside); n_mrun = 0: more runs than kMaxMaskRun.  Bit q of seg_plain:
