@@ -503,9 +503,12 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
             necessary_bytes += gather_bytes
         LAST_PROFILE_REC.clear()
         traffic, src = measured_traffic(a, n_launch, k_iters)
-        inst = "k_longrow<256>, two workgroups per CU" if P // 2 >= 512 else "k_longrow<512>"  # (launch_phase's rule, 256 CUs)
-        if P // 2 >= 512 and a.partners == "current" and not (a.snooker or w["engine"].get("theta_snooker")) and w["masks"] is not None:
-            inst += " for the subject sweep + k_frozen_sweep<256> for the hyper-parameter sweep (the row frozen: one pass over the own row)"
+        # (launch_phase's rule, 256 CUs: enough moving particles for two workgroups per CU -> the row-streaming kernel, both instances)
+        moving = P // 2 if a.partners == "current" else P
+        inst = "k_longrow<512>, one particle per CU"
+        if moving >= 512 and w["masks"] is not None:
+            inst = ("k_frozen_sweep<256,big> for the subject sweep + k_frozen_sweep<256> for the hyper-parameter sweep (rows streamed, no LDS "
+                    "row, three / four workgroups per CU)")
         ach_survey = survey_bytes / t_s / 1e9
         ach_traffic = None if traffic is None else traffic * n_launch / t_s / 1e9
         rf = dict(bound="hbm", kernel=inst + " (a workgroup per particle, one pass: proposal, prior, subject terms, accept, store)",
@@ -864,7 +867,7 @@ ROWS = [
     # = 0.1, block updates [hyper; subject] -- the 80 KB partner rows are gathered from the history
     ("cfg4_whole_history_partners_snooker_blocks", dict(config="cfg4", n_groups=128, partners="history", n_initial=4, snooker=0.1,
                                                         steps=10, warmup=3)),
-    # ... past burn-in (no base particle from the current population: the synchronous sweep is ONE k_longrow launch per block)
+    # ... past burn-in (no base particle from the current population: nothing a particle reads is written in the launch)
     ("cfg4_whole_history_partners_snooker_blocks_post_burnin", dict(config="cfg4", n_groups=128, partners="history", n_initial=4,
                                                                     snooker=0.1, burnin=0, steps=10, warmup=3)),
     # test/multivariate_normal_tests.jl:50-59 (DE-MC_Z + snooker on MvNormal(mu, sigma^2 I), 31 parameters), groups scaled to fill the chip

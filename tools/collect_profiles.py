@@ -39,7 +39,7 @@ def dominant_pattern(over):
         return "k_direct_mvn"
     if cfg in ("cfg2", "cfg3"):
         return "k_res_mvn|k_propose<"  # (history partners: the lean body past burn-in, k_propose<256,false,...> inside it)
-    return {"cfg4": "k_longrow", "cfg5": "k_lba_loglike|k_obs_loglike", "cfg1": "k_propose<", "mvn30": "k_res_mvn|k_propose<"}[cfg]
+    return {"cfg4": "k_longrow|k_frozen_sweep", "cfg5": "k_lba_loglike|k_obs_loglike", "cfg1": "k_propose<", "mvn30": "k_res_mvn|k_propose<"}[cfg]
 
 
 MFMA_CTRS = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_F64", "SQ_INSTS_VALU_MFMA_MOPS_F64", "GRBM_GUI_ACTIVE",
@@ -157,8 +157,9 @@ def main():
             rec["launches"] = e["launches_total"]
             also = [n for n in totals if "k_frozen_sweep" in n and n != dom]
             if cfg == "cfg4" and also:
-                # the hyper-parameter sweep of a blocked long-row run is k_frozen_sweep, the subject sweep k_longrow: the row's
-                # traffic is both kernels' -- reduced to bytes per iteration over the whole run, like the resident rows
+                # a blocked long-row run alternates two kernels (k_frozen_sweep<256> for the hyper-parameter sweep, k_frozen_sweep<256,big>
+                # or k_longrow for the subject sweep): the row's traffic is both kernels' -- reduced to bytes per iteration over the
+                # whole run, like the resident rows
                 rec.pop("bytes_per_launch", None)
                 rec.pop("fetch_bytes_per_launch", None)
                 rec["bytes_per_iteration"] = (totals[dom] + sum(totals[n] for n in also)) / n_iters
