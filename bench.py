@@ -536,6 +536,8 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
             rf["gather_bytes_per_update"] = gather_bytes / (sweeps * P * k_iters)
             fb = LAST_PROFILE_REC.get("fetch_bytes_per_launch")
             rf["fetch_bytes_per_update"] = None if fb is None else fb / (sweeps * P * k_iters / n_launch)
+            if fb is None and LAST_PROFILE_REC.get("fetch_bytes_per_iteration") is not None:  # (two kernels alternate: reduced per iteration)
+                rf["fetch_bytes_per_update"] = LAST_PROFILE_REC["fetch_bytes_per_iteration"] / (sweeps * P)
     else:  # cfg5
         N, na = w["dims"]
         t_s = tm["loglike"]["ms"] * 1e-3

@@ -131,7 +131,7 @@ def main():
         d = run(out_dir, f"{tag}_stats", ["--stats"], prof)
         for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
             shutil.copy(f, os.path.join(out_dir, f"bench_{tag}_kernel_stats.csv"))
-        res, totals = {}, defaultdict(float)
+        res, totals, fetch_totals = {}, defaultdict(float), defaultdict(float)
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             vals, grid = counters(run(out_dir, f"{tag}_{ctr}", ["--pmc", ctr], prof))
             for kname, cs in vals.items():
@@ -143,6 +143,8 @@ def main():
                 e[ctr + "_KB_total"] = sum(v)
                 e["launches_total"] = len(v)
                 totals[short(kname)] += (2.0 if ctr == "FETCH_SIZE" else 1.0) * sum(v) * 1024.0
+                if ctr == "FETCH_SIZE":
+                    fetch_totals[short(kname)] += 2.0 * sum(v) * 1024.0
         dom = dominant_kernel(totals, pattern, resident=True)
         if dom:
             e = res[dom]
@@ -163,6 +165,7 @@ def main():
                 rec.pop("bytes_per_launch", None)
                 rec.pop("fetch_bytes_per_launch", None)
                 rec["bytes_per_iteration"] = (totals[dom] + sum(totals[n] for n in also)) / n_iters
+                rec["fetch_bytes_per_iteration"] = (fetch_totals[dom] + sum(fetch_totals[n] for n in also)) / n_iters
                 rec["iterations"] = n_iters
                 rec["also"] = also
                 rec["launches"] = e["launches_total"] + sum(res[n]["launches_total"] for n in also)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The ONE current measurement table of DESIGN.md section 6, generated from the committed records of a round:
-    python3 tools/design_tables.py profiles/r05 > /tmp/table.md
+    python3 tools/design_tables.py profiles/r05 > /tmp/table.md          (or: ... profiles/r05 --into DESIGN.md, which replaces the table in place)
 Per row of bench.ROWS (and the headline): value, ms per step, the dominant kernel's launch time and roofline fraction from
 `bench_<row>_line.json` (the un-profiled run's full record), the rocprofv3 --stats average of the same kernel from
 `bench_<row>_kernel_stats.csv`, and the counters (`bench_<row>_pmc.json`, `bench_<row>_pipe_pmc.json`).  Nothing is typed by
@@ -67,5 +67,24 @@ def main(d):
               f"**{g(rf.get('frac'), 3)}** ({rf.get('bound')}) | {'; '.join(ctr) or '—'} |")
 
 
+def install(d, path):
+    """replace the table in `path` (from its header line to the last row) with the one generated from d"""
+    import contextlib
+    import io
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        main(d)
+    new = buf.getvalue().rstrip("\n").split("\n")
+    lines = open(path).read().split("\n")
+    a = next(i for i, ln in enumerate(lines) if ln.startswith("| row | particle-updates/s"))
+    b = a
+    while b < len(lines) and lines[b].startswith("|"):
+        b += 1
+    open(path, "w").write("\n".join(lines[:a] + new + lines[b:]))
+
+
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if len(sys.argv) > 3 and sys.argv[2] == "--into":  # python3 tools/design_tables.py profiles/r05 --into DESIGN.md
+        install(sys.argv[1], sys.argv[3])
+    else:
+        main(sys.argv[1])
