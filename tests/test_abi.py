@@ -148,3 +148,11 @@ def test_every_kernel_fits_the_registers_of_its_workgroup(demc, tmp_path):
     for name, regs, _, _, scratch in ks:
         if "k_longrow" in name:
             assert scratch == 0 and regs <= 200, (name, regs, scratch)
+    # The row-streaming kernel's point is workgroups per CU: the frozen instance must stay within 128 registers (four 256-thread
+    # workgroups per CU), the subject-block instance within 168 (three); neither may spill.
+    # (mangled: k_frozen_sweepILi<WG>ELi<MINW>ELi<PAIRS>ELb<BIG>EE)
+    frozen = [(n, r, sc) for n, r, _, _, sc in ks if "k_frozen_sweep" in n]
+    assert {bool(re.search(r"k_frozen_sweepILi256ELi3ELi2ELb1E", n)) for n, _, _ in frozen} == {True, False}, frozen
+    for name, regs, scratch in frozen:
+        big = re.search(r"k_frozen_sweepILi\d+ELi\d+ELi\d+ELb1E", name) is not None
+        assert scratch == 0 and regs <= (168 if big else 128), (name, regs, scratch)
