@@ -431,6 +431,52 @@ def test_long_row_randomised_free_runs(demc, orc, c):
     free_run(demc, orc, w, (3 if hist else 0) + 5, [], G, Np, theta_exact=False, **c)
 
 
+def _row_streaming_cases(n, seed=20261008):
+    """populations large enough for k_frozen_sweep (two workgroups' worth of moving particles per CU) over random row lengths,
+    block layouts (the reference's [hyper ; subject]; the hyper-parameters one block each and the subjects in two halves: short runs
+    inside the block next to long ones, a run that starts on an odd scalar), snooker, mutation-heavy runs, partners from the
+    population or from the history, inside / leaving / past burn-in"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        hist = bool(rng.random() < 0.5)
+        c = dict(S=int(rng.choice([2046, 2047, 2100, 2210, 2304])), G=int(rng.integers(33, 44)) if hist else int(rng.integers(65, 72)),
+                 Np=int(rng.choice([16, 32])) if hist else 16,
+                 # (DE-MC_Z from prior-drawn history rows accepts next to nothing without snooker moves in so short a run: the
+                 # reference's own DE-MC_Z runs use theta_snooker = 0.1; the snooker-free form is test_frozen_row_sweep_kernel's)
+                 theta_snooker=float(rng.choice([0.1, 0.3] if hist else [0.0, 0.1, 0.3])), beta=float(rng.choice([0.0, 0.1, 0.5])),
+                 burnin=int(rng.choice([0, 5, 100])), seed=int(rng.integers(1, 2**31)), hist=hist, layout=int(rng.integers(0, 3)))
+        out.append(pytest.param(c, id=f"{i}-S{c['S']}-G{c['G']}-Np{c['Np']}-h{int(hist)}-l{c['layout']}-s{c['theta_snooker']:g}-b{c['burnin']}"))
+    return out
+
+
+def run_row_streaming_case(demc, orc, c):
+    from demc_amd import workloads as W
+    c = dict(c)
+    S, G, Np, hist, layout = c.pop("S"), c.pop("G"), c.pop("Np"), c.pop("hist"), c.pop("layout")
+    w = W.cfg4(S=S, G=G, Np=Np)
+    D = w["D"]
+    if layout == 1:  # four blocks: mu | sd | the first subjects up to an odd border | the rest
+        cut = 2 + (S // 2) | 1
+        m = np.zeros((4, D), np.uint8)
+        m[0, 0] = 1; m[1, 1] = 1; m[2, 2:cut] = 1; m[3, cut:] = 1
+        w["masks"] = m
+    elif layout == 2:  # the subject block first, then the hyper-parameters (the by-product snapshot has no sweep to serve)
+        w["masks"] = w["masks"][::-1].copy()
+    if hist:
+        c.update(schedule=1, partner_kind=1, n_initial=3)
+    return free_run(demc, orc, w, (3 if hist else 0) + 4, [], G, Np, theta_exact=False, lp_rtol=1e-8, **c)
+
+
+@pytest.mark.parametrize("c", _row_streaming_cases(6))
+def test_row_streaming_kernel_randomised_free_runs(demc, orc, c):
+    """the generator above against the oracle: every accept decision and particle id equal, theta to 1e-10
+    (tests/free_run_sweep.py row_streaming N runs the long form)"""
+    ran = run_row_streaming_case(demc, orc, c)
+    if c["S"] % 2 == 0 or c["layout"] == 2:  # (the name is the LAST sweep's; an odd row's subject sweeps stay with k_longrow)
+        assert ran.startswith("k_frozen_sweep<256"), ran
+
+
 def test_cfg5_shape_lba_thread_per_proposal(demc, orc):
     """LBA, 3 accumulators, snooker 0.1 (Examples/Run_LBA.jl), N = 500 simulated trials: K1 -> k_obs_loglike (Phi / phi
     tables in LDS) -> k_accept_store.  LBA log-densities at 1e-5 (survival factors formed by cancellation, see
