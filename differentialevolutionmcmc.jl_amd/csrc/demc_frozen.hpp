@@ -1,27 +1,33 @@
-// demc_frozen.hpp -- K1 for the block sweeps of a LONG row in which the row itself is frozen (round 5).
+// demc_frozen.hpp -- K1 for the block sweeps of LONG rows over a whole population: the rows are streamed, nothing is parked (round 5).
 //
-// block_update! (main.jl:169-179) sweeps the group once per block; in a hierarchical model the first block is the handful of
-// hyper-parameters (Examples/Hierarchical_Example.jl:88-92: [true, true, fill(false, n_subj), true]) and reset!
-// (crossover.jl:336-352) puts every other scalar of a crossover proposal back.  Such a sweep still costs a full evaluation --
-// every subject term depends on the hyper-parameters -- but it moves nothing: no partner rows (two or three scalars of each),
-// no theta' to park, no row to write.  k_longrow (demc_longrow.hpp) runs it with its subject-sweep machinery: 183 registers,
-// an 80 KB LDS row per workgroup, hence 8 waves per CU -- and at 8 waves the span rounds wait for latency (0.28 of the vector
-// pipe over the launch; profiles/r05/NOTES.md: 30 - 37 us per particle where its row needs 9).  This kernel is the sweep
-// reduced to what it is: ONE workgroup per particle streams the particle's own row once, one softplus (hier. Binomial) or
-// p.d residuals (hier. Gaussian) and one prior term per scalar, no LDS row, ~100 registers -- five 256-thread workgroups per
-// CU, so one particle's prologue (Philox, base pick, hyper-parameter proposals: dependent round trips) runs under the
-// arithmetic of four others.
+// block_update! (main.jl:169-179) sweeps the group once per block; in a hierarchical model the blocks are the handful of
+// hyper-parameters and the subjects (Examples/Hierarchical_Example.jl:88-92: [true, true, fill(false, n_subj), true] and its
+// complement), and reset! (crossover.jl:336-352) puts every scalar outside the block back.  k_longrow (demc_longrow.hpp) parks
+// theta' in an 80 KB LDS row per workgroup -- two workgroups, eight waves per CU -- and in-kernel stamps showed its pass, and the
+// first form of this kernel's, running at the vector pipe's issue rate (profiles/r05/NOTES.md sections 8, 9).  Here ONE workgroup
+// per particle streams the rows once, with no LDS row, so three or four 256-thread workgroups share a CU:
+//   <256>      the block holds a few scalars (<= kFrozenMax) and the rest of a crossover proposal is frozen: one pass over the
+//              particle's OWN row (one prior term and one softplus -- hier. Binomial -- or p.d residuals -- hier. Gaussian -- per
+//              scalar), the block's scalars proposed by single lanes, partner rows read at those scalars only -- whole, for the
+//              projections, by the particles whose snooker coin fired.  120 registers: four workgroups per CU.
+//   <256,big>  the block is most of the row (hier. Binomial, even rows): the proposal of every scalar formed on the fly from own,
+//              partner and base rows -- a Philox noise block of four scalars per thread and round, rows one round ahead -- and
+//              formed AGAIN by an accepted particle for its stores.  155 registers: three workgroups per CU.
+// Both: softplus from two small LDS tables (softplus_tab, demc_device.hpp); what is linear in a piece of the row summed raw and
+// scaled once (subject() / flush()); past burn-in the history row of an iteration's last sweep written in the pass (the current
+// values; an accepted proposal overwrites the block's); partners from the population or cells of the history (DE-MC_Z), the base row and
+// select_base's weights from the sweep-start snapshot when the launch has one (KParams::base_theta); <256> can leave the rows it
+// streamed behind as the NEXT sweep's snapshot (KParams::snap_theta).
 //
-// Same addressed draws and the same arithmetic per scalar as k_longrow / k_propose (proposals bit for bit); the sums of the prior
-// and likelihood terms run in another order (tests compare log-posteriors to 1e-9 and every decision).  Mutation sweeps
-// (mutate_or_crossover!, main.jl:199-207: the group's coin; mutation! ignores the block, main.jl:205) move the whole row:
-// v = theta + sigma z per scalar in the same pass, and an ACCEPTED mutation forms the row again to store it (no LDS copy to
-// keep it in: the second pass is paid by the accepted particles of one group in ten).
+// Same addressed draws and the same arithmetic per proposed scalar as k_longrow / k_propose (proposals bit for bit); the sums of
+// the prior and likelihood terms run in another order and softplus_tab is not softplus_fast bit for bit (tests compare
+// log-posteriors to 1e-9 / 1e-8 and every decision).  Mutation sweeps (mutate_or_crossover!, main.jl:199-207: the group's coin;
+// mutation! ignores the block, main.jl:205) move the whole row: v = theta + sigma z per scalar in the same pass, and an ACCEPTED
+// mutation forms the row again to store it.
 //
-// Taken by launch_phase for: hierarchical families, rows long enough for a workgroup per particle, a block mask with at most
-// kFrozenMax scalars inside the block, the reference's default crossover or its fixed / variable gamma forms, no snooker
-// (theta_snooker = 0: as in the PLAIN instances the 2^-53 event of crossover.jl:31 is not taken), kappa = 1, partners from the
-// current population, pools of at most 256, no trace, no replay.  Everything else stays with k_longrow.
+// Taken by launch_phase (demc_hip.cpp) for: hierarchical families, rows long enough for a workgroup per particle, at least two
+// workgroups' worth of moving particles per CU, a block mask, kappa = 1, pools of at most 256, no trace, no replay.  Everything
+// else -- recombination, odd or unblocked rows, the hier. Gaussian subject block, one particle per CU -- stays with k_longrow.
 #pragma once
 #include "demc_kernels.hpp"
 
@@ -142,6 +148,8 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
     const double* pt = grows + (size_t)pl * D;
     const double w_cur = gw[pl];
     double* srow = (!BIG && p.snap_theta) ? p.snap_theta + slot * D : nullptr;  // the row as this sweep leaves it (by-product snapshot)
+    // the history row of a sweep that is the iteration's last: the row as it stands after the decision (utilities.jl:161-180)
+    double* hrow = (p.store_row >= 0) ? p.hist + ((size_t)p.store_row * p.P + slot) * D : nullptr;
     const bool maybe_base = p.proposal_kind == 0 && p.iter <= p.burnin && wave == 0;
     double pw_r[4] = {0.0, 0.0, 0.0, 0.0};
     if (maybe_base) {
@@ -163,6 +171,12 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
     // instances), 2 mutation
     const bool snooker = !is_mut && p.theta_snooker > 0.0 && u_snk <= p.theta_snooker;
     const int kind = is_mut ? 2 : snooker ? 1 : 0;
+    // Past burn-in a crossover / snooker sweep writes the CURRENT value of every scalar it reads into the history row on its way
+    // (the stores ride under the pass); an accepted proposal then overwrites the block's scalars, a rejected one has nothing left
+    // to do -- where the row is otherwise read a second time for the copy: 80 KB per particle at cfg4, and in 10^4 dimensions a
+    // converged population rejects nearly everything (whole cfg4 from a converged start: 0.459 -> 0.421 ms per iteration).
+    // Inside burn-in, where a prior-drawn population accepts every other proposal, the overwritten stores cost 2 %: the copy stays.
+    const bool h_pass = hrow != nullptr && kind != 2 && p.iter > p.burnin;
     const double *Pa = pt, *Pb2 = pt, *Pc = pt, *Pbase = pt;
     double g1 = 0.0, g2 = 0.0;
     bool use_base = false;
@@ -453,6 +467,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
                 auto moved = [&](int j) {
                     const double v = theta_new(j);
                     term(j, v);
+                    if (h_pass) hrow[j] = pt[j];
                     if (kind == 1) {  // adjust_loglike norms (crossover.jl:268-273)
                         const double z = Pa[j], a1 = v - z, a0 = pt[j] - z;
                         ds1 += a1 * a1 - a0 * a0;
@@ -495,6 +510,10 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
                         const double2 nb0 = two ? ld(Pb2, mn, 0) : zero2, nb1 = two ? ld(Pb2, mn, 2) : zero2;
                         const double2 ne0 = use_base ? ld(Pbase, mn, 0) : zero2, ne1 = use_base ? ld(Pbase, mn, 2) : zero2;
                         const double2 nc0 = ld(p.data, mn, -2), nc1 = ld(p.data, mn, 0);
+                        if (h_pass) {
+                            *reinterpret_cast<double2*>(hrow + 4 * (size_t)m) = t0;
+                            *reinterpret_cast<double2*>(hrow + 4 * (size_t)m + 2) = t1;
+                        }
                         const U4 nb = draw_block(p.seed, S_NOISE, p.sweep, (uint64_t)p.iter, eslot, (uint32_t)m);
                         auto one = [&](double tj, double aj, double bj2, double ej, uint32_t wj, double kk) {
                             const double bj = -eps + eps2 * u32unit(wj);
@@ -535,6 +554,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
                         const double v = pt[j];
                         term(j, v);
                         if (srow) srow[j] = v;
+                        if (h_pass) hrow[j] = v;
                     }
                     continue;
                 }
@@ -558,6 +578,10 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
                                 *reinterpret_cast<double2*>(srow + 2 * (long long)k) = v0;
                                 if (on1) *reinterpret_cast<double2*>(srow + 2 * (long long)(k + WG)) = v1;
                             }
+                            if (h_pass) {
+                                *reinterpret_cast<double2*>(hrow + 2 * (long long)k) = v0;
+                                if (on1) *reinterpret_cast<double2*>(hrow + 2 * (long long)(k + WG)) = v1;
+                            }
                             subject(sc, v0.x, c0.x, true); subject(sc, v0.y, c0.y, true);
                             subject(sc, v1.x, c1.x, on1); subject(sc, v1.y, c1.y, on1);
                             v0 = nv0; v1 = nv1; c0 = nc0; c1 = nc1;
@@ -567,6 +591,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
                         for (; k < P_hi; k += WG) {
                             const double2 nv0 = ldp(pt, k + WG), nc0 = ldp(p.data, k + WG, -2);
                             if (srow) *reinterpret_cast<double2*>(srow + 2 * (long long)k) = v0;
+                            if (h_pass) *reinterpret_cast<double2*>(hrow + 2 * (long long)k) = v0;
                             subject(sc, v0.x, c0.x, true); subject(sc, v0.y, c0.y, true);
                             v0 = nv0; c0 = nc0;
                         }
@@ -576,6 +601,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
                         const double v = pt[j];
                         subject(sc, v, p.data[j - 2], true);
                         if (srow) srow[j] = v;
+                        if (h_pass) hrow[j] = v;
                     }
                 }
                 flush(sc, b_ - a_);
@@ -655,7 +681,6 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
     // ---- the row moves: an accepted crossover writes the block's scalars, an accepted mutation the row (formed again); the
     // history row (a sweep that is the iteration's last) is the row as it stands after the decision ----
     double* trow = p.theta + slot * D;
-    double* hrow = (p.store_row >= 0) ? p.hist + ((size_t)p.store_row * p.P + slot) * D : nullptr;
     if (acc && kind != 2) {
         for (int r = 0; r < p.n_mrun; ++r) {
             const int lo = run_lo(r), hi = run_hi(r);
@@ -707,7 +732,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
                     if (hrow) { *reinterpret_cast<double2*>(hrow + 4 * (size_t)m) = v0; *reinterpret_cast<double2*>(hrow + 4 * (size_t)m + 2) = v1; }
                 }
                 }
-            } else if (hrow)
+            } else if (hrow && !h_pass)  // (past burn-in the history scalars of the runs outside the block went out in the pass)
                 for (int j = lo + tid; j < hi; j += WG) hrow[j] = pt[j];
         }
     } else if (acc) {
@@ -725,7 +750,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
                     if (srow) srow[4 * m + e] = v;
                 }
         }
-    } else if (hrow) {
+    } else if (hrow && !h_pass) {
         for (int j = tid; j < D; j += WG) hrow[j] = pt[j];  // utilities.jl:170-180
     }
     // (by-product snapshot: the frozen scalars of a crossover / snooker sweep went out in the pass; what is left is the block's

@@ -88,6 +88,8 @@ def cfg4(S=10000, G=16, Np=32, seed=20260004):
     return dict(name="cfg4", G=G, Np=Np, fam=F.FAM_HIER_BINOMIAL, data=k, dims=[S], hyper=[n], D=D,
                 pk=[F.PRIOR_NORMAL, F.PRIOR_HALFCAUCHY] + [F.PRIOR_NORMAL_REF] * S, pa=[1, 0] + [0] * S, pb=[1, 1] + [1] * S,
                 pref=[0, 0] + [1] * S, lo=[-INF, 0] + [-INF] * S, hi=[INF] * D, masks=np.stack([m0, 1 - m0]), engine={},
+                # the generating parameters and (roughly) the posterior's spread around them: a converged population (`--start posterior`)
+                truth=np.concatenate([[1.0, 1.0], b0]), truth_sd=np.concatenate([[0.01, 0.01], np.full(S, 0.3)]),
                 init=lambda P, rng: np.concatenate([rng.normal(1, 1, (P, 1)), np.abs(rng.standard_cauchy((P, 1))) + 0.3,
                                                     rng.normal(0, 1, (P, S))], 1))
 
