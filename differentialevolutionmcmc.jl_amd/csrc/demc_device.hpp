@@ -322,16 +322,18 @@ __device__ __forceinline__ double recip_pos(double x) {
 // the factor a trial contributes to the likelihood PRODUCT: max(density, 1e-10), or 0 where the reference's log-density is
 // -Inf (decision time not after tau, NaN density) -- the caller takes ONE log of the product of several trials.
 // nuS = S nu, kS = S k, bS = S b, inv_SA = 1 / (S A)
-template <int NA, int RS = kPhiRow>
+// (C = int: the winner as a wave-uniform index, k_obs_loglike; C = double: as it lies in the data, one per lane -- k_lba_wave --
+// compared without a conversion instruction)
+template <int NA, int RS = kPhiRow, typename C = int>
 __device__ __forceinline__ double lba_trial(const double* tab, int na_rt, const double* nu, const double* nuS, double kS, double bS,
-                                            double tau, double inv_A, double inv_SA, double inv_norm, int c, double rt) {
+                                            double tau, double inv_A, double inv_SA, double inv_norm, C c, double rt) {
     const int na = NA > 0 ? NA : na_rt;
     const double t = rt - tau;
     const double inv_t = recip_pos(t), c1 = kS * inv_t, c2 = bS * inv_t, t_inv_SA = t * inv_SA;
     double den = inv_norm;
 #pragma unroll
     for (int a = 0; a < (NA > 0 ? NA : 8); ++a)
-        if (a < na) den *= lba_factor<RS>(tab, a + 1 == c, nu[a], nuS[a], c1, c2, inv_A, t_inv_SA);
+        if (a < na) den *= lba_factor<RS>(tab, (C)(a + 1) == c, nu[a], nuS[a], c1, c2, inv_A, t_inv_SA);
     const double floored = fmax(den, 1e-10);  // (a NaN density is caught below)
     // The table clamps its argument with v_max / v_min, which read a NaN as -8.5: a NaN ARGUMENT would no longer reach `den`.
     // The arguments can only become NaN through 1/t of a denormal t (rcp = Inf, 0 * Inf in the Newton steps); decision times

@@ -76,6 +76,7 @@ struct demc_handle {
     int dp_direct = 0;          // DIRECT mode: padded length of a whitened observation row (8 / 16 / 32 / 64)
     int direct_wgs_per_cu = 0;  // ... resident workgroups of its kernel per CU (asked once)
     int obs_wgs_per_cu = 0;     // the same for k_obs_loglike
+    int lba_wave_wgs_per_cu = 0;  // ... and k_lba_wave
     bool lba_wide_ok = false;   // k_lba_loglike's 140 KB of dynamic LDS were granted (demc_create)
     double *data = nullptr, *Ainv = nullptr, *Ypad = nullptr, *Xf = nullptr, *sx = nullptr, *xbar = nullptr;
     size_t data2_off = 0;
@@ -539,6 +540,33 @@ int launch_loglike(demc_handle* h, KParams& k) {
             }
 #endif
             (void)lba_wide;
+            if (h->family == FAM_LBA) {
+                // a wave per proposal, lanes across the (sorted) trials: k_lba_wave.  Chunks of whole batches (512 trials), at least two a chunk.
+                bool on = true;
+                if (const char* e = experiment("DEMC_LBA_WAVE")) on = e[0] == '1';  // A/B experiments
+                if (on) {
+                    if (h->lba_wave_wgs_per_cu == 0) {
+                        int nb = 0;
+                        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_lba_wave<3>, 256, 0));
+                        h->lba_wave_wgs_per_cu = nb > 0 ? nb : 1;
+                    }
+                    long long capw = h->N / 1024;
+                    if (capw > h->partial_cap) capw = h->partial_cap;
+                    if (capw < 1) capw = 1;
+                    int nc = chunks_filling_rounds((n_prop + 3) / 4, capw, (double)h->lba_wave_wgs_per_cu * h->n_cus);
+                    if (const char* e = experiment("DEMC_OBS_CHUNKS"))  // A/B experiments
+                        if (std::atoi(e) > 0 && std::atoi(e) <= capw) nc = std::atoi(e);
+                    h->last.k2 = 8;
+                    tick(h, 2, true);
+                    const dim3 grid((unsigned)((n_prop + 3) / 4), (unsigned)nc);
+                    if (h->n_acc == 3) LAUNCH_T(h, k_lba_wave<3>, grid, dim3(256), 0, k, nc);
+                    else if (h->n_acc == 2) LAUNCH_T(h, k_lba_wave<2>, grid, dim3(256), 0, k, nc);
+                    else LAUNCH_T(h, k_lba_wave<0>, grid, dim3(256), 0, k, nc);
+                    tick(h, 2, false);
+                    k.n_partials = nc;
+                    break;
+                }
+            }
             h->last.k2 = 2;
             tick(h, 2, true);
             LAUNCH_T(h, k_obs_loglike, dim3((unsigned)((n_prop + 255) / 256), (unsigned)n_chunks), dim3(256), 0,
@@ -1634,6 +1662,18 @@ int32_t demc_set_model(demc_handle* h, int32_t family, const double* data, const
             h->c0 = (family == DEMC_FAM_LNR) ? (nhyper > 0 ? hyper[0] : 1.0) : 0.0;
             dev.assign(data, data + 2 * dm[0]);
             h->data2_off = (size_t)dm[0];
+            if (family == DEMC_FAM_LBA) {
+                // The log-likelihood is a sum over trials: their order is the library's to choose.  Sorted by (choice, decision time)
+                // the 64 lanes of k_lba_wave -- 64 consecutive trials of one proposal -- read the same row or two of the Phi table and
+                // share their winner (demc_kernels.hpp).
+                const size_t N = (size_t)dm[0];
+                std::vector<size_t> order(N);
+                for (size_t i = 0; i < N; ++i) order[i] = i;
+                std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b2) {
+                    return data[a] != data[b2] ? data[a] < data[b2] : data[N + a] < data[N + b2];
+                });
+                for (size_t i = 0; i < N; ++i) { dev[i] = data[order[i]]; dev[N + i] = data[N + order[i]]; }
+            }
         } break;
         case DEMC_FAM_RASTRIGIN:
             h->N = 1;
@@ -2839,6 +2879,7 @@ int32_t demc_last_kernels(demc_handle* h, char* out, int32_t nbytes) {
     std::string s = buf;
     if (L.k2 == 1) s += " + k_cross_mfma<" + std::to_string(L.ks) + ",4>";
     else if (L.k2 == 2) s += " + k_obs_loglike";
+    else if (L.k2 == 8) s += " + k_lba_wave";
     else if (L.k2 == 3) s += " + k_hier_loglike";
     else if (L.k2 == 4) s += " + k_user_loglike";
     else if (L.k2 == 5) s += " + k_direct_mvn<" + std::to_string(L.ks) + ">";

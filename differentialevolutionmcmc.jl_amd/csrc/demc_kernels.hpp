@@ -2084,6 +2084,85 @@ __global__ __launch_bounds__(256) void k_obs_loglike(KParams p, int n_chunks) {
 }
 #endif
 
+// ------------------------------------------------------------------------------------------------
+// K2 (LBA, Examples/Run_LBA.jl:33-37): a WAVE per proposal, lanes across trials (round 5).
+// k_obs_loglike's lanes are proposals at one trial: in a population that has not converged every lane reads another row of the
+// Phi table and the LDS pipe, not the vector pipe, sets the pace (LDS busy 0.88, VALU 0.62 on cfg5's prior-drawn row).  Here the
+// lanes of a wave are 64 TRIALS of one proposal, and demc_set_model has sorted the trials by (choice, decision time): the table
+// argument S (b / t - nu_a) moves by a fraction of a row across the wave, whatever the proposal -- the reads are broadcasts -- and
+// the winner is the same accumulator in all lanes but at the three borders of the sort.  The proposal's parameters are
+// wave-uniform (scalar loads).  Per (proposal, chunk): trials i0 + lane, + 64, ...; a batch of kLbaBatch trials per lane
+// contributes one log of the product of its floored densities, as in lba_range_sum; the lanes' sums are added in a fixed order.
+// Same arithmetic per (trial, proposal) as lba_trial; another order of the sum over trials (the LBA's log-likelihoods are
+// compared with the oracle at 1e-5).
+// ------------------------------------------------------------------------------------------------
+#ifndef DEMC_DEVICE_HELPERS_ONLY
+template <int NA>
+__global__ __launch_bounds__(256, 2) void k_lba_wave(KParams p, int n_chunks) {
+    __shared__ double s_tab[kPhiIntervals * kPhiRow];
+    for (int i = threadIdx.x; i < kPhiIntervals * kPhiRow; i += 256) s_tab[i] = kPhiTable[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = blockIdx.x * 4 + wave;
+    const int n_prop = p.n_groups * p.n_act;
+    const int chunk = blockIdx.y;
+    if (q >= n_prop) return;
+    const size_t slot = (size_t)slot_of(p, q);
+    const double* th = p.prop + slot * p.D;  // wave-uniform
+    const int na = NA > 0 ? NA : p.n_acc;
+    double nu[8], nuS[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        nu[a] = a < na ? th[a] : 0.0;
+        nuS[a] = kPhiS * nu[a];
+    }
+    const double A = th[na], kk = th[na + 1], tau = th[na + 2], b = A + kk, inv_A = 1.0 / A;
+    const double kS = kPhiS * kk, bS = kPhiS * b, inv_SA = inv_A * (1.0 / kPhiS);
+    double pneg = 1.0;
+#pragma unroll
+    for (int a = 0; a < (NA > 0 ? NA : 8); ++a)
+        if (a < na) {
+            double qq, Ph;
+            phiS_Phi_table(s_tab, -nuS[a], qq, Ph);
+            pneg *= Ph;
+        }
+    const double inv_norm = 1.0 / (1.0 - pneg);
+    // chunks of whole batches (64 lanes x kLbaBatch trials), the last one ragged
+    constexpr long long kStep = 64LL * kLbaBatch;
+    const long long n_steps = (p.N + kStep - 1) / kStep, per = (n_steps + n_chunks - 1) / n_chunks;
+    const long long i0 = (long long)chunk * per * kStep, i1r = i0 + per * kStep, i1 = i1r < p.N ? i1r : p.N;
+    double acc = 0.0;
+    long long base = i0;
+    for (; base + kStep <= i1; base += kStep) {  // whole batches: every lane has its kLbaBatch trials, no predicate in the body
+        double cc[kLbaBatch], rr[kLbaBatch];
+#pragma unroll
+        for (int j = 0; j < kLbaBatch; ++j) {
+            cc[j] = p.data[base + 64LL * j + lane];
+            rr[j] = p.data2[base + 64LL * j + lane];
+        }
+        double prod = 1.0;
+        // (both factors of lba_factor and a select per lane: a batch-level test for ONE winner in all 512 trials -- all but three
+        // batches of a proposal -- with the scalar-branch form behind it measured 2 % SLOWER, profiles/r05/NOTES.md section 10)
+#pragma unroll
+        for (int j = 0; j < kLbaBatch; ++j)
+            prod *= lba_trial<NA, kPhiRow, double>(s_tab, na, nu, nuS, kS, bS, tau, inv_A, inv_SA, inv_norm, cc[j], rr[j]);
+        if (__builtin_expect(!(prod < 1e300), 0)) {  // (see lba_range_sum: the batch again, a log per trial)
+            double s2 = 0.0;
+#pragma unroll 1
+            for (int j = 0; j < kLbaBatch; ++j)
+                s2 += log(lba_trial<NA, kPhiRow, double>(s_tab, na, nu, nuS, kS, bS, tau, inv_A, inv_SA, inv_norm, cc[j], rr[j]));
+            acc += s2;
+        } else
+            acc += log(prod);
+    }
+#pragma unroll 1
+    for (long long i = base + lane; i < i1; i += 64)  // the ragged end of the data (fewer than 512 trials): a log per trial
+        acc += log(lba_trial<NA, kPhiRow, double>(s_tab, na, nu, nuS, kS, bS, tau, inv_A, inv_SA, inv_norm, p.data[i], p.data2[i]));
+    acc = subgroup_sum(acc, 64);
+    if (lane == 0) p.partial[(size_t)chunk * p.P + slot] = acc;
+}
+#endif
+
 #ifdef DEMC_EXPERIMENTS
 // ------------------------------------------------------------------------------------------------
 // K2 (LBA, Examples/Run_LBA.jl:33-37) with EIGHT shifted copies of the table -- an A/B EXPERIMENT (make EXPERIMENTS=1,

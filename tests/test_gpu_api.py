@@ -546,7 +546,7 @@ def test_bench_rows_and_the_row_flags(tmp_path):
     assert rows["cfg3_suffstat_history_partners_post_burnin"]["kernels"] == "k_res_mvn<512,false,32,1>"
     # (a row's sampler settings must reach its engine: the workload object is shared between the rows of a configuration)
     assert rows["cfg3_suffstat_history_partners_snooker"]["kernels"] == "k_res_mvn<512,false,32,3>"
-    assert rows["cfg4_share"]["kernels"] == "k_longrow<512>" and "k_obs_loglike" in rows["cfg5_share_converged"]["kernels"]
+    assert rows["cfg4_share"]["kernels"] == "k_longrow<512>" and "k_lba_wave" in rows["cfg5_share_converged"]["kernels"]
     assert r["headline_context"]["direct_frac"] == rows["cfg3_direct"]["roofline"]["frac"]
     # the headline itself is untouched by the rows
     assert r["metric"].startswith("particle-updates/sec") and "cfg3" in r["config"]["workload"] and r["roofline"]["bound"] == "mfma"

@@ -210,7 +210,7 @@ def test_cfg4_sharded_over_eight_equals_one_handle(D):
 
 def test_cfg5_sharded_over_eight_equals_one_handle(D):
     """BASELINE cfg5's partition -- 512 groups of the LBA model (snooker 0.1) over 8 GPUs, 64 groups each -- as an 8-shard set on one
-    device against the single handle (500 simulated trials, 16 particles per group): K1 -> k_obs_loglike -> k_accept_store with
+    device against the single handle (500 simulated trials, 16 particles per group): K1 -> k_lba_wave -> k_accept_store with
     the chunk counts of the whole population; ids, accept flags and theta bit for bit, log-densities too (same kernels, same sums)."""
     from demc_amd import workloads as W
     w = W.cfg5(N=500, G=512, Np=16)

@@ -477,13 +477,16 @@ def test_row_streaming_kernel_randomised_free_runs(demc, orc, c):
         assert ran.startswith("k_frozen_sweep<256"), ran
 
 
-def test_cfg5_shape_lba_thread_per_proposal(demc, orc):
-    """LBA, 3 accumulators, snooker 0.1 (Examples/Run_LBA.jl), N = 500 simulated trials: K1 -> k_obs_loglike (Phi / phi
-    tables in LDS) -> k_accept_store.  LBA log-densities at 1e-5 (survival factors formed by cancellation, see
-    test_gpu_parity._rtol), snooker projections to 1e-10."""
+@pytest.mark.parametrize("N", [500, 1500, 4096, 5000])
+def test_cfg5_shape_lba_wave_per_proposal(demc, orc, N):
+    """LBA, 3 accumulators, snooker 0.1 (Examples/Run_LBA.jl), simulated trials: K1 -> k_lba_wave (a wave per proposal, lanes
+    across the trials, which demc_set_model sorted by (choice, decision time); Phi / phi tables in LDS) -> k_accept_store.
+    N = 500: no whole batch of 512 trials, the ragged-end loop alone; 1 500: two whole batches and a ragged end; 4 096: whole
+    batches only, several chunks; 5 000: chunks of unequal length.  LBA log-densities at 1e-5 (survival factors formed by
+    cancellation, see test_gpu_parity._rtol), snooker projections to 1e-10."""
     from demc_amd import workloads as W
-    w = W.cfg5(N=500, G=8, Np=16)
-    free_run(demc, orc, w, 10, ["k_obs_loglike", "k_accept_store"], 8, 16, theta_exact=False, lp_rtol=1e-5)
+    w = W.cfg5(N=N, G=8, Np=16)
+    free_run(demc, orc, w, 10, ["k_lba_wave", "k_accept_store"], 8, 16, theta_exact=False, lp_rtol=1e-5)
 
 
 def test_sample_runs_the_production_instances(demc):
