@@ -563,14 +563,15 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
         try:
             pj = os.path.join(ROOT, "profiles", PROFILE_ROUND, f"bench_{profile_tag(a)}_pipe_pmc.json")
             if profile_is_current(pj):
-                pipes = [v for k, v in json.load(open(pj)).items() if "k_lba_loglike" in k or "k_obs_loglike" in k][0]
+                pipes = [v for k, v in json.load(open(pj)).items() if "k_lba_wave" in k or "k_lba_loglike" in k or "k_obs_loglike" in k][0]
                 pipes_src = f"profiles/{PROFILE_ROUND}/{os.path.basename(pj)} (rocprofv3 --pmc passes of this command, not this run)"
             else:
                 pipes_src = f"profiles/{PROFILE_ROUND}/{os.path.basename(pj)} was collected on other kernel sources: not quoted"
         except (OSError, KeyError, ValueError, IndexError):
             pass
-        rf = dict(bound="valu", kernel="k_obs_loglike (LBA: thread per proposal, wave-uniform trial loads in batches of 8, one degree-7 "
-                                       "Phi polynomial table on intervals of 1/32 in LDS whose derivative gives phi, one log per batch)",
+        rf = dict(bound="valu", kernel="k_lba_wave (LBA: a wave per proposal, lanes across trials sorted by (choice, decision time), batches of 8 "
+                                       "trials per lane, one degree-7 Phi polynomial table on intervals of 1/32 in LDS whose derivative gives phi -- "
+                                       "read as broadcasts --, one log per batch)",
                   achieved=ach, peak=PEAK_FP64_TFLOPS, unit="TFLOP/s", frac=None if ach is None else ach / PEAK_FP64_TFLOPS,
                   flop_counted=None if flop_per_eval is None else f"{flop_per_eval:.1f} executed FP64 flop per (trial, proposal) evaluation x N x proposals",
                   flop_source=inner_src, static_valu_insts_per_eval=inner.get("valu_insts_per_eval"),
@@ -578,8 +579,8 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
                   valu_busy_frac=pipes.get("valu_busy_frac"), lds_busy_frac=pipes.get("lds_busy_frac"),
                   measured_valu_insts_per_eval=(pipes["SQ_INSTS_VALU_mean"] * 64.0 / (float(N) * P * k_iters / n_launch)
                                                 if "SQ_INSTS_VALU_mean" in pipes else None), pipe_source=pipes_src,
-                  limiting_pipe="LDS (table reads: 6 look-ups x 4 ds_read_b128 per wave and trial, served in groups of 16 lanes over 64 banks; bank conflicts "
-                                "on top -- eight shifted copies of the table measured 4 % slower, profiles/r04/NOTES.md)",
+                  limiting_pipe="the FP64 vector pipe (~190 vector instructions per evaluation); until round 5 the LDS pipe: with lanes = proposals "
+                                "a population that had not converged read another table row in every lane",
                   trial_proposal_evaluations_per_s=evals / t_s, launch_ms=t_s / n_launch * 1e3, launches=n_launch,
                   updates_per_launch=P * k_iters / n_launch, traffic=None, traffic_source=None, wasted_traffic_ratio=None)
     rf["timing"] = ("HIP events recorded on the timed iterations, on the stream the kernels run on" if getattr(a, "events_inline", not two_pass(a)) else

@@ -39,7 +39,7 @@ def dominant_pattern(over):
         return "k_direct_mvn"
     if cfg in ("cfg2", "cfg3"):
         return "k_res_mvn|k_propose<"  # (history partners: the lean body past burn-in, k_propose<256,false,...> inside it)
-    return {"cfg4": "k_longrow|k_frozen_sweep", "cfg5": "k_lba_loglike|k_obs_loglike", "cfg1": "k_propose<", "mvn30": "k_res_mvn|k_propose<"}[cfg]
+    return {"cfg4": "k_longrow|k_frozen_sweep", "cfg5": "k_lba_wave|k_lba_loglike|k_obs_loglike", "cfg1": "k_propose<", "mvn30": "k_res_mvn|k_propose<"}[cfg]
 
 
 MFMA_CTRS = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_F64", "SQ_INSTS_VALU_MFMA_MOPS_F64", "GRBM_GUI_ACTIVE",
