@@ -504,6 +504,21 @@ def test_lba_lnr_against_scipy_goldens(demc):
         eng.close()
 
 
+@pytest.mark.parametrize("na,N", [(2, 1500), (3, 1100), (4, 1500), (6, 700), (2, 300)])
+def test_lba_wave_kernel_every_accumulator_count(demc, orc, na, N):
+    """k_lba_wave has compiled-in instances for two and three accumulators and a general one: the log-posterior of random
+    proposals against the oracle for 2 / 3 / 4 / 6 accumulators, with whole batches + a ragged end (N = 1 500, 1 100), a ragged
+    end only (700, 300) -- the trials arrive UNSORTED and demc_set_model sorts its own copy (the sum is compared, 1e-9)"""
+    prob = make_problem("lba", np.random.default_rng(200 + na), N=N, na=na)
+    eng, o = _pair(demc, orc, prob, n_groups=2, Np=16, schedule=1)
+    th = prob["init"](32)
+    lg, lo_ = eng.logpost(th), o.logpost(th)
+    assert np.isfinite(lo_).sum() >= 24 and np.array_equal(np.isfinite(lg), np.isfinite(lo_))
+    fin = np.isfinite(lo_)
+    np.testing.assert_allclose(lg[fin], lo_[fin], rtol=1e-9)
+    eng.close()
+
+
 @pytest.mark.parametrize("kind,a,b", [(6, 2.5, 1.5), (7, 0.0, 0.7), (8, 0.3, 0.8), (9, -1.0, 2.0), (4, 2.0, 3.0), (3, 0.1, 5.0)])
 def test_prior_kinds_match_oracle_and_goldens(demc, orc, kind, a, b):
     """every registered prior (Gamma, Exponential, LogNormal, Cauchy, Beta, Uniform) on the sigma slot of the Gaussian
