@@ -59,3 +59,57 @@ def test_softplus_table_of_the_row_streaming_kernel():
     for v, want in ((np.inf, np.inf), (-np.inf, 0.0), (-1e300, 0.0)):
         got = device_form(np.array([v]))[0]
         assert got == want or abs(got - want) < 1e-300, (v, got)
+
+
+def _table(header, name):
+    txt = open(os.path.join(CSRC, header)).read()
+    ints = {k: int(v) for k, v in re.findall(r"constexpr int (k\w+) = (-?\d+);", txt)}
+    body = txt[txt.index(name + "["):]
+    body = body[body.index("{") + 1:body.index("};")]
+    vals = np.array([float(v) for v in re.findall(r"-?\d+\.?\d*(?:e[+-]?\d+)?", body)])
+    return ints, vals
+
+
+def test_phi_table_of_the_lba_kernels():
+    """phiS_Phi_table (demc_device.hpp) on the committed table (tools/gen_phi_table.py): Phi and the phi recovered from the SAME
+    coefficients as the derivative, on a dense grid of [-8.5, 8.5] and clamped beyond, against scipy to 2.5e-16 absolute"""
+    from scipy.special import ndtr
+    ints, tab = _table("demc_phi_table.hpp", "kPhiTable")
+    deg, rows, S, row = ints["kPhiDeg"], ints["kPhiIntervals"], ints["kPhiPerUnit"], ints["kPhiRow"]
+    assert tab.size == rows * row and rows == 17 * S + 1
+    tab = tab.reshape(rows, row)
+    z = np.concatenate([np.linspace(-8.5, 8.5, 400001), [-30.0, 30.0, -8.5, 8.5]])
+    zs = np.clip(z * S, -8.5 * S, 8.5 * S)
+    i = np.rint(zs + 8.5 * S).astype(np.int64)
+    u = zs - (i - 8.5 * S)
+    a = tab[i]
+    P = a[:, deg].copy()
+    dP = a[:, deg].copy()
+    P = P * u + a[:, deg - 1]
+    for k in range(deg - 2, -1, -1):
+        dP = dP * u + P
+        P = P * u + a[:, k]
+    zc = np.clip(z, -8.5, 8.5)
+    assert np.abs(P - ndtr(zc)).max() < 2.5e-16
+    assert np.abs(dP * S - np.exp(-0.5 * zc * zc) / np.sqrt(2 * np.pi)).max() < 3e-16
+
+
+def test_log_phi_table_of_the_lnr_kernel():
+    """log_Phi_neg_table (demc_device.hpp) on the committed table (tools/gen_logphi_table.py): log Phi(-z) on [-8.5, 38.5] against
+    40-digit arithmetic (scipy's log_ndtr is itself off by 1e-15 near z = 0), error relative to max(1, |g|) below 3e-16"""
+    import mpmath
+    mpmath.mp.dps = 40
+    ints, tab = _table("demc_logphi_table.hpp", "kLogPhiTable")
+    deg, rows, per, row = ints["kLogPhiDeg"], ints["kLogPhiRows"], ints["kLogPhiPerUnit"], ints["kLogPhiRow"]
+    assert tab.size == rows * row and rows == 47 * per + 1 and row == deg + 1
+    tab = tab.reshape(rows, row)
+    z = np.concatenate([np.linspace(-8.5, 38.5, 4001), np.random.default_rng(4).uniform(-8.5, 38.5, 4000)])
+    zc = np.clip(per * z, -8.5 * per, 38.5 * per)
+    i = np.rint(zc + 8.5 * per).astype(np.int64)
+    u = zc - (i - 8.5 * per)
+    a = tab[i]
+    P = a[:, deg].copy()
+    for k in range(deg - 1, -1, -1):
+        P = P * u + a[:, k]
+    g = np.array([float(mpmath.log(mpmath.ncdf(-mpmath.mpf(float(v))))) for v in z])
+    assert (np.abs(P - g) / np.maximum(1.0, np.abs(g))).max() < 3e-16
