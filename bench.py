@@ -4,9 +4,12 @@
 Metric (BASELINE.json): particle-updates/sec (proposal + loglike + accept) at D=32, N=1e5.
 Default workload (BASELINE.json configs[2], "cfg3", the configuration the metric is quoted on): Multivariate Gaussian D=32
 full-Sigma, n_groups=256, Np=256, N=1e5 observations, sampler defaults (alpha=beta=0.1, eps=1e-3, sigma=0.05, kappa=1, no
-snooker, burnin=1000), two_colour schedule, STREAMING likelihood (every proposal visits every observation, as the
-reference's loglike does).  One "step" = one DE-MCMC iteration over all P = n_groups*Np particles (migration when the alpha
-coin fires, proposal, prior+loglike, Metropolis accept, history store).
+snooker, burnin=1000), two_colour schedule, DIRECT likelihood: the residual form the reference's loglike writes
+(test/multivariate_normal_tests.jl:31-33: sum_i logpdf(MvNormal(mu, Sigma), x_i)), every proposal visits every observation term
+by term -- SURVEY 8(d)'s 3*N*D flop per particle-update on the FP64 vector pipe, the work that does not collapse.  (Rounds 1-5
+quoted the STREAMING mode here: the expanded quadratic form on the matrix cores, whose [proposals x D].[D x N] product is
+analytically zero after centring -- it stays as a labelled row.)  One "step" = one DE-MCMC iteration over all P = n_groups*Np
+particles (migration when the alpha coin fires, proposal, prior+loglike, Metropolis accept, history store).
 
 --config cfg2 | cfg4 | cfg5 run the other BASELINE configs (their own roofline definition, same JSON contract); they are
 measured rows of SURVEY 8(d), not the headline.
@@ -33,7 +36,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP64_TFLOPS = 78.6   # MI355X FP64 matrix = vector peak: 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (datasheet)
 PEAK_HBM_GBS = 8000.0     # MI355X HBM3E nominal; /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_ROUND = "r05"     # profiles/<round>/ holds the rocprofv3 PMC passes `traffic` is read from
+PROFILE_ROUND = "r06"     # profiles/<round>/ holds the rocprofv3 PMC passes `traffic` is read from
 
 
 def parse(argv=None):
@@ -42,9 +45,10 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="cfg3", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "mvn30"])
-    ap.add_argument("--mode", default="streaming", choices=["streaming", "suffstat", "direct"],
-                    help="MvNormal likelihood: streaming = expanded quadratic form on the FP64 matrix cores (headline); suffstat = "
-                         "O(D^2) per proposal; direct = the residual form sum_i |L^-1(x_i - mu)|^2 term by term on the FP64 vector pipe")
+    ap.add_argument("--mode", default="direct", choices=["streaming", "suffstat", "direct"],
+                    help="MvNormal likelihood: direct = the residual form sum_i |L^-1(x_i - mu)|^2 term by term on the FP64 vector pipe "
+                         "(headline: SURVEY 8d's 3*N*D per update, nothing collapses); streaming = expanded quadratic form on the FP64 "
+                         "matrix cores (= suffstat + a [proposals x D].[D x N] product that is zero after centring); suffstat = O(D^2) per proposal")
     ap.add_argument("--schedule", default="two_colour", choices=["two_colour", "synchronous"])
     ap.add_argument("--n-groups", type=int, default=None, help="groups per GPU (default: the config's)")
     ap.add_argument("--np", "--particles-per-group", type=int, default=None, dest="Np",
@@ -239,6 +243,63 @@ class StageWatchdog(threading.Thread):
                 os._exit(code)
 
 
+class SclkSampler(threading.Thread):
+    """What the driver says the shader clock is while the timed region runs: the starred level of the device's sysfs
+    `pp_dpm_sclk`, read every 20 ms by a host thread (no GPU call).  Context only -- under a dense loop the clock the kernel
+    really holds reads up to 10 % below it (MI355X_MICROARCH.md, DVFS give-back): the in-kernel figure is
+    roofline.shader_clock_mhz (demc_timing_clock).  None when the file is not there or not readable."""
+
+    def __init__(self, device_index):
+        super().__init__(daemon=True)
+        self.path, self.samples, self.halt = None, [], threading.Event()
+        try:
+            import glob
+            import torch
+            bus = None
+            try:
+                bus = torch.cuda.get_device_properties(device_index).pci_bus_id  # (torch >= 2.5)
+            except Exception:
+                pass
+            cands = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+            if bus is not None:
+                def bus_of(c):  # .../0000:05:00.0 -> 5
+                    try:
+                        return int(os.path.basename(os.path.realpath(os.path.dirname(c))).split(":")[1], 16)
+                    except (IndexError, ValueError):
+                        return None
+                hit = [c for c in cands if bus_of(c) == int(bus)]
+                cands = hit or cands
+            if len(cands) == 1 or (cands and bus is not None):
+                self.path = cands[0]
+        except Exception:
+            self.path = None
+
+    def read_once(self):
+        try:
+            for ln in open(self.path).read().splitlines():
+                if ln.rstrip().endswith("*"):
+                    return float(ln.split(":")[1].strip().split("M")[0])
+        except (OSError, ValueError, IndexError, TypeError):
+            pass
+        return None
+
+    def run(self):
+        while self.path and not self.halt.is_set():
+            v = self.read_once()
+            if v is not None:
+                self.samples.append(v)
+            self.halt.wait(0.02)
+
+    def result(self):
+        self.halt.set()
+        if self.is_alive():
+            self.join(1.0)
+        if not self.samples:
+            return None
+        xs = sorted(self.samples)
+        return dict(median=xs[len(xs) // 2], min=xs[0], max=xs[-1], samples=len(xs), source=self.path)
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # workloads and their rooflines
 # ----------------------------------------------------------------------------------------------------------------
@@ -396,6 +457,11 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
             # operands of one launch: X once per colour phase + the proposals' y rows
             alg_bytes = (8.0 * N * d * phases + P * 8.0 * d) * k_iters / n_launch
             rf = dict(bound="mfma", kernel=kern, achieved=ach, peak=PEAK_FP64_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP64_TFLOPS,
+                      # `frac` = frac_executed: the MFMA flop the kernel really issues.  frac_survey prices SURVEY 8d's unit (3ND + 2D^2
+                      # per update) over the same time: ABOVE 1, because this mode does not do the survey's per-pair work -- its
+                      # [proposals x D].[D x N] product is analytically zero after centring (what_is_streamed)
+                      frac_executed=ach / PEAK_FP64_TFLOPS, frac_survey=survey / t_s / 1e12 / PEAK_FP64_TFLOPS,
+                      label="SUFFSTAT + a null GEMM: not the reference's per-pair work (that is --mode direct, the headline)",
                       flop_counted="executed 2*N*D per particle-update (every proposal x observation pair on the matrix cores)",
                       what_is_streamed="the cross term sum_i y.x~_i of the EXPANDED quadratic form, y = Sigma^-1 (theta' - xbar), x~_i = x_i - xbar. "
                                        "After centring it equals y.(sum_i x~_i), i.e. rounding noise around zero: STREAMING = SUFFSTAT + this "
@@ -411,14 +477,38 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
             t_s = tm["loglike"]["ms"] * 1e-3
             n_launch = max(1, tm["loglike"]["launches"])
             dp = 8 if d <= 8 else 16 if d <= 16 else 32 if d <= 32 else 64
-            executed = 3.0 * N * dp * P * k_iters   # per (proposal, observation, padded dimension): one add, one fma
-            ach = executed / t_s / 1e12
+            # SURVEY 8(d)'s unit: 3*N*D per (proposal, observation, dimension) -- one subtraction, one fused multiply-add -- and 2*D^2
+            # for m = L^-1 mu~ (K1's preparation on the matrix cores: it runs in k_propose, outside this kernel's time, and is 0.02 %
+            # of the count).  `frac` prices the flop of THIS kernel over THIS kernel's device time: 3*N*d, d the data dimension
+            # (the kernel also runs the zero-padded dimensions up to dp; they are not counted).
+            survey = 3.0 * N * d * P * k_iters
+            ach = survey / t_s / 1e12
+            clk = getattr(a, "clock", None) or {}
+            mhz = clk.get("mhz_median")
+            traffic, src = measured_traffic(a, n_launch, k_iters)
+            # what one launch must read and write: the whitened rows once (they are shared by every proposal: L2 / MALL serve the re-reads),
+            # the proposals' m rows, the per-chunk partial sums
+            n_chunks = (clk.get("workgroups") or 0) / max(1.0, (P / phases + 255) // 256)
+            alg_bytes = 8.0 * N * dp + (P / phases) * 8.0 * dp + (P / phases) * 8.0 * max(1.0, n_chunks)
             rf = dict(bound="valu", kernel=f"k_direct_mvn<{dp}> (thread per proposal, m = L^-1 mu~ in registers, wave-uniform z rows)",
                       achieved=ach, peak=PEAK_FP64_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP64_TFLOPS,
                       flop_counted="3*N*D per particle-update (SURVEY 8d's whitened residual form: v_add_f64 + v_fma_f64 per dimension; "
-                                   "an add counts one flop, so 0.75 of the FMA peak is this form's ceiling)",
+                                   "an add counts one flop, so 0.75 of the FMA peak is this form's ceiling at the nominal clock)",
+                      survey_tflops_whole_step=(3.0 * N * d + 2.0 * d * d) * P * k_iters / (dt_per_iter * k_iters) / 1e12,
+                      # the clock the vector pipe held under this kernel (s_memtime / s_memrealtime stamped by every workgroup of the last
+                      # timed launch: demc_timing_clock): the peak above is quoted at 2400 MHz, the chip holds less under a dense FP64
+                      # loop and devices differ (MI355X_MICROARCH.md, DVFS give-back) -- this is what moves `frac` between boxes
+                      shader_clock_mhz=mhz, shader_clock_mhz_min=clk.get("mhz_min"), shader_clock_mhz_max=clk.get("mhz_max"),
+                      peak_at_clock=None if not mhz else PEAK_FP64_TFLOPS * mhz / 2400.0,
+                      frac_at_clock=None if not mhz else ach / (PEAK_FP64_TFLOPS * mhz / 2400.0),
+                      mix_ceiling_at_clock=None if not mhz else 0.75 * mhz / 2400.0,
+                      frac_of_mix_ceiling_at_clock=None if not mhz else ach / (0.75 * PEAK_FP64_TFLOPS * mhz / 2400.0),
+                      sclk_sysfs_mhz=getattr(a, "sclk_sysfs", None),
                       launch_ms=t_s / n_launch * 1e3, launches=n_launch, updates_per_launch=P * k_iters / n_launch,
-                      traffic=None, traffic_source=None, wasted_traffic_ratio=None)
+                      traffic=traffic, traffic_source=src,
+                      wasted_traffic_ratio=None if (traffic is None or not n_chunks) else traffic / alg_bytes,
+                      traffic_note="a VALU-bound kernel: the z rows (25.6 MB at cfg3) are re-read by every block of 256 proposals and served "
+                                   "by L2 / MALL; what reaches HBM is the counters' figure, far from the 8 TB/s roof")
         else:
             t_s = fused_ms * 1e-3
             n_launch = max(1, tm["propose"]["launches"])
@@ -600,16 +690,16 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
 def accuracy_leg(a, w, demc_amd, local, rng):
     """posterior-mean L1 against the closed-form conjugate posterior (MvNormal configs), from an UNTIMED run that does not
     depend on --steps: the same sampler configuration run past the reference's burn-in BY THE KERNELS THAT WERE TIMED
-    (round 4: the leg runs in the likelihood mode of the timed region -- 1500 STREAMING iterations of the headline are
-    8 s; rounds 1-3 ran it in SUFFSTAT mode, which makes the same decisions at 1/150 of the cost, and that is still what a
-    `--mode direct` run does).  The ensemble of all particles is averaged over the last iterations."""
+    (the leg runs in the likelihood mode of the timed region: 1500 DIRECT iterations of the headline are ~21 s; rounds 1-3 ran it
+    in SUFFSTAT mode, which makes the same decisions at a fraction of the cost).  The ensemble of all particles is averaged over the
+    last iterations."""
     if a.accuracy_iters <= 0 or "posterior_mean" not in w:
         return None
     from demc_amd import workloads as W
     G, Np, D = w["G"], w["Np"], w["D"]
     P = G * Np
     n_it = max(a.accuracy_iters, a.burnin + 200)
-    leg_mode = a.mode if a.mode in ("streaming", "suffstat") else "suffstat"
+    leg_mode = a.mode
     eng = demc_amd.HipEngine(n_groups=G, Np=Np, D=D, n_rows=0, store_history=0, schedule=2 if a.schedule == "two_colour" else 1,
                              seed=20260001, device_id=local, burnin=a.burnin, loglike_mode=MODES[leg_mode], trace=0, **w["engine"])
     W.configure(eng, w)
@@ -666,7 +756,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(a, w, seconds_target=14.0):
+def cpu_baseline(a, w, seconds_target=14.0, seconds_single=3.0):
     """oracle source built -O3 -march=native -fopenmp on this host, reference schedule (sequential in-place sweep per group,
     one group per OpenMP thread like p_update!, src/main.jl:135-148) on a bounded sample of the same workload: timed on
     ONE thread and on all the cores this process may use."""
@@ -676,6 +766,7 @@ def cpu_baseline(a, w, seconds_target=14.0):
     O.use_native_build()
     cores = usable_cores()
     Np, D = w["Np"], w["D"]
+    n_sweeps = 1 if w["masks"] is None else len(w["masks"])
     rng = np.random.default_rng(1234)
 
     def run(n_groups, threads, seconds):
@@ -691,9 +782,9 @@ def cpu_baseline(a, w, seconds_target=14.0):
         o.step(2, iters)
         dt = time.time() - t0
         o.close()
-        return n_groups * Np * iters / dt, iters
+        return n_groups * Np * n_sweeps * iters / dt, iters  # (like `value`: every block sweep updates every particle once)
 
-    one_thread, it1 = run(1, 1, 3.0)
+    one_thread, it1 = run(1, 1, seconds_single)
     ng = max(2, min(cores, 4 * w["G"]))
     value, iters = run(ng, cores, seconds_target)
     cpu_model, host_cores = "unknown", os.cpu_count()
@@ -722,19 +813,20 @@ def control_plane_store(rank, world, timeout_s=120.0):
                     timeout=timedelta(seconds=timeout_s))
 
 
-def exchange_comm_id(store, rank, make_id):
-    """rank 0 draws the id (make_id() -> 128 bytes, demc_comm_unique_id) and publishes it; everybody reads it back"""
-    key = "demc/comm_id/" + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+def exchange_comm_id(store, rank, make_id, tag=""):
+    """rank 0 draws the id (make_id() -> 128 bytes, demc_comm_unique_id) and publishes it; everybody reads it back
+    (`tag`: one key per communicator -- the sharded rows create their own)"""
+    key = "demc/comm_id/" + tag + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
     if rank == 0:
         store.set(key, make_id())
     return bytes(store.get(key))
 
 
-def agree_on_init(store, rank, world, error):
+def agree_on_init(store, rank, world, error, tag=""):
     """every rank posts how its communicator creation ended and reads everybody's: None if all succeeded, else the first
     failure's text -- so that a CLEAN failure (an error code, not a hang: those are the watchdog's) takes every rank down
     the same road"""
-    key = "demc/init/" + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0") + "/"
+    key = "demc/init/" + tag + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0") + "/"
     store.set(key + str(rank), b"ok" if error is None else ("rank %d: %s" % (rank, error)).encode()[:400])
     states = [bytes(store.get(key + str(r))).decode("utf-8", "replace") for r in range(world)]
     bad = [x for x in states if x != "ok"]
@@ -764,7 +856,7 @@ def start_rows(a, w, P, rng):
 
 def is_plain_headline(a):
     """the command the driver runs: BASELINE's headline workload with nothing overridden"""
-    return (a.config == "cfg3" and a.mode == "streaming" and a.partners == "current" and a.start == "prior" and
+    return (a.config == "cfg3" and a.mode == "direct" and a.partners == "current" and a.start == "prior" and
             a.n_groups is None and a.Np is None and a.nobs is None and a.dim is None and a.snooker is None and not a.fuse)
 
 
@@ -788,7 +880,7 @@ def make_engine(a, w, demc_amd, local, rank=0, world=1, seed=20260001):
     cfg = dict(n_groups=G, Np=Np, D=D, n_rows=n_rows, n_initial=a.n_initial,
                schedule=1 if (hist or a.schedule == "synchronous") else 2, partner_kind=1 if hist else 0,
                group_offset=rank * G, n_groups_total=G * world, seed=seed, device_id=local, burnin=a.burnin,
-               loglike_mode=MODES[a.mode], trace=0, fuse=a.fuse)
+               loglike_mode=MODES[a.mode] if a.config in ("cfg2", "cfg3", "mvn30") else 0, trace=0, fuse=a.fuse)
     cfg.update(w["engine"])
     eng = demc_amd.HipEngine(**cfg)
     from demc_amd import workloads as W
@@ -823,6 +915,7 @@ def measure_row(name, a, w, demc_amd, local):
         dt_ = time.perf_counter() - t0
         tm_ = e.timing_read() if instrument else None
         if instrument:
+            a.clock = e.timing_clock()  # (DIRECT rows: the clock the likelihood kernel held; None otherwise)
             e.timing_enable(False)
         return e, dt_, tm_
 
@@ -840,7 +933,8 @@ def measure_row(name, a, w, demc_amd, local):
     eng.close()
     sweeps = 1 if w["masks"] is None else len(w["masks"])
     rf = roofline_of(a, w, tm, a.steps, P, dt / a.steps)
-    keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "launch_ms", "launches", "traffic", "traffic_source",
+    keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_executed", "frac_survey", "label", "shader_clock_mhz",
+            "frac_at_clock", "launch_ms", "launches", "traffic", "traffic_source",
             "wasted_traffic_ratio", "flop_counted", "bytes_counted", "counter_frac", "necessary_frac", "survey_formula_frac",
             "valu_busy_frac", "lds_busy_frac", "device_ms_per_iter", "gather_bytes_per_update", "fetch_bytes_per_update", "shape_frac",
             "shape_roof_launch_ms", "shape_roof_source", "necessary_gbs")
@@ -855,7 +949,10 @@ def measure_row(name, a, w, demc_amd, local):
 # The other rows of SURVEY 8(d), as flag sets of this same program (tools/collect_profiles.py profiles exactly these commands
 # and writes profiles/<round>/bench_<name>_line.json from them).  Steps are chosen so that every row takes a second or two.
 ROWS = [
-    ("cfg3_direct", dict(config="cfg3", mode="direct", steps=20, warmup=5)),
+    # the expanded quadratic form on the matrix cores: SUFFSTAT + a [proposals x D].[D x N] product that is zero after centring (the
+    # headline of rounds 1-5; `frac_executed` prices the MFMA flop it executes, `frac_survey` SURVEY 8d's unit -- above 1, which is
+    # what "the kernel is not doing the survey's work" looks like)
+    ("cfg3_streaming", dict(config="cfg3", mode="streaming", steps=20, warmup=5)),
     ("cfg3_streaming_post_burnin", dict(config="cfg3", mode="streaming", burnin=0, steps=20, warmup=5)),
     ("cfg3_suffstat", dict(config="cfg3", mode="suffstat", steps=400, warmup=50)),
     ("cfg3_suffstat_post_burnin", dict(config="cfg3", mode="suffstat", burnin=0, steps=400, warmup=50)),
@@ -888,8 +985,10 @@ ROWS = [
 ]
 
 
+CPU_ROWS = ("cfg4_share", "cfg5_share")  # rows that also carry a cpu_baseline leg (one GPU's share of BASELINE's 8-GPU configs)
+
 # what identifies a workload (steps / warm-up do not)
-ROW_DEFAULTS = dict(config="cfg3", mode="streaming", schedule="two_colour", n_groups=None, Np=None, nobs=None, dim=None,
+ROW_DEFAULTS = dict(config="cfg3", mode="direct", schedule="two_colour", n_groups=None, Np=None, nobs=None, dim=None,
                     burnin=1000, snooker=None, fuse=0, partners="current", n_initial=0, start="prior")
 
 
@@ -920,7 +1019,7 @@ def dict_args(a, **over):
 
 def run_rows(a, w_headline, demc_amd, local, budget_s=120.0):
     want = None if a.rows in (None, "all") else set(a.rows.split(","))
-    rows, t0 = [], time.perf_counter()
+    rows, t0, cpu_todo = [], time.perf_counter(), []
     # the headline's workload is reused only when it IS the plain one: sampler flags (--snooker ...) ride in w["engine"], and a
     # row that inherited them would be labelled and profile-tagged as the plain row while running another kernel
     cache = {("cfg3", None): w_headline} if is_plain_headline(a) else {}
@@ -941,9 +1040,122 @@ def run_rows(a, w_headline, demc_amd, local, budget_s=120.0):
             elif b.config in ("cfg2", "cfg3"):  # (cfg5's own theta_snooker = 0.1 is its workload's; the MvNormal rows' default is 0)
                 assert not wl["engine"].get("theta_snooker"), (name, wl["engine"])
             rows.append(measure_row(name, b, wl, demc_amd, local))
+            if name in CPU_ROWS and not a.no_cpu_baseline:
+                cpu_todo.append((rows[-1], b, wl))
         except Exception as e:  # a row that fails is reported as failed; the headline stands
             rows.append(dict(name=name, error=f"{type(e).__name__}: {e}"[:500]))
+    # the CPU figure of BASELINE's other configs (the reference's CPU path timed beside the GPU's): the oracle in
+    # the reference's schedule on this row's workload, time-boxed, after every GPU row has been measured
+    for row, b, wl in cpu_todo:
+        try:
+            row["cpu_baseline"] = cpu_baseline(b, wl, seconds_target=5.0, seconds_single=2.0)
+            row["gpu_over_cpu"] = row["value"] / row["cpu_baseline"]["value"]
+        except Exception as e:
+            row["cpu_baseline"] = dict(error=f"{type(e).__name__}: {e}"[:300])
     return rows
+
+
+# BASELINE.json's configs that are DEFINED as 8-GPU runs, measured in the N > 1 line as SHARDED rows: the config's whole
+# population partitioned over the ranks (strong partition: 128 / 512 groups in total whatever N is; p_update!'s groups side by
+# side, main.jl:135-148), migration! across the ranks as ONE all-gather per migration event (migration.jl:11-19) on the row
+# engine's own communicator behind the C-ABI -- or torch.distributed's when the run fell back to it.
+SHARDED_ROWS = [
+    ("cfg4_sharded", dict(config="cfg4", total_groups=128, steps=40, warmup=10)),  # hierarchical Binomial, Np 32, blocks [hyper; subject]
+    ("cfg5_sharded", dict(config="cfg5", total_groups=512, steps=40, warmup=10)),  # LBA, Np 128, theta_snooker 0.1
+]
+
+
+def run_sharded_rows(a, demc_amd, local, rank, world, store, dist, barrier, reduce, stage, fallback):
+    """After the headline's timed region (its engine and communicator still alive: `barrier` / `reduce` run on them), every
+    rank builds its share of each config, creates the row's communicator (id through the launcher's store, agreed on like the
+    headline's), and times K steps between two barriers; the line takes the MAX over the ranks.  A row that cannot be built
+    on some rank is skipped by ALL ranks (agreed before the first collective); a rank's numbers are on disk
+    (gpurun_out/rank<r>.json, `rows`) before the reduction that follows its timed region."""
+    import torch
+    rows, mine = [], []
+    for name, spec in SHARDED_ROWS:
+        t_wall = time.perf_counter()
+        stage("row " + name, 150.0)
+        total = spec["total_groups"]
+        if total % world:
+            rows.append(dict(name=name, skipped=f"{total} groups do not divide over {world} ranks"))
+            continue
+        b = row_args(a, name, dict(config=spec["config"], n_groups=total // world, steps=spec["steps"], warmup=spec["warmup"]))
+        b.rows, b.no_roofline = "none", True
+        eng = drv = None
+        err = None
+        lib_row = store is not None and dist is None
+        try:
+            w = build_workload(b)
+            eng = make_engine(b, w, demc_amd, local, rank, world)
+            if lib_row:
+                eng.comm_init(exchange_comm_id(store, rank, eng.comm_unique_id, tag=name + "/"), rank, world)
+                eng.comm_set_overlap(a.async_migration)
+                step = eng.step_enqueue
+            else:
+                from demc_amd.distributed import ShardedDriver
+                drv = ShardedDriver(eng, dist, torch.device("cuda", local), stream_ordered=True, async_migration=a.async_migration)
+                step = drv.step
+        except Exception as e:
+            err = f"{type(e).__name__}: {e}"
+        if store is not None:
+            bad = agree_on_init(store, rank, world, err, tag=name + "/")
+        else:  # (--collective torch from the start: no store of ours; a sum of failure flags over the process group)
+            n_bad = reduce([0.0 if err is None else 1.0], "sum")[0]
+            bad = None if n_bad == 0.0 else (err or "another rank failed to build the row")
+        if bad is not None:
+            if eng is not None:
+                eng.close()
+            rows.append(dict(name=name, error=short(bad, 300)))
+            continue
+        P = w["G"] * w["Np"]
+        sweeps = 1 if w["masks"] is None else len(w["masks"])
+        it0 = 1 + b.n_initial
+        step(it0, b.warmup)
+        eng.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        step(it0 + b.warmup, b.steps)
+        eng.synchronize()
+        barrier()
+        dt_own = time.perf_counter() - t0
+        cstats = eng.comm_stats() if lib_row else None
+        n_gathers = cstats["exchanges"] if lib_row else drv.n_exchanges
+        mine.append(dict(name=name, config=spec["config"], steps=b.steps, warmup=b.warmup, seconds_timed=dt_own, particles=P,
+                         block_sweeps_per_step=sweeps, all_gathers=n_gathers, groups=w["G"],
+                         rccl_nranks=None if cstats is None else cstats["world"]))
+        try:  # this rank's numbers on disk BEFORE the next collective (merge_rank_files reads `rows` too)
+            rec = json.load(open(rank_file(rank)))
+            rec["rows"] = mine
+            write_rank_file(rank, rec)
+        except (OSError, ValueError):
+            pass
+        dt = reduce([dt_own], "max")[0]
+        dt_min = reduce([dt_own], "min")[0]
+        gathers = [int(x) for x in reduce([n_gathers if r == rank else 0 for r in range(world)], "sum")]
+        finite = True
+        if rank == 0:
+            import numpy as np
+            finite = bool(np.isfinite(eng.get_state()[1]).all())
+        kernels = eng.last_kernels()
+        if lib_row:
+            eng.comm_destroy()
+        eng.close()
+        value = P * world * sweeps * b.steps / dt
+        rows.append(dict(name=name, workload=describe(b, w, world), value=value, unit="particle-updates/s", scaling="strong",
+                         particle_parameter_updates_per_s=value * w["D"], ms_per_step=dt / b.steps * 1e3,
+                         ms_per_step_min_over_ranks=dt_min / b.steps * 1e3, steps=b.steps, warmup=b.warmup, n_gpus=world,
+                         groups_total=total, groups_per_rank=w["G"], particles_per_gpu=P, block_sweeps_per_step=sweeps,
+                         all_gathers_per_rank=gathers, rccl_nranks=None if cstats is None else cstats["world"],
+                         collective="library" if lib_row else "torch", collective_fallback=fallback, kernels=kernels,
+                         finite_weights=finite, seconds=time.perf_counter() - t_wall))
+    return rows
+
+
+def compact_sharded_row(r):
+    if "value" not in r:
+        return {k: (short(v, 80) if isinstance(v, str) else v) for k, v in r.items() if k in ("name", "skipped", "error")}
+    return sig({k: r[k] for k in ("name", "value", "ms_per_step", "steps", "n_gpus", "groups_per_rank", "all_gathers_per_rank", "rccl_nranks")})
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -984,6 +1196,10 @@ def compact_row(r):
         c["counter_frac"] = rf["counter_frac"]
     if rf.get("shape_frac") is not None:  # (cfg4: against what a bare kernel of this traffic shape reaches)
         c["shape_frac"] = rf["shape_frac"]
+    if (r.get("cpu_baseline") or {}).get("value") is not None:  # (rows with a CPU leg: the oracle on all cores / on one thread)
+        c["cpu"], c["cpu_1thread"] = r["cpu_baseline"]["value"], r["cpu_baseline"].get("value_single_thread")
+    if rf.get("frac_survey") is not None:  # (STREAMING rows: the executed MFMA flop and SURVEY 8d's unit side by side -- the latter > 1)
+        c["frac_executed"], c["frac_survey"] = rf.get("frac_executed"), rf["frac_survey"]
     return sig(c)
 
 
@@ -1004,12 +1220,15 @@ def compact_line(out):
                             accept_rate=(acc.get("timed_chain") or {}).get("accept_rate"))
     line["roofline"] = None if rf is None else dict(
         {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "launch_ms", "launches", "traffic", "wasted_traffic_ratio",
-                                "device_ms_per_iter", "counter_frac")}, kernel=short(rf.get("kernel"), 60))
+                                "device_ms_per_iter", "counter_frac", "shader_clock_mhz", "frac_at_clock", "frac_of_mix_ceiling_at_clock")},
+        kernel=short(rf.get("kernel"), 60), sclk_sysfs_mhz=(rf.get("sclk_sysfs_mhz") or {}).get("median"))
     line["cpu_baseline"] = None if cpu is None else dict(
         {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "value_single_thread", "cpu_model")}, sample=short(cpu.get("sample"), 160))
-    line["headline_context"] = None if ctx is None else {k: ctx.get(k) for k in ("direct_value", "direct_frac", "cpu_baseline_like_for_like_ratio")}
+    line["headline_context"] = None if ctx is None else {k: ctx.get(k) for k in ("streaming_value", "streaming_frac_executed", "streaming_frac_survey",
+                                                                                 "suffstat_value", "cpu_baseline_like_for_like_ratio")}
     rows = out.get("rows")
-    line["rows"] = None if rows is None else [compact_row(r) for r in rows]
+    line["rows"] = None if rows is None else [compact_sharded_row(r) if (r.get("scaling") == "strong" or "n_gpus" in r) else compact_row(r)
+                                              for r in rows]
     line["detail"] = DETAIL_FILE
     line = sig(line)
     text = json.dumps(line, separators=(",", ":"))
@@ -1059,6 +1278,18 @@ def merge_rank_files(recs, why):
                       "ms_per_step_min_over_ranks": min(r["ms_per_step"] for r in recs),
                       "ms_per_step_max_over_ranks": max(r["ms_per_step"] for r in recs)},
            "roofline": None, "cpu_baseline": None, "rows": None}
+    names = [r["name"] for r in recs[0].get("rows") or []]
+    merged = []
+    for i, nm in enumerate(names):  # the sharded rows every rank got through (each rank's own K-step time, MAX over the ranks)
+        per = [(r.get("rows") or [])[i] if len(r.get("rows") or []) > i and r["rows"][i]["name"] == nm else None for r in recs]
+        if any(x is None for x in per):
+            break
+        dt_r = max(x["seconds_timed"] for x in per)
+        merged.append(compact_sharded_row(dict(name=nm, value=sum(x["particles"] * x["block_sweeps_per_step"] for x in per) * per[0]["steps"] / dt_r,
+                                               ms_per_step=dt_r / per[0]["steps"] * 1e3, steps=per[0]["steps"], n_gpus=world,
+                                               groups_per_rank=per[0]["groups"], all_gathers_per_rank=[x["all_gathers"] for x in per],
+                                               rccl_nranks=per[0]["rccl_nranks"])))
+    out["rows"] = merged or None
     text = json.dumps(sig(out), separators=(",", ":"))
     assert len(text) <= LINE_LIMIT
     return text
@@ -1172,10 +1403,14 @@ def main():
     if not a.no_roofline and not split:
         eng.timing_enable(True)  # HIP events on the handle's stream around every launch of the timed iterations
     stage("timed", max(120.0, a.deadline / 3))
+    sclk = SclkSampler(local)
+    sclk.start()
     t0 = time.perf_counter()
     step(it0 + a.warmup, a.steps)
     sync()
     dt_own = time.perf_counter() - t0
+    a.sclk_sysfs = sclk.result()
+    a.clock = None
     tm = None
     if split and not multi:  # (two_pass: the same K steps of the same chain on a fresh engine, with the events on)
         eng_p = make_engine(a, w, demc_amd, local, rank, world)
@@ -1186,6 +1421,7 @@ def main():
         eng_p.synchronize()
         torch.cuda.synchronize()
         tm = eng_p.timing_read()
+        a.clock = eng_p.timing_clock()
         eng_p.close()
     elif split:  # (several ranks: the K steps again on the same engines; not part of the timed region)
         stage("profiled", max(120.0, a.deadline / 3))
@@ -1193,9 +1429,11 @@ def main():
         step(it0 + a.warmup + a.steps, a.steps)
         sync()
         tm = eng.timing_read()
+        a.clock = eng.timing_clock()
         eng.timing_enable(False)
     elif not a.no_roofline:
         tm = eng.timing_read()
+        a.clock = eng.timing_clock()
         eng.timing_enable(False)
     cstats = eng.comm_stats() if library else None
     n_gathers = cstats["exchanges"] if library else (drv.n_exchanges if multi else 0)
@@ -1230,6 +1468,9 @@ def main():
     if tm is not None:
         roofline = roofline_of(a, w, tm, a.steps, P, dt / a.steps)
     kernels_ran = eng.last_kernels() if rank == 0 else None  # (demc_last_kernels: the instances the last step launched)
+    sharded = None
+    if multi and a.rows != "none" and is_plain_headline(a):  # BASELINE's 8-GPU configs, partitioned over the ranks of this run
+        sharded = run_sharded_rows(a, demc_amd, local, rank, world, store, dist, sync, reduce, stage, fallback)
     stage("teardown", 120.0)
     if library:
         eng.comm_allreduce([])  # nobody leaves (and rank 0 keeps the store up) before everybody has finished
@@ -1243,7 +1484,7 @@ def main():
         accuracy = dict(timed_chain=timed_chain)
         if acc is not None:
             accuracy.update(acc)
-        rows = None
+        rows = sharded
         plain_headline = is_plain_headline(a)
         if world == 1 and not multi and a.rows != "none" and (a.rows is not None or plain_headline) and not a.no_roofline:
             rows = run_rows(a, w, demc_amd, local)
@@ -1253,14 +1494,17 @@ def main():
         context = None
         if rows:
             byname = {r["name"]: r for r in rows if "value" in r}
-            d = byname.get("cfg3_direct")
-            if d is not None and a.config == "cfg3":
-                context = dict(direct_value=d["value"], direct_frac=d["roofline"].get("frac"),
-                               direct_particle_parameter_updates_per_s=d["value"] * D,
-                               cpu_baseline_like_for_like_ratio=None if cpu is None else d["value"] / cpu["value"],
-                               note="the headline's STREAMING cross term collapses analytically after centring (roofline.what_is_streamed); the "
-                                    "per-pair work that does not is DIRECT -- and it is what cpu_baseline (the residual form on the host) does, "
-                                    "so DIRECT / cpu_baseline is the like-for-like ratio")
+            st, su = byname.get("cfg3_streaming"), byname.get("cfg3_suffstat")
+            if a.config == "cfg3" and (st is not None or su is not None):
+                context = dict(streaming_value=None if st is None else st["value"],
+                               streaming_frac_executed=None if st is None else st["roofline"].get("frac_executed"),
+                               streaming_frac_survey=None if st is None else st["roofline"].get("frac_survey"),
+                               suffstat_value=None if su is None else su["value"],
+                               cpu_baseline_like_for_like_ratio=None if cpu is None else value / cpu["value"],
+                               note="the headline is DIRECT: the residual form term by term, SURVEY 8d's 3ND per update -- and what cpu_baseline "
+                                    "(the oracle's whitened residual form on the host) does, so value / cpu_baseline is like for like.  "
+                                    "STREAMING (the headline of rounds 1-5) = SUFFSTAT + a [proposals x D].[D x N] matrix-core product that is "
+                                    "analytically zero after centring: same accept decisions, frac_survey above 1 says it is not the survey's work")
         out = {
             "metric": "particle-updates/sec (proposal+loglike+accept) at D=32, N=1e5" if a.config == "cfg3" else
                       f"particle-updates/sec (proposal+loglike+accept), {a.config}",

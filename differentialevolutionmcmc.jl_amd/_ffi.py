@@ -20,7 +20,7 @@ EXPORTS = [
     "demc_set_history_rows", "demc_get_history", "demc_export_chains", "demc_step", "demc_update", "demc_migration_due",
     "demc_migration_pack", "demc_migration_apply", "demc_migration_pack_async", "demc_migration_apply_async", "demc_migration_groups",
     "demc_update_groups_async", "demc_apply_migration", "demc_get_weights", "demc_logpost",
-    "demc_get_trace", "demc_set_replay", "demc_timing_enable", "demc_timing_read",
+    "demc_get_trace", "demc_set_replay", "demc_timing_enable", "demc_timing_read", "demc_timing_clock",
     "demc_step_async", "demc_synchronize", "demc_last_kernels", "demc_set_model_source_row",
     "demc_comm_unique_id", "demc_comm_init", "demc_comm_destroy", "demc_comm_set_overlap", "demc_migration_exchange",
     "demc_migration_exchange_async", "demc_comm_allreduce", "demc_comm_stats",
@@ -153,6 +153,7 @@ def load():
     L.demc_set_replay.argtypes = [H, C.POINTER(DemcReplay)]
     L.demc_timing_enable.argtypes = [H, C.c_int32]
     L.demc_timing_read.argtypes = [H, _dp, C.c_int32]
+    L.demc_timing_clock.argtypes = [H, _dp]
     L.demc_step_async.argtypes = [H, C.c_int64, C.c_int32]
     L.demc_synchronize.argtypes = [H]
     L.demc_last_kernels.argtypes = [H, C.c_char_p, C.c_int32]
@@ -447,6 +448,15 @@ class HipEngine:
         self._ck(self.L.demc_timing_read(self.h, _d(out), 1 if reset else 0))
         names = ("propose", "loglike_prep", "loglike", "accept_store", "migration")
         return {n: dict(ms=out[i], launches=int(out[5 + i])) for i, n in enumerate(names)}
+
+    def timing_clock(self):
+        """shader clock (MHz) the DIRECT MvNormal likelihood kernel held in its last launch with timing enabled: median / min /
+        max over its workgroups (each stamps s_memtime against the 100 MHz s_memrealtime); None if no such launch ran"""
+        out = np.zeros(4)
+        self._ck(self.L.demc_timing_clock(self.h, _d(out)))
+        if out[3] == 0:
+            return None
+        return dict(mhz_median=float(out[0]), mhz_min=float(out[1]), mhz_max=float(out[2]), workgroups=int(out[3]))
 
 
 class MultiEngine:

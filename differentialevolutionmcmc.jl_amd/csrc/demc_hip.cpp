@@ -15,6 +15,7 @@
 #include <hip/hiprtc.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -174,6 +175,9 @@ struct demc_handle {
     std::vector<hipEvent_t> event_pool;  // recycled events: a timed launch costs two hipEventRecord, no create/destroy
     double t_ms[5] = {0, 0, 0, 0, 0};
     long long t_n[5] = {0, 0, 0, 0, 0};
+    // clock probe of the DIRECT likelihood kernel (demc_timing_clock): per workgroup {s_memtime ticks, s_memrealtime ticks}
+    unsigned long long* clk_dev = nullptr;
+    size_t clk_cap = 0, clk_n = 0;  // workgroups the buffer holds / the last timed launch wrote
 };
 
 namespace {
@@ -466,13 +470,25 @@ int launch_loglike(demc_handle* h, KParams& k) {
                 }
                 const int n_chunks = chunks_filling_rounds(blocks, cap, (double)h->direct_wgs_per_cu * h->n_cus);
                 h->last.k2 = 5; h->last.ks = h->dp_direct;
+                // timing on: every workgroup also leaves its shader-clock / reference-clock ticks (demc_timing_clock)
+                unsigned long long* clk = nullptr;
+                if (h->timing) {
+                    const size_t wgs = (size_t)blocks * (size_t)n_chunks;
+                    if (wgs > h->clk_cap) {
+                        if (h->clk_dev) { HIPCHK(hipStreamSynchronize(h->stream)); hipFree(h->clk_dev); h->clk_dev = nullptr; h->clk_cap = 0; }
+                        ALLOC(h->clk_dev, 2 * wgs);
+                        h->clk_cap = wgs;
+                    }
+                    clk = h->clk_dev;
+                    h->clk_n = wgs;
+                }
                 tick(h, 2, true);
                 const dim3 grid((unsigned)blocks, (unsigned)n_chunks);
                 switch (h->dp_direct) {
-                    case 8: LAUNCH_T(h, k_direct_mvn<8>, grid, dim3(256), 0, k, n_chunks); break;
-                    case 16: LAUNCH_T(h, k_direct_mvn<16>, grid, dim3(256), 0, k, n_chunks); break;
-                    case 32: LAUNCH_T(h, k_direct_mvn<32>, grid, dim3(256), 0, k, n_chunks); break;
-                    default: LAUNCH_T(h, k_direct_mvn<64>, grid, dim3(256), 0, k, n_chunks); break;
+                    case 8: LAUNCH_T(h, k_direct_mvn<8>, grid, dim3(256), 0, k, n_chunks, clk); break;
+                    case 16: LAUNCH_T(h, k_direct_mvn<16>, grid, dim3(256), 0, k, n_chunks, clk); break;
+                    case 32: LAUNCH_T(h, k_direct_mvn<32>, grid, dim3(256), 0, k, n_chunks, clk); break;
+                    default: LAUNCH_T(h, k_direct_mvn<64>, grid, dim3(256), 0, k, n_chunks, clk); break;
                 }
                 tick(h, 2, false);
                 k.n_partials = n_chunks;
@@ -1567,6 +1583,7 @@ int32_t demc_destroy(demc_handle* h) {
     if (h->frozen_order_d) hipFree(h->frozen_order_d);
     if (h->snap2) hipFree(h->snap2);
     if (h->snap2_w) hipFree(h->snap2_w);
+    if (h->clk_dev) hipFree(h->clk_dev);
     if (h->st_err) hipHostFree(h->st_err);
     if (h->side) hipStreamSynchronize(h->side);
     if (h->comm && h->own_comm) ncclCommDestroy(h->comm);
@@ -2914,6 +2931,29 @@ int32_t demc_timing_read(demc_handle* h, double* out10, int32_t reset) {
     }
     if (reset)
         for (int i = 0; i < 5; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
+    return DEMC_OK;
+    });
+}
+
+int32_t demc_timing_clock(demc_handle* h, double* out4) {
+    return guarded(h, [&]() -> int32_t {
+    if (!h || !out4) return DEMC_EINVAL;
+    USE_DEVICE(h);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    out4[0] = out4[1] = out4[2] = out4[3] = 0.0;
+    if (!h->clk_dev || h->clk_n == 0) return DEMC_OK;  // no DIRECT likelihood launch ran with timing enabled
+    std::vector<unsigned long long> t(2 * h->clk_n);
+    HIPCHK(hipMemcpy(t.data(), h->clk_dev, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    std::vector<double> mhz;
+    mhz.reserve(h->clk_n);
+    for (size_t i = 0; i < h->clk_n; ++i)
+        if (t[2 * i + 1] > 0) mhz.push_back(100.0 * (double)t[2 * i] / (double)t[2 * i + 1]);  // s_memrealtime ticks at 100 MHz
+    if (mhz.empty()) return DEMC_OK;
+    std::sort(mhz.begin(), mhz.end());
+    out4[0] = mhz[mhz.size() / 2];
+    out4[1] = mhz.front();
+    out4[2] = mhz.back();
+    out4[3] = (double)mhz.size();
     return DEMC_OK;
     });
 }

@@ -2020,8 +2020,17 @@ __global__ __launch_bounds__(256, 2) void k_cross_mfma(KParams p, const double* 
 // dimension one v_add_f64 and one v_fma_f64.  DP = padded row length (host pads z rows and m with zeros).
 // grid = (proposal blocks of 256, observation chunks).
 // ------------------------------------------------------------------------------------------------
+// `clk` (demc_timing_enable only, else null: a wave-uniform branch on a kernarg): every workgroup leaves the shader-clock ticks
+// (s_memtime) and the 100 MHz reference ticks (s_memrealtime) of its lifetime, so that the host can say which clock the vector pipe
+// held under THIS kernel's load (demc_timing_clock) -- the chip lowers its clock under a dense FP64 loop and devices differ
+// (MI355X_MICROARCH.md, "DVFS give-back" items 5 and 6), and a VALU-bound rate scales with it.
 template <int DP>
-__global__ __launch_bounds__(256) void k_direct_mvn(KParams p, int n_chunks) {
+__global__ __launch_bounds__(256) void k_direct_mvn(KParams p, int n_chunks, unsigned long long* __restrict__ clk) {
+    unsigned long long clk_t0 = 0, clk_r0 = 0;
+    if (clk) {
+        clk_t0 = __builtin_amdgcn_s_memtime();
+        clk_r0 = __builtin_amdgcn_s_memrealtime();
+    }
     const int q = blockIdx.x * 256 + threadIdx.x;
     const int n_prop = p.n_groups * p.n_act;
     const int chunk = blockIdx.y;
@@ -2046,6 +2055,14 @@ __global__ __launch_bounds__(256) void k_direct_mvn(KParams p, int n_chunks) {
         }
     }
     if (ok) p.partial[(size_t)chunk * p.P + slot] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    if (clk) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) {
+            const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+            clk[2 * wg] = t1 - clk_t0;
+            clk[2 * wg + 1] = r1 - clk_r0;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

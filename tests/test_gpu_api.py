@@ -449,7 +449,7 @@ def test_host_planned_migration_moves_whole_rows():
     eng.close()
 
 
-@pytest.mark.parametrize("mode", ["streaming", "suffstat"])
+@pytest.mark.parametrize("mode", ["direct", "streaming", "suffstat"])
 def test_bench_contract_on_a_small_workload(mode):
     """bench.py prints ONE JSON line with the driver's keys, a `roofline` object for the dominant kernel and a
     `cpu_baseline` object; checked on a reduced workload so that the line's shape cannot rot unnoticed"""
@@ -474,7 +474,13 @@ def test_bench_contract_on_a_small_workload(mode):
     assert abs(det["value"] - 16 * 32 * 6 / (det["ms_per_step"] * 6e-3)) <= 1e-6 * det["value"]
     assert abs(r["value"] / det["value"] - 1) < 1e-4
     rf = r["roofline"]
-    assert rf["bound"] == ("mfma" if mode == "streaming" else "hbm") and rf["unit"] == ("TFLOP/s" if mode == "streaming" else "GB/s")
+    assert rf["bound"] == {"direct": "valu", "streaming": "mfma", "suffstat": "hbm"}[mode] and rf["unit"] == ("GB/s" if mode == "suffstat" else "TFLOP/s")
+    if mode == "direct":  # the headline's mode: the fraction in SURVEY 8d's unit, and the clock the vector pipe held beside it
+        assert 500.0 < rf["shader_clock_mhz"] <= 2500.0 and rf["frac_at_clock"] >= rf["frac"]
+        assert det["roofline"]["shader_clock_mhz_min"] <= rf["shader_clock_mhz"] <= det["roofline"]["shader_clock_mhz_max"]
+        assert "3*N*D" in det["roofline"]["flop_counted"] and "THE KERNELS OF THE TIMED REGION" in det["accuracy"]["leg"]
+    if mode == "streaming":  # a labelled row since round 6: both fractions, SURVEY's unit prices work the kernel does not do
+        assert det["roofline"]["frac_survey"] > det["roofline"]["frac_executed"] == det["roofline"]["frac"]
     assert rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and "traffic" in rf  # (5 significant digits)
     assert abs(det["roofline"]["frac"] - det["roofline"]["achieved"] / det["roofline"]["peak"]) < 1e-12
     cb = r["cpu_baseline"]
@@ -523,9 +529,9 @@ def test_bench_rows_and_the_row_flags(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import bench
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "3", "--no-cpu-baseline",
-                          "--accuracy-iters", "0", "--rows", "cfg3_direct,cfg3_suffstat_history_partners_post_burnin,cfg3_suffstat_history_partners_snooker,"
-                                                            "cfg4_share,cfg5_share_converged"],
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "3",
+                          "--accuracy-iters", "0", "--rows", "cfg3_streaming,cfg3_suffstat,cfg3_suffstat_history_partners_post_burnin,"
+                                                            "cfg3_suffstat_history_partners_snooker,cfg4_share,cfg5_share_converged"],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -536,8 +542,8 @@ def test_bench_rows_and_the_row_flags(tmp_path):
         assert c["name"] == x["name"] and abs(c["value"] / x["value"] - 1) < 1e-4 and abs(c["frac"] / x["roofline"]["frac"] - 1) < 1e-4
         assert c["bound"] == x["roofline"]["bound"] and c["steps"] == x["steps"] and c["launch_ms"] > 0
     rows = {x["name"]: x for x in r["rows"]}
-    assert set(rows) == {"cfg3_direct", "cfg3_suffstat_history_partners_post_burnin", "cfg3_suffstat_history_partners_snooker", "cfg4_share",
-                         "cfg5_share_converged"}
+    assert set(rows) == {"cfg3_streaming", "cfg3_suffstat", "cfg3_suffstat_history_partners_post_burnin", "cfg3_suffstat_history_partners_snooker",
+                         "cfg4_share", "cfg5_share_converged"}
     for name, x in rows.items():
         assert "error" not in x and x["value"] > 0 and x["finite_weights"], (name, x.get("error"))
         assert x["steps"] == dict(bench.ROWS)[name]["steps"]
@@ -547,9 +553,24 @@ def test_bench_rows_and_the_row_flags(tmp_path):
     # (a row's sampler settings must reach its engine: the workload object is shared between the rows of a configuration)
     assert rows["cfg3_suffstat_history_partners_snooker"]["kernels"] == "k_res_mvn<512,false,32,3>"
     assert rows["cfg4_share"]["kernels"] == "k_longrow<512>" and "k_lba_wave" in rows["cfg5_share_converged"]["kernels"]
-    assert r["headline_context"]["direct_frac"] == rows["cfg3_direct"]["roofline"]["frac"]
-    # the headline itself is untouched by the rows
-    assert r["metric"].startswith("particle-updates/sec") and "cfg3" in r["config"]["workload"] and r["roofline"]["bound"] == "mfma"
+    # STREAMING is a labelled row: the executed MFMA flop at most the peak, SURVEY 8d's unit over the same time ABOVE it (the
+    # [proposals x D].[D x N] product it executes is zero after centring: not the survey's per-pair work)
+    st = rows["cfg3_streaming"]["roofline"]
+    assert st["frac"] == st["frac_executed"] <= 1.0 < st["frac_survey"] and "null GEMM" in st["label"]
+    ctx = r["headline_context"]
+    assert ctx["streaming_frac_survey"] == st["frac_survey"] and ctx["suffstat_value"] == rows["cfg3_suffstat"]["value"]
+    assert abs(ctx["cpu_baseline_like_for_like_ratio"] - r["value"] / r["cpu_baseline"]["value"]) < 1e-9 * ctx["cpu_baseline_like_for_like_ratio"]
+    compact = {c["name"]: c for c in line["rows"]}
+    assert compact["cfg3_streaming"]["frac_survey"] > 1.0 and "frac_survey" not in compact["cfg4_share"]
+    # one GPU's share of BASELINE's 8-GPU cfg4 carries its own CPU leg (the oracle, reference schedule)
+    cb = rows["cfg4_share"]["cpu_baseline"]
+    assert cb["value"] > 0 and cb["value_single_thread"] > 0 and cb["kind"] == "port" and "cfg4" in cb["sample"]
+    assert abs(compact["cfg4_share"]["cpu"] / cb["value"] - 1) < 1e-4 and rows["cfg4_share"]["gpu_over_cpu"] > 1
+    # the headline: DIRECT, the fraction in SURVEY 8d's unit
+    assert r["metric"].startswith("particle-updates/sec") and "cfg3" in r["config"]["workload"] and "loglike=direct" in r["config"]["workload"]
+    assert r["roofline"]["bound"] == "valu" and 0 < r["roofline"]["frac"] <= 0.75 and "k_direct_mvn<32>" in r["kernels"]
+    N, d, P = 100000, 32, 65536
+    assert 3.0 * N * d * P / (r["ms_per_step"] * 1e-3) / 1e12 <= 78.6, "SURVEY 8d's flop per step over the step's wall time cannot exceed the peak"
 
 
 def test_rccl_all_gather_path_at_world_size_one():

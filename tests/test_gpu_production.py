@@ -402,6 +402,52 @@ def test_hierarchical_example_configuration_with_enough_particles_for_the_frozen
     assert ran == "k_frozen_sweep<256,big>", ran
 
 
+@pytest.mark.parametrize("order,beta,kernel", [("hyper_then_subject", 0.1, "k_frozen_sweep<256,big>"), ("subject_then_hyper", 0.1, "k_frozen_sweep<256>"),
+                                               ("hyper_then_subject", 0.5, "k_frozen_sweep<256,big>")])
+def test_row_streaming_kernel_at_the_benchmarked_row_length(demc, orc, order, beta, kernel):
+    """k_frozen_sweep AT cfg4's ROW LENGTH (missing 2): S = 10 000 subjects, D = 10 002 -- the rows the `cfg4_whole*`
+    bench rows stream -- on 40 x 32 particles (640 moving particles per colour phase: the form is taken), blocks [hyper ; subject]
+    of Examples/Hierarchical_Example.jl:88-92, crossover and mutation sweeps (beta = 0.1 / 0.5), inside and past burn-in
+    (burnin = 3 of 6 iterations), migrations on: free-running against the oracle, every accept decision and particle id equal,
+    theta to 1e-10.  demc_last_kernels names the LAST sweep's instance, so the block order is run both ways: the subject
+    block last names k_frozen_sweep<256,big> (every scalar proposed on the fly from own, partner and base rows, 40 rounds of 256
+    scalars per row, the ragged end at scalar 10 002), the hyper-parameter block last names k_frozen_sweep<256> (the frozen pass
+    over 10 000 subject terms, whose history row is then what the comparison reads)."""
+    from demc_amd import workloads as W
+    w = W.cfg4(S=10000, G=40, Np=32)
+    assert w["D"] == 10002
+    if order == "subject_then_hyper":
+        w["masks"] = w["masks"][::-1].copy()
+    ran = free_run(demc, orc, w, 6, [], 40, 32, theta_exact=False, lp_rtol=1e-8, beta=beta)
+    assert ran == kernel, ran
+
+
+@pytest.mark.parametrize("burnin", [100, 0, 5])
+def test_hierarchical_example_configuration_at_the_benchmarked_row_length(demc, orc, burnin):
+    """Examples/Hierarchical_Example.jl:88-114 as the reference runs it -- `sample = resample` (DE-MC_Z), theta_snooker = 0.1, blocks
+    [hyper ; subject] -- at D = 10 002 on 40 x 32 particles (synchronous schedule: 1 280 moving particles), inside burn-in (base
+    rows and select_base's weights from the sweep-start snapshot: block columns for the hyper-parameter sweep, the rows that sweep
+    streamed for the subject sweep), past it, and leaving it on the way: both k_frozen_sweep instances alternate on one stream,
+    partner rows are 80 KB history cells, a snooker particle projects over three of them -- against the oracle, free-running."""
+    from demc_amd import workloads as W
+    w = W.cfg4(S=10000, G=40, Np=32)
+    ran = free_run(demc, orc, w, 4 + 6, [], 40, 32, theta_exact=False, beta=0.1, burnin=burnin, theta_snooker=0.1, lp_rtol=1e-8, **_Z)
+    assert ran == "k_frozen_sweep<256,big>", ran
+
+
+@pytest.mark.parametrize("extra", [dict(), dict(_Z, theta_snooker=0.1, burnin=2)])
+def test_whole_cfg4_population_against_the_oracle(demc, orc, extra):
+    """BASELINE's cfg4 at the WHOLE population's geometry -- 128 groups x 32 particles x 10 002 scalars, the `cfg4_whole` bench row
+    (two_colour, partners from the population) and the reference's own configuration of it (DE-MC_Z + snooker + blocks, leaving
+    burn-in inside the run) -- for a few iterations against the oracle (4 096 particles x 10 002 scalars x 2 sweeps: a second per
+    iteration on the host's threads).  Until round 6 these rows were checked for finite weights only."""
+    from demc_amd import workloads as W
+    w = W.cfg4(S=10000, G=128, Np=32)
+    n_init = extra.get("n_initial", 0)
+    ran = free_run(demc, orc, w, n_init + 3, [], 128, 32, theta_exact=False, beta=0.1, lp_rtol=1e-8, **extra)
+    assert ran == "k_frozen_sweep<256,big>", ran
+
+
 def _long_row_cases(n, seed=20261006):
     rng = np.random.default_rng(seed)
     out = []

@@ -301,7 +301,7 @@ def test_bench_rows_are_commands_of_the_same_program():
     bench = _bench_module()
     names = [n for n, _ in bench.ROWS]
     assert len(set(names)) == len(names)
-    for need in ("cfg3_direct", "cfg3_suffstat", "cfg3_suffstat_post_burnin", "cfg2_streaming", "cfg2_streaming_post_burnin", "cfg4_share",
+    for need in ("cfg3_streaming", "cfg3_suffstat", "cfg3_suffstat_post_burnin", "cfg2_streaming", "cfg2_streaming_post_burnin", "cfg4_share",
                  "cfg4_whole", "cfg5_share"):
         assert need in names
     assert bench.profile_tag(bench.parse([])) == "headline"
@@ -364,7 +364,23 @@ def _fake_bench_result(bench, n_gpus=1, n_rows=None):
     rows = [dict(name=name, workload=prose, value=4973723.868929676, unit="particle-updates/s", ms_per_step=13.176445200224407,
                  steps=20, warmup=5, kernels=prose, accept_rate=0.408, finite_weights=True, roofline=dict(rf), seconds=0.91)
             for name, _ in bench.ROWS][:n_rows]
+    for r in rows:  # the fields only some rows carry: STREAMING rows both fractions, HBM rows the counters' fraction, two rows a CPU leg
+        if "streaming" in r["name"]:
+            r["roofline"].update(frac_executed=0.9650654701118142, frac_survey=1.4175654701118142)
+        if "suffstat" in r["name"]:
+            r["roofline"]["counter_frac"] = 0.21512345678
+        if r["name"].startswith("cfg4_whole"):
+            r["roofline"]["shape_frac"] = 0.63123456789
+        if r["name"] in bench.CPU_ROWS:
+            r["cpu_baseline"] = dict(value=23877.65572005412, value_single_thread=1737.3869838033977, cores=16, sample=prose)
     rows.append(dict(name="a_row_that_failed", error="RuntimeError: " + prose))
+    sharded = [dict(name=name, workload=prose, value=7822123.456789, unit="particle-updates/s", scaling="strong", ms_per_step=0.1309123456,
+                    steps=40, warmup=10, n_gpus=n_gpus, groups_total=spec["total_groups"], groups_per_rank=spec["total_groups"] // n_gpus,
+                    particles_per_gpu=512, block_sweeps_per_step=2, all_gathers_per_rank=[5] * n_gpus, rccl_nranks=n_gpus,
+                    collective="library", collective_fallback=None, kernels=prose, finite_weights=True, seconds=3.2)
+               for name, spec in bench.SHARDED_ROWS]
+    rf = dict(rf, shader_clock_mhz=2051.123456, frac_at_clock=0.7012345678, frac_of_mix_ceiling_at_clock=0.93512345678,
+              sclk_sysfs_mhz=dict(median=2100.0, min=2100.0, max=2400.0, samples=140, source=prose))
     return {"metric": "particle-updates/sec (proposal+loglike+accept) at D=32, N=1e5", "value": 11631628.466947727,
             "unit": "particle-updates/s", "n_gpus": n_gpus, "steps": 200, "warmup": 50, "ms_per_step": 5.634292754984926,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -375,11 +391,12 @@ def _fake_bench_result(bench, n_gpus=1, n_rows=None):
             "particle_parameter_updates_per_s": 372212110.94232726, "particle_iterations_per_s": 11631628.466947727,
             "accuracy": dict(timed_chain=dict(accept_rate=0.2288818359375, note=prose), posterior_mean_l1_rel=9.978460843456112e-06,
                              max_abs_err_in_posterior_sd=0.00976138608426626, leg=prose),
-            "roofline": rf, "headline_context": dict(direct_value=4973723.868929676, direct_frac=0.6034435300919369,
+            "roofline": rf, "headline_context": dict(streaming_value=11631628.466947727, streaming_frac_executed=0.9650654701118142,
+                                                     streaming_frac_survey=1.4175654701118142, suffstat_value=3736123456.789,
                                                      cpu_baseline_like_for_like_ratio=208.3003426819826, note=prose),
             "cpu_baseline": dict(value=23877.65572005412, unit="particle-updates/s", cores=16, kind="port",
                                  value_single_thread=1737.3869838033977, cpu_model="AMD EPYC 9575F 64-Core Processor", sample=prose),
-            "rows": rows if n_gpus == 1 else None}
+            "rows": rows if n_gpus == 1 else sharded}
 
 
 def test_bench_final_line_fits_what_a_harness_keeps(capsys):
@@ -404,18 +421,27 @@ def test_bench_final_line_fits_what_a_harness_keeps(capsys):
         assert abs(line["value"] / out["value"] - 1) < 1e-4  # 5 significant digits
         for k in ("value", "unit", "cores", "kind", "value_single_thread", "cpu_model", "sample"):
             assert k in line["cpu_baseline"], k
-        assert set(line["headline_context"]) == {"direct_value", "direct_frac", "cpu_baseline_like_for_like_ratio"}
+        assert set(line["headline_context"]) == {"streaming_value", "streaming_frac_executed", "streaming_frac_survey", "suffstat_value",
+                                                 "cpu_baseline_like_for_like_ratio"}
+        assert line["roofline"]["shader_clock_mhz"] == 2051.1 and line["roofline"]["sclk_sysfs_mhz"] == 2100.0
         assert line["config"]["all_gathers_per_rank"] == [21] * n_gpus
         assert line["config"]["ms_per_step_min_over_ranks"] == 5.61 and line["config"]["ms_per_step_max_over_ranks"] > 5.63
         if n_gpus == 1:
             assert [r["name"] for r in line["rows"]] == [n for n, _ in bench.ROWS] + ["a_row_that_failed"]
             for r in line["rows"][:-1]:
-                assert set(r) == {"name", "value", "ms_per_step", "steps", "frac", "launch_ms", "bound", "traffic"}, r
+                assert {"name", "value", "ms_per_step", "steps", "frac", "launch_ms", "bound", "traffic"} <= set(r), r
+                assert set(r) <= {"name", "value", "ms_per_step", "steps", "frac", "launch_ms", "bound", "traffic", "counter_frac", "shape_frac",
+                                  "frac_executed", "frac_survey", "cpu", "cpu_1thread"}, r
+                assert ("frac_survey" in r) == ("streaming" in r["name"]) and ("cpu" in r) == (r["name"] in bench.CPU_ROWS)
                 assert all(not isinstance(v, str) or len(v) < 64 for v in r.values())
             assert len(line["rows"][-1]["error"]) <= 80
             assert "rows_truncated" not in line
-        else:
+        else:  # the N > 1 line: BASELINE's 8-GPU configs as sharded rows (strong partition), numbers only
             assert line["config"]["rccl_nranks"] == 8
+            assert [r["name"] for r in line["rows"]] == [n for n, _ in bench.SHARDED_ROWS] == ["cfg4_sharded", "cfg5_sharded"]
+            for r, (_, spec) in zip(line["rows"], bench.SHARDED_ROWS):
+                assert set(r) == {"name", "value", "ms_per_step", "steps", "n_gpus", "groups_per_rank", "all_gathers_per_rank", "rccl_nranks"}
+                assert r["groups_per_rank"] * 8 == spec["total_groups"] and r["all_gathers_per_rank"] == [5] * 8 and r["n_gpus"] == 8
     # what main() prints: the detail line first, the compact line last
     bench.DETAIL_FILE = os.path.join("gpurun_out", "bench_detail_test.json")
     try:
@@ -446,7 +472,18 @@ def test_bench_rank_files_merge_into_one_short_line():
     assert line["config"]["all_gathers_per_rank"] == [21] * 8
     assert abs(line["value"] / (8 * 65536 * 200 / 1.19) - 1) < 1e-4  # whole job / MAX over ranks
     assert line["config"]["ms_per_step_min_over_ranks"] == 5.6 and line["config"]["ms_per_step_max_over_ranks"] == 5.95
+    assert line["rows"] is None
     assert bench.merge_rank_files(recs[:7], "x") is None  # a rank without a file: no line is made up
+    # ranks that also got through the sharded rows (BASELINE's cfg4 / cfg5 partitioned over the ranks) carry them in their files
+    for r in recs:
+        r["rows"] = [dict(name="cfg4_sharded", config="cfg4", steps=40, warmup=10, seconds_timed=0.0052 + 1e-4 * r["rank"], particles=512,
+                          block_sweeps_per_step=2, all_gathers=4, groups=16, rccl_nranks=8)] + \
+                    ([dict(name="cfg5_sharded", config="cfg5", steps=40, warmup=10, seconds_timed=0.1, particles=8192, block_sweeps_per_step=1,
+                           all_gathers=3, groups=64, rccl_nranks=8)] if r["rank"] != 5 else [])  # (rank 5 died inside the second row)
+    text = bench.merge_rank_files(recs, "late failure")
+    line = json.loads(text)
+    assert len(text) < bench.LINE_LIMIT and [r["name"] for r in line["rows"]] == ["cfg4_sharded"]
+    assert abs(line["rows"][0]["value"] / (8 * 512 * 2 * 40 / 0.0059) - 1) < 1e-4 and line["rows"][0]["all_gathers_per_rank"] == [4] * 8
 
 
 def test_bench_reads_the_traffic_shape_roof_of_the_long_row_kernel():
