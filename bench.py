@@ -962,6 +962,9 @@ ROWS = [
     ("cfg3_suffstat_history_partners_snooker", dict(config="cfg3", mode="suffstat", partners="history", n_initial=16, snooker=0.1, steps=200,
                                                     warmup=20)),  # DE-MC_Z as the reference's own runs configure it (theta_snooker = 0.1)
     ("cfg3_streaming_history_partners", dict(config="cfg3", mode="streaming", partners="history", n_initial=16, steps=20, warmup=5)),
+    # cfg2 in the headline's mode: 2 048 particles cannot fill the chip with a K1 -> k_direct_mvn -> K3 chain per colour phase (six
+    # dependent launches for 4.9e8 flop): a latency row, kept so that every MvNormal config is also measured in the form that does not collapse
+    ("cfg2_direct", dict(config="cfg2", mode="direct", steps=400, warmup=50)),
     ("cfg2_streaming", dict(config="cfg2", mode="streaming", steps=400, warmup=50)),
     ("cfg2_streaming_post_burnin", dict(config="cfg2", mode="streaming", burnin=0, steps=400, warmup=50)),
     ("cfg4_share", dict(config="cfg4", steps=40, warmup=10)),

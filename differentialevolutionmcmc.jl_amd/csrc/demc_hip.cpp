@@ -112,6 +112,9 @@ struct demc_handle {
     int snap2_sweep = -1;
     int* frozen_order_d = nullptr;
     size_t frozen_order_cap = 0;
+    int* frozen_order_pin = nullptr;        // pinned staging of the table (a truly asynchronous copy: nothing is drained)
+    size_t frozen_order_pin_cap = 0;
+    hipEvent_t frozen_order_ev = nullptr;   // the last copy out of the staging buffer has been consumed
     long long frozen_iter0 = 0;
     int frozen_iters = 0;
     int st_C = 0, st_nact_max = 0, st_rows = 0, st_x_lds = 0, st_chunk_tiles = 0, st_lpp = 0, st_scr_doubles = 0, st_wg = 512;
@@ -698,7 +701,9 @@ int lean_hist(const demc_handle* h, const KParams& k) {
 }
 int tail_of(const KParams& k) { return k.prep_mfma ? TAIL_PREP_MFMA : k.fuse_prep ? TAIL_PREP : k.fuse_obs ? TAIL_OBS : TAIL_NONE; }
 
-int launch_phase(demc_handle* h, KParams& k) {
+// (`k` by value: the frozen-sweep / snapshot overrides below -- glist, base_*, snap_*, the fuse flags -- stay inside this launch;
+// run_sweep reuses its own copy for the second colour phase and for every particle of the sequential schedule)
+int launch_phase(demc_handle* h, KParams k) {
     const long long n_prop = (long long)k.n_groups * k.n_act;
     if (n_prop == 0) return DEMC_OK;
     const demc_config& c = h->c;
@@ -770,7 +775,8 @@ int launch_phase(demc_handle* h, KParams& k) {
     };
     // A block sweep that FREEZES the row (the block holds a few hyper-parameters): the sweep reduced to what it is -- one pass
     // over the particle's own row, partner rows read at the block's scalars only (whole only by the one particle in ten whose
-    // snooker coin fired: its projections run over the row), no LDS row, five workgroups per CU (demc_frozen.hpp) -- instead of
+    // snooker coin fired: its projections run over the row), no LDS row, four workgroups per CU (<256>: 120 registers; three for
+    // <256,big>: 155; demc_frozen.hpp) -- instead of
     // the subject-sweep machinery of k_longrow at eight waves per CU.  Partners from the population or from the history, the
     // base row from the sweep-start snapshot when there is one.
     if (lr_shape && k.fuse_obs && k.fuse_accept && k.mask && k.n_mrun > 0 && !k.trace &&
@@ -816,13 +822,7 @@ int launch_phase(demc_handle* h, KParams& k) {
                 k.n_groups == c.n_groups) {
                 bool on2 = true;
                 if (const char* e = experiment("DEMC_FROZEN_SNAP2")) on2 = e[0] == '1';  // A/B experiments
-                if (on2 && !h->snap2) {
-                    if (hipMalloc((void**)&h->snap2, sizeof(double) * (size_t)h->P * c.D) != hipSuccess) { h->snap2 = nullptr; (void)hipGetLastError(); }
-                    if (h->snap2 && hipMalloc((void**)&h->snap2_w, sizeof(double) * (size_t)h->P) != hipSuccess) {
-                        hipFree(h->snap2); h->snap2 = nullptr; h->snap2_w = nullptr; (void)hipGetLastError();
-                    }
-                }
-                if (on2 && h->snap2) {
+                if (on2 && h->snap2) {  // (allocated at plan time -- plan_snap2 -- never inside an enqueued step)
                     k.snap_theta = h->snap2; k.snap_weight = h->snap2_w;
                     h->snap2_iter = (int64_t)k.iter; h->snap2_sweep = (int)k.sweep + 1;
                 }
@@ -1329,6 +1329,38 @@ int evaluate_rows(demc_handle* h, double* theta_dev, double* weight_dev) {
     return launch_phase(h, k);
 }
 
+// The by-product snapshot (KParams::snap_theta / snap_weight: a frozen sweep over the whole population leaves the rows it streamed
+// behind as the NEXT sweep's sweep-start snapshot) costs another P x D doubles -- 328 MB at cfg4, the size of theta itself.  The
+// buffers exist exactly while the configuration can take that path (DE-MC_Z inside burn-in, long hierarchical rows, more than one
+// block, enough particles for the row-streaming kernel): allocated here, when demc_set_model / demc_set_blocks learn it -- not by a
+// hipMalloc in the middle of an enqueued step -- and freed when the model or the blocks change so that it no longer can.  Out of
+// memory is not an error (the sweeps copy the population instead); demc_last_error then says so.
+int plan_snap2(demc_handle* h) {
+    const demc_config& c = h->c;
+    const bool hier = h->family == FAM_HIER_BINOMIAL || h->family == FAM_HIER_GAUSSIAN;
+    const bool want = hier && h->hier_scr && h->lpp > 64 && c.n_blocks > 1 && c.schedule == DEMC_SCHED_SYNCHRONOUS &&
+                      c.partner_kind == DEMC_PARTNER_HISTORY && c.proposal_kind == 0 && c.burnin >= 1 && c.fuse == 0 && !c.trace &&
+                      c.kappa == 1.0 && (long long)h->geo_groups * c.Np >= 2LL * h->n_cus;
+    if (!want) {
+        if (h->snap2 || h->snap2_w) {
+            HIPCHK(hipStreamSynchronize(h->stream));
+            if (h->snap2) hipFree(h->snap2);
+            if (h->snap2_w) hipFree(h->snap2_w);
+            h->snap2 = nullptr; h->snap2_w = nullptr; h->snap2_iter = -1;
+        }
+        return DEMC_OK;
+    }
+    if (h->snap2) return DEMC_OK;
+    const size_t bytes = sizeof(double) * (size_t)h->P * c.D;
+    if (hipMalloc((void**)&h->snap2, bytes) != hipSuccess) { h->snap2 = nullptr; (void)hipGetLastError(); }
+    if (h->snap2 && hipMalloc((void**)&h->snap2_w, sizeof(double) * (size_t)h->P) != hipSuccess) {
+        hipFree(h->snap2); h->snap2 = nullptr; h->snap2_w = nullptr; (void)hipGetLastError();
+    }
+    if (!h->snap2)
+        h->err = "note: no memory for the by-product snapshot (" + std::to_string(bytes) + " bytes): DE-MC_Z sweeps inside burn-in copy the population instead";
+    return DEMC_OK;
+}
+
 // K1 LDS carve-up (must match k_propose): group tile (if it fits) | Np prefix sums | A^-1 [d][d] | theta' scratch
 int size_k1_lds(demc_handle* h) {
     const demc_config& c = h->c;
@@ -1401,7 +1433,7 @@ int size_k1_lds(demc_handle* h) {
     plan_stream(h);
     plan_lean(h);
     HIPCHK(hipFuncSetAttribute((const void*)k_mig_pack, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
-    return DEMC_OK;
+    return plan_snap2(h);
 }
 
 void free_replay(demc_handle* h) {
@@ -1581,6 +1613,8 @@ int32_t demc_destroy(demc_handle* h) {
     }
     if (h->st_gran) hipFree(h->st_gran);
     if (h->frozen_order_d) hipFree(h->frozen_order_d);
+    if (h->frozen_order_pin) hipHostFree(h->frozen_order_pin);
+    if (h->frozen_order_ev) hipEventDestroy(h->frozen_order_ev);
     if (h->snap2) hipFree(h->snap2);
     if (h->snap2_w) hipFree(h->snap2_w);
     if (h->clk_dev) hipFree(h->clk_dev);
@@ -1674,6 +1708,15 @@ int32_t demc_set_model(demc_handle* h, int32_t family, const double* data, const
         case DEMC_FAM_LNR: {
             const int extra = (family == DEMC_FAM_LBA) ? 3 : 1;
             if (dm[1] < 1 || dm[1] > 8 || D != dm[1] + extra) return fail(h, DEMC_EINVAL, "LBA/LNR: dims=[N,n_acc<=8]");
+            // data = [choice[N] ; rt[N]]: the kernels pick the winning accumulator by comparing the choice code with 1..n_acc
+            // (k_lba_wave: exact double equality) and the sort below compares decision times -- a non-integral or out-of-range
+            // code would silently make every accumulator a loser, a NaN is no strict weak ordering: refused here
+            for (long long i = 0; i < dm[0]; ++i) {
+                const double ch = data[i], rt = data[dm[0] + i];
+                if (!(ch >= 1.0 && ch <= (double)dm[1] && ch == std::floor(ch)))
+                    return fail(h, DEMC_EINVAL, "LBA/LNR: choice of trial " + std::to_string(i) + " is not an integer in [1, n_acc]");
+                if (!std::isfinite(rt)) return fail(h, DEMC_EINVAL, "LBA/LNR: decision time of trial " + std::to_string(i) + " is not finite");
+            }
             h->N = dm[0];
             h->n_acc = (int)dm[1];
             h->c0 = (family == DEMC_FAM_LNR) ? (nhyper > 0 ? hyper[0] : 1.0) : 0.0;
@@ -1967,7 +2010,7 @@ int32_t demc_set_blocks(demc_handle* h, const uint8_t* masks, int32_t n_blocks) 
             }
         if (mr.n < 0) mr = demc_handle::MaskRuns();
     }
-    return DEMC_OK;
+    return plan_snap2(h);
     });
 }
 
@@ -2164,6 +2207,10 @@ static void plan_frozen_order(demc_handle* h, int64_t iter0, int32_t n_iters) {
     h->frozen_iters = 0;
     const bool hier = h->family == FAM_HIER_BINOMIAL || h->family == FAM_HIER_GAUSSIAN;
     if (!hier || c.n_blocks < 1 || h->lpp <= 64 || h->cur_glist || c.beta <= 0.0 || h->rp_active || n_iters < 1) return;
+    // nothing to plan where launch_phase cannot take the frozen form at all: too few moving particles for two workgroups per CU,
+    // recombination, a pool beyond the kernel's, the unfused / per-phase forms, a trace
+    const int n_act = c.schedule == DEMC_SCHED_TWO_COLOUR ? c.Np - c.Np / 2 : c.schedule == DEMC_SCHED_SEQUENTIAL ? 1 : c.Np;
+    if ((long long)h->geo_groups * n_act < 2LL * h->n_cus || c.kappa != 1.0 || c.Np > 512 || c.fuse != 0 || c.trace || !h->hier_scr) return;
     bool any = false;
     std::vector<char> frozen((size_t)c.n_blocks, 0);
     for (int b = 0; b < c.n_blocks && (size_t)b < h->mask_runs.size(); ++b) {
@@ -2177,17 +2224,30 @@ static void plan_frozen_order(demc_handle* h, int64_t iter0, int32_t n_iters) {
     const size_t need = (size_t)n_iters * c.n_blocks * c.n_groups;
     if (!any || need > ((size_t)1 << 24)) return;
     if (need > h->frozen_order_cap) {
-        if (h->frozen_order_d) hipFree(h->frozen_order_d);
+        if (h->frozen_order_d) { if (hipStreamSynchronize(h->stream) != hipSuccess) return; hipFree(h->frozen_order_d); }
         h->frozen_order_d = nullptr; h->frozen_order_cap = 0;
-        if (hipMalloc((void**)&h->frozen_order_d, need * sizeof(int)) != hipSuccess) return;
+        if (hipMalloc((void**)&h->frozen_order_d, need * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return; }
         h->frozen_order_cap = need;
     }
-    std::vector<int> order(need);
+    // PINNED staging owned by the handle, guarded by an event: the copy below is asynchronous for the host too (a pageable source
+    // made it wait for everything already queued on the stream -- step_body's "nothing is drained" was not true for blocked
+    // hierarchical models), and the buffer outlives the call
+    if (!h->frozen_order_ev && hipEventCreateWithFlags(&h->frozen_order_ev, hipEventDisableTiming) != hipSuccess) { h->frozen_order_ev = nullptr; return; }
+    if (h->frozen_order_pin && hipEventSynchronize(h->frozen_order_ev) != hipSuccess) return;  // (the previous table has left the buffer)
+    if (need > h->frozen_order_pin_cap) {
+        if (h->frozen_order_pin) hipHostFree(h->frozen_order_pin);
+        h->frozen_order_pin = nullptr; h->frozen_order_pin_cap = 0;
+        if (hipHostMalloc((void**)&h->frozen_order_pin, need * sizeof(int), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return; }
+        h->frozen_order_pin_cap = need;
+    }
+    int* order = h->frozen_order_pin;
+    std::vector<int> rest;
+    rest.reserve((size_t)c.n_groups);
     for (int32_t t = 0; t < n_iters; ++t)
         for (int b = 0; b < c.n_blocks; ++b) {
-            int* o = order.data() + ((size_t)t * c.n_blocks + b) * c.n_groups;
+            int* o = order + ((size_t)t * c.n_blocks + b) * c.n_groups;
             int n_front = 0;
-            std::vector<int> rest;
+            rest.clear();
             for (int g = 0; g < c.n_groups; ++g) {
                 bool mut = false;
                 if (frozen[(size_t)b]) {
@@ -2198,9 +2258,9 @@ static void plan_frozen_order(demc_handle* h, int64_t iter0, int32_t n_iters) {
             }
             for (size_t i = 0; i < rest.size(); ++i) o[n_front + (int)i] = rest[i];
         }
-    // (pageable source: the runtime stages it before the call returns, so `order` may go out of scope; the copy is ordered on
-    // the handle's stream behind every kernel that still reads the previous call's table)
-    if (hipMemcpyAsync(h->frozen_order_d, order.data(), need * sizeof(int), hipMemcpyHostToDevice, h->stream) != hipSuccess) return;
+    // ordered on the handle's stream behind every kernel that still reads the previous call's table
+    if (hipMemcpyAsync(h->frozen_order_d, order, need * sizeof(int), hipMemcpyHostToDevice, h->stream) != hipSuccess) return;
+    if (hipEventRecord(h->frozen_order_ev, h->stream) != hipSuccess) return;
     h->frozen_iter0 = iter0; h->frozen_iters = n_iters;
 }
 

@@ -288,7 +288,8 @@ int32_t demc_comm_stats(demc_handle* h, int64_t* out3);
  * (demc_config.geometry_groups) -- kernel form and observation-chunk count of the STREAMING likelihood included -- so the set
  * reproduces a single handle of n_groups groups bit for bit.  Shards that share a device run on ONE stream (the first such
  * shard's; do not give them streams of their own with demc_set_stream): the streaming-resident kernels assume the chip to
- * themselves; demc_set_stream on a shard of a built set is refused, DEMC_EINVAL).  demc_comm_init / _destroy / _set_overlap are
+ * themselves; demc_set_stream on a shard of a built set -- of ANY built set, a one-shard set included: the set's event
+ * ordering is wired to the streams it was built with -- is refused, DEMC_EINVAL).  demc_comm_init / _destroy / _set_overlap are
  * refused on a shard (DEMC_EINVAL): its communicator belongs to the set.
  * History partners (partner_kind = DEMC_PARTNER_HISTORY, `resample`, crossover.jl:113-124) draw their cells from the history of
  * ALL particles of the population; a shard holds the history of its own groups only.  A set of more than one shard could

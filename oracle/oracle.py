@@ -21,6 +21,8 @@ def use_native_build():
     """Switch to libdemc_oracle_native.so (built ON THIS HOST with -O3 -march=native).  Must be called before the
     first lib(); never for parity tests (FMA contraction changes the last bits of the proposal algebra)."""
     global _LIB, _NATIVE
+    if _NATIVE:  # (bench.py times several workloads: the switch is made once)
+        return
     assert _lib is None, "use_native_build() must come before the library is loaded"
     _LIB = os.path.join(_HERE, "libdemc_oracle_native.so")
     _NATIVE = True

@@ -493,7 +493,7 @@ def test_bench_contract_on_a_small_workload(mode):
 
 
 @pytest.mark.parametrize("config,extra", [("cfg1", []), ("cfg3", ["--mode", "direct", "--n-groups", "16", "--np", "32", "--nobs", "4000", "--dim", "8"]),
-                                          ("cfg2", ["--nobs", "2000"]), ("cfg4", ["--nobs", "600", "--n-groups", "4", "--np", "8"]),
+                                          ("cfg2", ["--mode", "streaming", "--nobs", "2000"]), ("cfg4", ["--nobs", "600", "--n-groups", "4", "--np", "8"]),
                                           ("cfg5", ["--nobs", "500", "--n-groups", "4", "--np", "16"])])
 def test_bench_lines_of_the_other_configs(config, extra):
     """--config cfg2 / cfg4 / cfg5 print the same contract with their own roofline definition"""
