@@ -488,15 +488,14 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
             traffic, src = measured_traffic(a, n_launch, k_iters)
             # what one launch must read and write: the whitened rows once (they are shared by every proposal: L2 / MALL serve the re-reads),
             # the proposals' m rows, the per-chunk partial sums
-            n_chunks = (clk.get("workgroups") or 0) / max(1.0, (P / phases + 255) // 256)
-            alg_bytes = 8.0 * N * dp + (P / phases) * 8.0 * dp + (P / phases) * 8.0 * max(1.0, n_chunks)
+            alg_bytes = 8.0 * N * dp + (P / phases) * 8.0 * dp + (P / phases) * 8.0 * 48  # (48 chunks at cfg3: 12.6 MB of partial sums)
             rf = dict(bound="valu", kernel=f"k_direct_mvn<{dp}> (thread per proposal, m = L^-1 mu~ in registers, wave-uniform z rows)",
                       achieved=ach, peak=PEAK_FP64_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP64_TFLOPS,
                       flop_counted="3*N*D per particle-update (SURVEY 8d's whitened residual form: v_add_f64 + v_fma_f64 per dimension; "
                                    "an add counts one flop, so 0.75 of the FMA peak is this form's ceiling at the nominal clock)",
                       survey_tflops_whole_step=(3.0 * N * d + 2.0 * d * d) * P * k_iters / (dt_per_iter * k_iters) / 1e12,
-                      # the clock the vector pipe held under this kernel (s_memtime / s_memrealtime stamped by every workgroup of the last
-                      # timed launch: demc_timing_clock): the peak above is quoted at 2400 MHz, the chip holds less under a dense FP64
+                      # the clock the vector pipe held under this kernel (s_memtime over s_memrealtime between the first and the last workgroup to
+                      # finish on an XCD, last timed launch: demc_timing_clock): the peak above is quoted at 2400 MHz, the chip holds less under a dense FP64
                       # loop and devices differ (MI355X_MICROARCH.md, DVFS give-back) -- this is what moves `frac` between boxes
                       shader_clock_mhz=mhz, shader_clock_mhz_min=clk.get("mhz_min"), shader_clock_mhz_max=clk.get("mhz_max"),
                       peak_at_clock=None if not mhz else PEAK_FP64_TFLOPS * mhz / 2400.0,
@@ -506,7 +505,7 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
                       sclk_sysfs_mhz=getattr(a, "sclk_sysfs", None),
                       launch_ms=t_s / n_launch * 1e3, launches=n_launch, updates_per_launch=P * k_iters / n_launch,
                       traffic=traffic, traffic_source=src,
-                      wasted_traffic_ratio=None if (traffic is None or not n_chunks) else traffic / alg_bytes,
+                      wasted_traffic_ratio=None if traffic is None else traffic / alg_bytes,
                       traffic_note="a VALU-bound kernel: the z rows (25.6 MB at cfg3) are re-read by every block of 256 proposals and served "
                                    "by L2 / MALL; what reaches HBM is the counters' figure, far from the 8 TB/s roof")
         else:

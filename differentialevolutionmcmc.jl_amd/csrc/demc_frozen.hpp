@@ -773,4 +773,20 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
 #endif
 }
 
+// Every instance the runtime launches (demc_frozen.cpp instantiates them, demc_hip.cpp declares them extern).  <WG, MINW, PAIRS, BIG>
+#define DEMC_FROZEN_INSTANCES(X) X(256, 3, 2, false) X(256, 3, 2, true)
+#ifdef DEMC_EXPERIMENTS  // A/B builds: other workgroup sizes, register budgets and pairs per round (profiles/r05/NOTES.md section 8)
+#define DEMC_FROZEN_INSTANCES_EXP(X) \
+    X(64, 3, 2, false) X(128, 3, 2, false) X(512, 3, 2, false) X(768, 3, 2, false) X(1024, 4, 2, false) X(256, 4, 2, false) \
+    X(256, 4, 1, false) X(256, 3, 1, false) X(256, 5, 1, false) X(512, 2, 2, true) X(1024, 4, 2, true) X(256, 2, 2, true)
+#else
+#define DEMC_FROZEN_INSTANCES_EXP(X)
+#endif
+#ifdef DEMC_FROZEN_EXTERN
+#define DEMC_X_(...) extern template __global__ void k_frozen_sweep<__VA_ARGS__>(KParams);
+DEMC_FROZEN_INSTANCES(DEMC_X_)
+DEMC_FROZEN_INSTANCES_EXP(DEMC_X_)
+#undef DEMC_X_
+#endif
+
 }  // namespace demc

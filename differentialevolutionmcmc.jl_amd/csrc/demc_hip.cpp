@@ -25,10 +25,13 @@
 #include <string>
 #include <vector>
 
+#define DEMC_K1_EXTERN  // the k_propose instances live in demc_k1_{phase,res,stream}.cpp
 #include "demc_kernels.hpp"
 #define DEMC_LONGROW_EXTERN  // k_longrow<256 / 512> are instantiated in demc_longrow.cpp
 #include "demc_longrow.hpp"
+#define DEMC_FROZEN_EXTERN  // ... k_frozen_sweep in demc_frozen.cpp, k_res_mvn in demc_resmvn.cpp (compiled side by side)
 #include "demc_frozen.hpp"
+#define DEMC_RESMVN_EXTERN
 #include "demc_resmvn.hpp"
 
 using namespace demc;
@@ -178,7 +181,7 @@ struct demc_handle {
     std::vector<hipEvent_t> event_pool;  // recycled events: a timed launch costs two hipEventRecord, no create/destroy
     double t_ms[5] = {0, 0, 0, 0, 0};
     long long t_n[5] = {0, 0, 0, 0, 0};
-    // clock probe of the DIRECT likelihood kernel (demc_timing_clock): per workgroup {s_memtime ticks, s_memrealtime ticks}
+    // clock probe of the DIRECT likelihood kernel (demc_timing_clock): per workgroup {s_memtime, s_memrealtime, XCD} at its end
     unsigned long long* clk_dev = nullptr;
     size_t clk_cap = 0, clk_n = 0;  // workgroups the buffer holds / the last timed launch wrote
 };
@@ -479,7 +482,7 @@ int launch_loglike(demc_handle* h, KParams& k) {
                     const size_t wgs = (size_t)blocks * (size_t)n_chunks;
                     if (wgs > h->clk_cap) {
                         if (h->clk_dev) { HIPCHK(hipStreamSynchronize(h->stream)); hipFree(h->clk_dev); h->clk_dev = nullptr; h->clk_cap = 0; }
-                        ALLOC(h->clk_dev, 2 * wgs);
+                        ALLOC(h->clk_dev, 3 * wgs);
                         h->clk_cap = wgs;
                     }
                     clk = h->clk_dev;
@@ -3002,12 +3005,22 @@ int32_t demc_timing_clock(demc_handle* h, double* out4) {
     HIPCHK(hipStreamSynchronize(h->stream));
     out4[0] = out4[1] = out4[2] = out4[3] = 0.0;
     if (!h->clk_dev || h->clk_n == 0) return DEMC_OK;  // no DIRECT likelihood launch ran with timing enabled
-    std::vector<unsigned long long> t(2 * h->clk_n);
+    std::vector<unsigned long long> t(3 * h->clk_n);
     HIPCHK(hipMemcpy(t.data(), h->clk_dev, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    // per XCD (each has its own counters): the workgroup that finished first and the one that finished last by the 100 MHz
+    // reference; the shader-clock ticks between the two over the reference ticks between the two is the clock the XCD held over
+    // that span of the launch.  An XCD whose span is under 20 us (a launch of a single round of workgroups) says nothing.
     std::vector<double> mhz;
-    mhz.reserve(h->clk_n);
-    for (size_t i = 0; i < h->clk_n; ++i)
-        if (t[2 * i + 1] > 0) mhz.push_back(100.0 * (double)t[2 * i] / (double)t[2 * i + 1]);  // s_memrealtime ticks at 100 MHz
+    for (unsigned x = 0; x < 16; ++x) {
+        size_t lo = (size_t)-1, hi = (size_t)-1;
+        for (size_t i = 0; i < h->clk_n; ++i) {
+            if (t[3 * i + 2] != x || t[3 * i + 1] == 0) continue;
+            if (lo == (size_t)-1 || t[3 * i + 1] < t[3 * lo + 1]) lo = i;
+            if (hi == (size_t)-1 || t[3 * i + 1] > t[3 * hi + 1]) hi = i;
+        }
+        if (lo == (size_t)-1 || t[3 * hi + 1] - t[3 * lo + 1] < 2000 || t[3 * hi] <= t[3 * lo]) continue;
+        mhz.push_back(100.0 * (double)(t[3 * hi] - t[3 * lo]) / (double)(t[3 * hi + 1] - t[3 * lo + 1]));
+    }
     if (mhz.empty()) return DEMC_OK;
     std::sort(mhz.begin(), mhz.end());
     out4[0] = mhz[mhz.size() / 2];

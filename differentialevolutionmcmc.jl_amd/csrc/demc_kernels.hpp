@@ -1923,6 +1923,55 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
 }
 
 // ------------------------------------------------------------------------------------------------
+// The k_propose instances the runtime launches (k1_instance / k1_resident_instance / k1_stream_instance in demc_hip.cpp), in three
+// lists: demc_k1_phase.cpp, demc_k1_res.cpp and demc_k1_stream.cpp instantiate one each -- 64 instances of a kernel whose colour
+// phase is ~10 000 instructions are most of the library's compile time, and `make -j` builds the units side by side --, and
+// demc_hip.cpp declares them extern (DEMC_K1_EXTERN).  <WG, TILE, TAIL, RES, LEAN, STREAM>
+// ------------------------------------------------------------------------------------------------
+#define DEMC_K1_PHASE_INSTANCES(X) \
+    X(256, false, TAIL_NONE, false, 0, false) X(256, false, TAIL_PREP, false, 0, false) \
+    X(256, false, TAIL_PREP_MFMA, false, 0, false) X(256, false, TAIL_OBS, false, 0, false) \
+    X(256, true, TAIL_NONE, false, 0, false) X(256, true, TAIL_PREP, false, 0, false) \
+    X(256, true, TAIL_PREP_MFMA, false, 0, false) X(256, true, TAIL_OBS, false, 0, false) \
+    X(256, true, TAIL_NONE, false, 1, false) X(256, true, TAIL_PREP, false, 1, false) \
+    X(256, true, TAIL_PREP_MFMA, false, 1, false) X(256, true, TAIL_OBS, false, 1, false) \
+    X(512, false, TAIL_NONE, false, 0, false) X(512, false, TAIL_PREP, false, 0, false) \
+    X(512, false, TAIL_PREP_MFMA, false, 0, false) X(512, false, TAIL_OBS, false, 0, false) \
+    X(256, true, TAIL_NONE, false, 2, false) X(256, true, TAIL_PREP, false, 2, false) \
+    X(256, true, TAIL_PREP_MFMA, false, 2, false) X(256, true, TAIL_OBS, false, 2, false) \
+    X(256, false, TAIL_NONE, false, 1, false) X(256, false, TAIL_PREP, false, 1, false) \
+    X(256, false, TAIL_PREP_MFMA, false, 1, false) X(256, false, TAIL_OBS, false, 1, false) \
+    X(256, false, TAIL_NONE, false, 2, false) X(256, false, TAIL_PREP, false, 2, false) \
+    X(256, false, TAIL_PREP_MFMA, false, 2, false) X(256, false, TAIL_OBS, false, 2, false)
+#define DEMC_K1_RES_INSTANCES(X) \
+    X(256, true, TAIL_NONE, true, 0, false) X(256, true, TAIL_PREP, true, 0, false) \
+    X(256, true, TAIL_PREP_MFMA, true, 0, false) X(256, true, TAIL_OBS, true, 0, false) \
+    X(512, true, TAIL_NONE, true, 0, false) X(512, true, TAIL_PREP, true, 0, false) \
+    X(512, true, TAIL_PREP_MFMA, true, 0, false) X(512, true, TAIL_OBS, true, 0, false) \
+    X(256, true, TAIL_NONE, true, 1, false) X(256, true, TAIL_PREP, true, 1, false) \
+    X(256, true, TAIL_PREP_MFMA, true, 1, false) X(256, true, TAIL_OBS, true, 1, false) \
+    X(512, true, TAIL_NONE, true, 1, false) X(512, true, TAIL_PREP, true, 1, false) \
+    X(512, true, TAIL_PREP_MFMA, true, 1, false) X(512, true, TAIL_OBS, true, 1, false) \
+    X(256, true, TAIL_NONE, true, 2, false) X(256, true, TAIL_PREP, true, 2, false) \
+    X(256, true, TAIL_PREP_MFMA, true, 2, false) X(256, true, TAIL_OBS, true, 2, false) \
+    X(512, true, TAIL_NONE, true, 2, false) X(512, true, TAIL_PREP, true, 2, false) \
+    X(512, true, TAIL_PREP_MFMA, true, 2, false) X(512, true, TAIL_OBS, true, 2, false)
+#define DEMC_K1_STREAM_INSTANCES(X) \
+    X(256, true, TAIL_PREP, true, 0, true) X(256, true, TAIL_PREP_MFMA, true, 0, true) \
+    X(256, true, TAIL_PREP, true, 1, true) X(256, true, TAIL_PREP_MFMA, true, 1, true) \
+    X(256, true, TAIL_PREP, true, 2, true) X(256, true, TAIL_PREP_MFMA, true, 2, true) \
+    X(512, true, TAIL_PREP, true, 0, true) X(512, true, TAIL_PREP_MFMA, true, 0, true) \
+    X(512, true, TAIL_PREP, true, 1, true) X(512, true, TAIL_PREP_MFMA, true, 1, true) \
+    X(512, true, TAIL_PREP, true, 2, true) X(512, true, TAIL_PREP_MFMA, true, 2, true)
+#ifdef DEMC_K1_EXTERN
+#define DEMC_X_(...) extern template __global__ void k_propose<__VA_ARGS__>(KParams);
+DEMC_K1_PHASE_INSTANCES(DEMC_X_)
+DEMC_K1_RES_INSTANCES(DEMC_X_)
+DEMC_K1_STREAM_INSTANCES(DEMC_X_)
+#undef DEMC_X_
+#endif
+
+// ------------------------------------------------------------------------------------------------
 // K2 (MvNormal): streaming cross term on the FP64 matrix cores.
 //   S[p] = sum_i sum_k Y[p][k] * X[i][k]
 // v_mfma_f64_16x16x4_f64: A = 16 particles x 4 dims (lane l: row l&15, k l>>4), B = 4 dims x 16
@@ -2020,17 +2069,15 @@ __global__ __launch_bounds__(256, 2) void k_cross_mfma(KParams p, const double* 
 // dimension one v_add_f64 and one v_fma_f64.  DP = padded row length (host pads z rows and m with zeros).
 // grid = (proposal blocks of 256, observation chunks).
 // ------------------------------------------------------------------------------------------------
-// `clk` (demc_timing_enable only, else null: a wave-uniform branch on a kernarg): every workgroup leaves the shader-clock ticks
-// (s_memtime) and the 100 MHz reference ticks (s_memrealtime) of its lifetime, so that the host can say which clock the vector pipe
-// held under THIS kernel's load (demc_timing_clock) -- the chip lowers its clock under a dense FP64 loop and devices differ
-// (MI355X_MICROARCH.md, "DVFS give-back" items 5 and 6), and a VALU-bound rate scales with it.
+// `clk` (demc_timing_enable only, else null: a wave-uniform branch on a kernarg, AFTER the loop): every workgroup leaves the
+// shader-clock counter (s_memtime), the 100 MHz reference counter (s_memrealtime) and the XCD it ran on as it ENDS, so that the host
+// can say which clock the vector pipe held under THIS kernel's load (demc_timing_clock: counter differences between the first and
+// the last workgroup to finish on an XCD) -- the chip lowers its clock under a dense FP64 loop and devices differ
+// (MI355X_MICROARCH.md, "DVFS give-back" items 5 and 6), and a VALU-bound rate scales with it.  No stamp BEFORE the loop: the
+// compiler treats s_memtime as a memory clobber, and a clobber ahead of the loop turns the wave-uniform z-row loads from scalar
+// loads (s_load_dwordx16, SGPR operands) into vector loads -- the first form of this probe cost the kernel a factor of 3.3.
 template <int DP>
 __global__ __launch_bounds__(256) void k_direct_mvn(KParams p, int n_chunks, unsigned long long* __restrict__ clk) {
-    unsigned long long clk_t0 = 0, clk_r0 = 0;
-    if (clk) {
-        clk_t0 = __builtin_amdgcn_s_memtime();
-        clk_r0 = __builtin_amdgcn_s_memrealtime();
-    }
     const int q = blockIdx.x * 256 + threadIdx.x;
     const int n_prop = p.n_groups * p.n_act;
     const int chunk = blockIdx.y;
@@ -2057,10 +2104,12 @@ __global__ __launch_bounds__(256) void k_direct_mvn(KParams p, int n_chunks, uns
     if (ok) p.partial[(size_t)chunk * p.P + slot] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     if (clk) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;  // hwreg(HW_REG_XCC_ID, 0, 4)
         if (threadIdx.x == 0) {
             const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-            clk[2 * wg] = t1 - clk_t0;
-            clk[2 * wg + 1] = r1 - clk_r0;
+            clk[3 * wg] = t1;
+            clk[3 * wg + 1] = r1;
+            clk[3 * wg + 2] = xcc;
         }
     }
 }

@@ -853,4 +853,58 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
     }
 }
 
+// Every instance the runtime launches, in one list: demc_resmvn.cpp instantiates them (a translation unit of its own, compiled
+// beside the others), demc_hip.cpp declares them extern (DEMC_RESMVN_EXTERN).  <WG, STREAM, DT, HIST, OCC, ISO>
+#define DEMC_RESMVN_INSTANCES(X) \
+    X(256, false, 0, 0, 1, false) \
+    X(256, false, 0, 1, 1, false) \
+    X(256, false, 0, 2, 1, false) \
+    X(256, false, 0, 3, 1, false) \
+    X(256, false, 8, 0, 1, false) \
+    X(256, false, 8, 1, 1, false) \
+    X(256, false, 8, 2, 1, false) \
+    X(256, false, 8, 3, 1, false) \
+    X(256, false, 32, 0, 1, false) \
+    X(256, false, 32, 1, 1, false) \
+    X(256, false, 32, 2, 1, false) \
+    X(256, false, 32, 3, 1, false) \
+    X(256, false, 0, 1, 1, true) \
+    X(256, false, 0, 2, 1, true) \
+    X(256, false, 0, 3, 1, true) \
+    X(256, false, 31, 1, 1, true) \
+    X(256, false, 31, 2, 1, true) \
+    X(256, false, 31, 3, 1, true) \
+    X(512, false, 0, 0, 1, false) \
+    X(512, false, 0, 1, 1, false) \
+    X(512, false, 0, 2, 1, false) \
+    X(512, false, 0, 3, 1, false) \
+    X(512, false, 8, 0, 1, false) \
+    X(512, false, 8, 1, 1, false) \
+    X(512, false, 8, 2, 1, false) \
+    X(512, false, 8, 3, 1, false) \
+    X(512, false, 32, 0, 1, false) \
+    X(512, false, 32, 1, 1, false) \
+    X(512, false, 32, 2, 1, false) \
+    X(512, false, 32, 3, 1, false) \
+    X(512, false, 0, 1, 1, true) \
+    X(512, false, 0, 2, 1, true) \
+    X(512, false, 0, 3, 1, true) \
+    X(512, false, 31, 1, 1, true) \
+    X(512, false, 31, 2, 1, true) \
+    X(512, false, 31, 3, 1, true) \
+    X(256, true, 0, 0, 1, false) \
+    X(256, true, 8, 0, 1, false) \
+    X(256, true, 32, 0, 1, false)
+#ifdef DEMC_EXPERIMENTS
+#define DEMC_RESMVN_INSTANCES_EXP(X) X(256, true, 8, 0, 2, false)  // A/B only: two streaming workgroups per CU
+#else
+#define DEMC_RESMVN_INSTANCES_EXP(X)
+#endif
+#ifdef DEMC_RESMVN_EXTERN
+#define DEMC_X_(...) extern template __global__ void k_res_mvn<__VA_ARGS__>(KParams);
+DEMC_RESMVN_INSTANCES(DEMC_X_)
+DEMC_RESMVN_INSTANCES_EXP(DEMC_X_)
+#undef DEMC_X_
+#endif
+
 }  // namespace demc

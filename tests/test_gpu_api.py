@@ -476,8 +476,7 @@ def test_bench_contract_on_a_small_workload(mode):
     rf = r["roofline"]
     assert rf["bound"] == {"direct": "valu", "streaming": "mfma", "suffstat": "hbm"}[mode] and rf["unit"] == ("GB/s" if mode == "suffstat" else "TFLOP/s")
     if mode == "direct":  # the headline's mode: the fraction in SURVEY 8d's unit, and the clock the vector pipe held beside it
-        assert 500.0 < rf["shader_clock_mhz"] <= 2500.0 and rf["frac_at_clock"] >= rf["frac"]
-        assert det["roofline"]["shader_clock_mhz_min"] <= rf["shader_clock_mhz"] <= det["roofline"]["shader_clock_mhz_max"]
+        assert "shader_clock_mhz" in rf and "frac_at_clock" in rf  # (a launch of one round of workgroups has nothing to difference: None)
         assert "3*N*D" in det["roofline"]["flop_counted"] and "THE KERNELS OF THE TIMED REGION" in det["accuracy"]["leg"]
     if mode == "streaming":  # a labelled row since round 6: both fractions, SURVEY's unit prices work the kernel does not do
         assert det["roofline"]["frac_survey"] > det["roofline"]["frac_executed"] == det["roofline"]["frac"]
@@ -568,7 +567,12 @@ def test_bench_rows_and_the_row_flags(tmp_path):
     assert abs(compact["cfg4_share"]["cpu"] / cb["value"] - 1) < 1e-4 and rows["cfg4_share"]["gpu_over_cpu"] > 1
     # the headline: DIRECT, the fraction in SURVEY 8d's unit
     assert r["metric"].startswith("particle-updates/sec") and "cfg3" in r["config"]["workload"] and "loglike=direct" in r["config"]["workload"]
-    assert r["roofline"]["bound"] == "valu" and 0 < r["roofline"]["frac"] <= 0.75 and "k_direct_mvn<32>" in r["kernels"]
+    assert r["roofline"]["bound"] == "valu" and 0.4 < r["roofline"]["frac"] <= 0.75 and "k_direct_mvn<32>" in r["kernels"]
+    # ... next to the clock the vector pipe held under it (in-kernel: s_memtime over s_memrealtime, per XCD) -- what moves a VALU-bound
+    # fraction between boxes; the fraction at that clock cannot exceed the instruction mix's 0.75 either
+    rf = r["roofline"]
+    assert 1000.0 < rf["shader_clock_mhz_min"] <= rf["shader_clock_mhz"] <= rf["shader_clock_mhz_max"] < 2450.0, rf
+    assert rf["frac"] <= rf["frac_at_clock"] <= 0.76 and abs(rf["frac_of_mix_ceiling_at_clock"] - rf["frac_at_clock"] / 0.75) < 1e-9
     N, d, P = 100000, 32, 65536
     assert 3.0 * N * d * P / (r["ms_per_step"] * 1e-3) / 1e12 <= 78.6, "SURVEY 8d's flop per step over the step's wall time cannot exceed the peak"
 
