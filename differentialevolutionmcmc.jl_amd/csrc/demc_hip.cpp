@@ -1145,7 +1145,8 @@ int launch_lean_hist(demc_handle* h, long long iter, bool snooker) {
     tick(h, 0, true);
     const bool iso = h->family == FAM_MVN_ISO;
     // (ISO: the row length of the reference's own test -- 30 means and sigma -- has an instance with D compiled in)
-    const int dt = iso ? (c.D == 31 ? 31 : 0) : (h->n_seg == 1 && (c.D == 32 || c.D == 8)) ? c.D : 0;
+    // (... which reads the prior table as [one entry for the 30 means | one for sigma]: any other table takes the general row length)
+    const int dt = iso ? ((c.D == 31 && h->n_seg == 2 && h->seg_start[1] == 30) ? 31 : 0) : (h->n_seg == 1 && (c.D == 32 || c.D == 8)) ? c.D : 0;
     h->last = demc_handle::LastPlan();
     const bool base = iter <= c.burnin;  // random_gamma reads a base particle (crossover.jl:164): the instance that loads its row
     h->last.k1 = 4; h->last.wg = h->lean_wg; h->last.stream = 0; h->last.dt = dt; h->last.hist = snooker ? 3 : base ? 2 : 1;

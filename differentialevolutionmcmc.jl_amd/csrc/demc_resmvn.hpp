@@ -162,7 +162,10 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
     // 245 and none this way.  Measured on all three instances in round 5 (profiles/r05/NOTES.md): parking costs 3-4 % per launch
     // (and parking the current row's scalars and xbar as well, which are read on the phase's dependent chain, 12 %), so instances
     // 1 and 2 (221 / 241 registers, no scratch) keep theirs in registers.
-    constexpr bool PARK = HIST_ == 3;
+    // Round 6: the odd-row ISO instances (D = 31: test/multivariate_normal_tests.jl) park in instance 2 as well -- their 16-byte loads at
+    // 8-byte alignment and the sigma scalar's own table entry cost the registers the D = 32 instances have to spare (instance 2 spilled
+    // 16 registers into 80 B of scratch, instance 3 26 into 112).
+    constexpr bool PARK = HIST_ == 3 || (ISO && HIST_ == 2);
     double* const pend_l = reinterpret_cast<double*>((reinterpret_cast<size_t>(bf_l + 16 * 64) + 15) & ~(size_t)15);  // (Np may be odd)
     auto park8 = [&](double* base, const double (&x)[8]) {
 #pragma unroll
@@ -443,7 +446,12 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
         double v8[8];
         int oob = 0;
         double prior = 0.0;
-        const bool one_seg = (DT > 0 && !ISO) || p.n_seg == 1;  // the usual case for this family: every scalar shares one table entry
+        // ISO with D compiled in (launch_lean_hist takes that instance only for the reference's own table: ONE entry for the means, one
+        // for sigma): the means share the wave-uniform entry 0 like any one-segment row, and the single sigma scalar -- scalar d, a fixed
+        // slot (second block, third scalar) of the quad's last lane -- reads entry 1.  The general per-scalar lookup (a table pointer, six
+        // LDS reads and a kind switch per scalar) was what these instances spilled on.
+        constexpr bool ISO2 = ISO && DT > 0;
+        const bool one_seg = (DT > 0 && !ISO) || ISO2 || p.n_seg == 1;  // the usual case for this family: every scalar shares one table entry
         // ... which is then wave-uniform: through readfirstlane its fields sit in SGPRs and the switch on the prior kind is a
         // scalar branch (as a per-lane value it compiles to one exec-masked region per prior kind and scalar)
         auto uni = [](double x) {
@@ -542,7 +550,11 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
                         v = t6 + (-eps + eps2 * u32unit(nw[e]));
                     }
                     v8[e] = v;
-                    if (one_seg) {
+                    if (ISO2 && blk == 1 && e4 == (DT - 1) % 4 && j == DT - 1) {  // sigma: its own table entry (Cauchy+ in the reference's test)
+                        const DimTab* tb = &s_seg[1].t;
+                        oob |= !(v >= tb->lo && v <= tb->hi);
+                        if (tb->kind != PR_FLAT) prior += prior_term_outofline(tb, v);
+                    } else if (one_seg) {
                         oob |= !(v >= tb1.lo && v <= tb1.hi);  // in_bounds utilities.jl:70-78
                         if (tb1.kind == PR_NORMAL) {
                             const double z = (v - tb1.a) * tb1.b;

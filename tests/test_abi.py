@@ -140,11 +140,19 @@ def test_every_kernel_fits_the_registers_of_its_workgroup(demc, tmp_path):
     # and so must the long-row kernel.
     # (mangled names: k_res_mvnILi<WG>ELb<STREAM>ELi<DT>ELi<HIST>ELi<OCC>ELb<ISO>EE -- matched on the leading parameters only,
     # so that a new trailing template parameter does not empty the list)
-    lean = [(n, r, sc) for n, r, _, _, sc in ks if re.search(r"k_res_mvnILi\d+ELb0ELi(8|32)ELi[123]E", n)]
-    assert len(lean) == 12, [n for n, _, _ in lean]
+    # Round 6: D = 31 -- the isotropic instances of the reference's own DE-MC_Z test (test/multivariate_normal_tests.jl:16-59) -- is a
+    # compiled-in dimension too; the guard of round 5 matched 8 and 32 only while those instances spilled 16 - 26 registers.
+    lean = [(n, r, sc) for n, r, _, _, sc in ks if re.search(r"k_res_mvnILi\d+ELb0ELi(8|31|32)ELi[123]E", n)]
+    assert len(lean) == 18, [n for n, _, _ in lean]
     for name, regs, scratch in lean:
         assert scratch == 0, f"{name}: {scratch} bytes of scratch per lane ({regs} registers)"
-        assert regs <= 250, f"{name}: {regs} registers -- back at the cap"
+        assert regs <= 252, f"{name}: {regs} registers -- back at the cap"
+    # the general-row-length instances (DT = 0: whatever shape has no compiled-in instance) do spill; a ceiling, so that it is seen
+    # when they get worse
+    general = [(n, sc) for n, _, _, _, sc in ks if re.search(r"k_res_mvnILi\d+ELb0ELi0ELi[0123]E", n)]
+    assert len(general) == 14, [n for n, _ in general]
+    for name, scratch in general:
+        assert scratch <= 192, f"{name}: {scratch} bytes of scratch per lane"
     for name, regs, _, _, scratch in ks:
         if "k_longrow" in name:
             assert scratch == 0 and regs <= 200, (name, regs, scratch)
