@@ -495,7 +495,7 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
                                    "an add counts one flop, so 0.75 of the FMA peak is this form's ceiling at the nominal clock)",
                       survey_tflops_whole_step=(3.0 * N * d + 2.0 * d * d) * P * k_iters / (dt_per_iter * k_iters) / 1e12,
                       # the clock the vector pipe held under this kernel (s_memtime over s_memrealtime between the first and the last workgroup to
-                      # finish on an XCD, last timed launch: demc_timing_clock): the peak above is quoted at 2400 MHz, the chip holds less under a dense FP64
+                      # finish on the same CU, median over the CUs, last timed launch: demc_timing_clock): the peak above is quoted at 2400 MHz, the chip holds less under a dense FP64
                       # loop and devices differ (MI355X_MICROARCH.md, DVFS give-back) -- this is what moves `frac` between boxes
                       shader_clock_mhz=mhz, shader_clock_mhz_min=clk.get("mhz_min"), shader_clock_mhz_max=clk.get("mhz_max"),
                       peak_at_clock=None if not mhz else PEAK_FP64_TFLOPS * mhz / 2400.0,

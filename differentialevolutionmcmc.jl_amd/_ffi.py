@@ -451,13 +451,13 @@ class HipEngine:
 
     def timing_clock(self):
         """shader clock (MHz) the DIRECT MvNormal likelihood kernel held in its last launch with timing enabled: median / min /
-        max over the XCDs (per XCD: s_memtime ticks over 100 MHz s_memrealtime ticks between the first and the last workgroup to
-        finish); None if no such launch ran or it was too short to difference"""
+        max over the CUs (per CU: s_memtime ticks over 100 MHz s_memrealtime ticks between the first and the last workgroup to
+        finish there); None if no such launch ran or it was too short to difference"""
         out = np.zeros(4)
         self._ck(self.L.demc_timing_clock(self.h, _d(out)))
         if out[3] == 0:
             return None
-        return dict(mhz_median=float(out[0]), mhz_min=float(out[1]), mhz_max=float(out[2]), xcds=int(out[3]))
+        return dict(mhz_median=float(out[0]), mhz_min=float(out[1]), mhz_max=float(out[2]), cus=int(out[3]))
 
 
 class MultiEngine:

@@ -33,6 +33,8 @@
 #include "demc_frozen.hpp"
 #define DEMC_RESMVN_EXTERN
 #include "demc_resmvn.hpp"
+#define DEMC_RESOBS_EXTERN
+#include "demc_resobs.hpp"
 
 using namespace demc;
 
@@ -133,6 +135,8 @@ struct demc_handle {
     int ainv_lds = 1;
     // lean resident kernel of the default sampler on MvNormal-full (demc_resmvn.hpp): geometry for SUFFSTAT / STREAMING
     bool lean_ok = false, lean_stream_ok = false, lean_hist_ok = false;  // (lean_hist: DE-MC_Z past burn-in, k_res_mvn<..., HIST>)
+    bool lean_obs_ok = false;  // lean resident kernel of the default sampler on the per-observation families (demc_resobs.hpp)
+    size_t lean_obs_lds = 0;
     int lean_wg = 0;
     size_t lean_lds = 0, lean_stream_lds = 0, lean_hist_lds = 0;
     // update of a subset of the groups (demc_update_groups_async): two device lists used alternately, and the one in force
@@ -170,7 +174,7 @@ struct demc_handle {
     bool multi_sealed = false;  // the set is built: demc_set_stream is refused from here on
     // which kernel instances the last update launched (demc_last_kernels: lets a test name the instance it compared)
     struct LastPlan {
-        int k1 = -1;  // 0 k_propose per phase, 1 k_longrow, 2 k_propose resident, 3 k_propose streaming-resident, 4 k_res_mvn, 5 k_frozen_sweep
+        int k1 = -1;  // 0 k_propose per phase, 1 k_longrow, 2 k_propose resident, 3 k_propose streaming-resident, 4 k_res_mvn, 5 k_frozen_sweep, 6 k_res_obs
         int wg = 0, tile = 0, tail = 0, plain = 0, dt = 0, stream = 0, hist = 0, iso = 0, big = 0;
         int k2 = 0;   // 0 none (fused into K1), 1 k_cross_mfma, 2 k_obs_loglike, 3 k_hier_loglike, 4 user plug-in
         int ks = 0, k3 = 0;
@@ -1023,6 +1027,22 @@ int launch_resident(demc_handle* h, long long iter0, int n_iters) {
 void plan_lean(demc_handle* h) {
     const demc_config& c = h->c;
     h->lean_ok = h->lean_stream_ok = h->lean_hist_ok = false;
+    // The per-observation families under the default sampler (demc_resobs.hpp): Gaussian, Binomial and the LNR with a handful of
+    // parameters (a lane per scalar of a sixteen-lane particle) and few enough observations for sixteen lanes to walk them; the
+    // group, its scratch rows and -- LNR -- the log Phi(-z) table in LDS.  Whether the SAMPLER is the default one is asked per step
+    // (is_plain: a replay or a trace takes the general kernel).
+    h->lean_obs_ok = false;
+    if ((h->family == FAM_GAUSSIAN || h->family == FAM_BINOMIAL || h->family == FAM_LNR) && c.D <= 16 && c.fuse == 0 &&
+        c.schedule == DEMC_SCHED_TWO_COLOUR && c.partner_kind == DEMC_PARTNER_CURRENT && c.Np >= 4 && c.Np <= 512 && h->n_seg >= 1 &&
+        h->N / 16 <= 512) {
+        bool ref = false;
+        for (const DimTab& t : h->h_tab) ref = ref || t.kind == PR_NORMAL_REF;
+        const size_t doubles = (size_t)c.Np * c.D + (size_t)c.Np + (size_t)(c.Np - c.Np / 2) + (size_t)(256 / 16) * c.D +
+                               (h->family == FAM_LNR ? (size_t)kLogPhiRows * kLogPhiRow : 0);
+        bool on = !ref && doubles * sizeof(double) <= kMaxDynLds;
+        if (const char* e = experiment("DEMC_LEAN_OBS")) on = on && e[0] == '1';  // A/B experiments
+        if (on) { h->lean_obs_ok = true; h->lean_obs_lds = doubles * sizeof(double); }
+    }
     // DE-MC_Z (history partners, the synchronous schedule) on the same family in SUFFSTAT mode: the lean body with partner rows
     // from the history, one launch per iteration (step_body) -- all it needs in LDS are select_base's cumulative weights and the
     // centred rows
@@ -1132,6 +1152,21 @@ int launch_lean(demc_handle* h, long long iter0, int n_iters, bool stream) {
     tick(h, 0, false);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, DEMC_EHIP, std::string("lean resident launch: ") + hipGetErrorString(e));
+    return DEMC_OK;
+}
+
+// the default sampler on a per-observation family: every iteration up to the next migration in one launch of k_res_obs
+int launch_lean_obs(demc_handle* h, long long iter0, int n_iters) {
+    const demc_config& c = h->c;
+    KParams k = base_params(h);
+    k.iter = iter0; k.n_iters = n_iters; k.n_rows = h->hist ? c.n_rows : 0;
+    h->last = demc_handle::LastPlan();
+    h->last.k1 = 6; h->last.wg = 256;
+    tick(h, 0, true);
+    LAUNCH_T(h, k_res_obs<256>, dim3((unsigned)k.n_groups), dim3(256), h->lean_obs_lds, k);
+    tick(h, 0, false);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, DEMC_EHIP, std::string("lean per-observation launch: ") + hipGetErrorString(e));
     return DEMC_OK;
 }
 
@@ -1432,6 +1467,7 @@ int size_k1_lds(demc_handle* h) {
                                    k_res_mvn<256, false, 31, 1, 1, true>, k_res_mvn<256, false, 31, 2, 1, true>, k_res_mvn<256, false, 31, 3, 1, true>,
                                    k_res_mvn<512, false, 31, 1, 1, true>, k_res_mvn<512, false, 31, 2, 1, true>, k_res_mvn<512, false, 31, 3, 1, true>};
         for (auto f : lean) HIPCHK(hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_res_obs<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
     }
     plan_resident(h);
     plan_stream(h);
@@ -2296,16 +2332,19 @@ static int step_body(demc_handle* h, int64_t iter0, int32_t n_iters, bool with_m
                 migration_enqueue(h, iter, h->mig_rows, h->mig_rows, true, true);
         }
         const bool st_ok = h->st_ok && !h->cur_glist;  // (a subset update never uses the form whose workgroups wait on each other)
-        if ((h->res_ok || st_ok) && !h->rp_active) {  // every iteration up to the next migration in one launch
+        // the default sampler has lean kernels of its own on MvNormal-full and on the per-observation families (same draws, same decisions)
+        KParams kp0 = base_params(h);
+        kp0.mode = MODE_STEP;
+        const bool plain = is_plain(h, kp0);
+        const bool obs_lean = h->lean_obs_ok && plain;
+        if ((h->res_ok || st_ok || obs_lean) && !h->rp_active) {  // every iteration up to the next migration in one launch
             int run = 1;  // capped so that a single launch stays in the millisecond range whatever the caller asks for
             const int cap = st_ok ? 64 : 1024;
             while (run < cap && iter + run < iter0 + n_iters && !(with_migration && migration_due_h(h, iter + run))) ++run;
-            // the default sampler on MvNormal-full has a lean kernel of its own (same draws, same decisions)
-            KParams kp = base_params(h);
-            const bool plain = is_plain(h, kp);
             int rc;
             if (st_ok && plain && h->lean_stream_ok) rc = launch_lean(h, iter, run, true);
             else if (!st_ok && plain && h->lean_ok) rc = launch_lean(h, iter, run, false);
+            else if (obs_lean) rc = launch_lean_obs(h, iter, run);
             else rc = st_ok ? launch_stream(h, iter, run) : launch_resident(h, iter, run);
             if (rc != DEMC_OK) return rc;
             iter += run - 1;
@@ -2944,6 +2983,7 @@ int32_t demc_last_kernels(demc_handle* h, char* out, int32_t nbytes) {
             break;
         case 1: std::snprintf(buf, sizeof buf, "k_longrow<%d>", L.wg); break;
         case 5: std::snprintf(buf, sizeof buf, "k_frozen_sweep<%d%s>", L.wg, L.big ? ",big" : ""); break;
+        case 6: std::snprintf(buf, sizeof buf, "k_res_obs<%d>", L.wg); break;
         case 2:
             std::snprintf(buf, sizeof buf, "k_propose<%d,true,%s,true,%s>", L.wg, tails[L.tail & 3], tf[L.plain]);
             break;
@@ -3008,19 +3048,24 @@ int32_t demc_timing_clock(demc_handle* h, double* out4) {
     if (!h->clk_dev || h->clk_n == 0) return DEMC_OK;  // no DIRECT likelihood launch ran with timing enabled
     std::vector<unsigned long long> t(3 * h->clk_n);
     HIPCHK(hipMemcpy(t.data(), h->clk_dev, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    // per XCD (each has its own counters): the workgroup that finished first and the one that finished last by the 100 MHz
-    // reference; the shader-clock ticks between the two over the reference ticks between the two is the clock the XCD held over
-    // that span of the launch.  An XCD whose span is under 20 us (a launch of a single round of workgroups) says nothing.
+    // per CU (the shader-clock counters of different CUs are not aligned: differencing across CUs gave 1.8 - 13.7 "GHz"): the
+    // workgroup that finished first there and the one that finished last, by the 100 MHz reference; the shader-clock ticks between
+    // the two over the reference ticks between the two is the clock the CU held over that span of the launch.  A CU whose span is
+    // under 20 us (a launch of a single round of workgroups) says nothing.
+    std::vector<size_t> order(h->clk_n);
+    for (size_t i = 0; i < h->clk_n; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return t[3 * a + 2] < t[3 * b + 2]; });
     std::vector<double> mhz;
-    for (unsigned x = 0; x < 16; ++x) {
-        size_t lo = (size_t)-1, hi = (size_t)-1;
-        for (size_t i = 0; i < h->clk_n; ++i) {
-            if (t[3 * i + 2] != x || t[3 * i + 1] == 0) continue;
-            if (lo == (size_t)-1 || t[3 * i + 1] < t[3 * lo + 1]) lo = i;
-            if (hi == (size_t)-1 || t[3 * i + 1] > t[3 * hi + 1]) hi = i;
+    for (size_t a = 0; a < order.size();) {
+        size_t b = a, lo = order[a], hi = order[a];
+        for (; b < order.size() && t[3 * order[b] + 2] == t[3 * order[a] + 2]; ++b) {
+            const size_t i = order[b];
+            if (t[3 * i + 1] < t[3 * lo + 1]) lo = i;
+            if (t[3 * i + 1] > t[3 * hi + 1]) hi = i;
         }
-        if (lo == (size_t)-1 || t[3 * hi + 1] - t[3 * lo + 1] < 2000 || t[3 * hi] <= t[3 * lo]) continue;
-        mhz.push_back(100.0 * (double)(t[3 * hi] - t[3 * lo]) / (double)(t[3 * hi + 1] - t[3 * lo + 1]));
+        if (t[3 * lo + 1] != 0 && t[3 * hi + 1] - t[3 * lo + 1] >= 2000 && t[3 * hi] > t[3 * lo])
+            mhz.push_back(100.0 * (double)(t[3 * hi] - t[3 * lo]) / (double)(t[3 * hi + 1] - t[3 * lo + 1]));
+        a = b;
     }
     if (mhz.empty()) return DEMC_OK;
     std::sort(mhz.begin(), mhz.end());

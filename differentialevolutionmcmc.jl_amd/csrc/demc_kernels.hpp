@@ -2070,9 +2070,9 @@ __global__ __launch_bounds__(256, 2) void k_cross_mfma(KParams p, const double* 
 // grid = (proposal blocks of 256, observation chunks).
 // ------------------------------------------------------------------------------------------------
 // `clk` (demc_timing_enable only, else null: a wave-uniform branch on a kernarg, AFTER the loop): every workgroup leaves the
-// shader-clock counter (s_memtime), the 100 MHz reference counter (s_memrealtime) and the XCD it ran on as it ENDS, so that the host
+// shader-clock counter (s_memtime), the 100 MHz reference counter (s_memrealtime) and the CU it ran on as it ENDS, so that the host
 // can say which clock the vector pipe held under THIS kernel's load (demc_timing_clock: counter differences between the first and
-// the last workgroup to finish on an XCD) -- the chip lowers its clock under a dense FP64 loop and devices differ
+// the last workgroup to finish on the SAME CU -- the counters of different CUs are not aligned) -- the chip lowers its clock under a dense FP64 loop and devices differ
 // (MI355X_MICROARCH.md, "DVFS give-back" items 5 and 6), and a VALU-bound rate scales with it.  No stamp BEFORE the loop: the
 // compiler treats s_memtime as a memory clobber, and a clobber ahead of the loop turns the wave-uniform z-row loads from scalar
 // loads (s_load_dwordx16, SGPR operands) into vector loads -- the first form of this probe cost the kernel a factor of 3.3.
@@ -2105,11 +2105,12 @@ __global__ __launch_bounds__(256) void k_direct_mvn(KParams p, int n_chunks, uns
     if (clk) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;  // hwreg(HW_REG_XCC_ID, 0, 4)
+        const unsigned hwid = __builtin_amdgcn_s_getreg(4 | (31 << 11));       // hwreg(HW_REG_HW_ID): cu_id [11:8], sh_id [12], se_id [15:13]
         if (threadIdx.x == 0) {
             const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
             clk[3 * wg] = t1;
             clk[3 * wg + 1] = r1;
-            clk[3 * wg + 2] = xcc;
+            clk[3 * wg + 2] = (xcc << 8) | ((hwid >> 8) & 0xffu);  // the CU the workgroup ran on
         }
     }
 }

@@ -361,9 +361,9 @@ int32_t demc_timing_enable(demc_handle* h, int32_t on);
 int32_t demc_timing_read(demc_handle* h, double* out10, int32_t reset);
 /* The shader clock the DIRECT MvNormal likelihood kernel (DEMC_LOGLIKE_DIRECT: FP64 vector-pipe work, whose rate scales with the
  * clock) held during its LAST launch with timing enabled: every workgroup stamps s_memtime (shader cycles), s_memrealtime (100 MHz
- * reference) and its XCD as it ends; per XCD the clock is the shader cycles over the reference ticks between the first and the last
- * workgroup to finish.  out[0] = median over the XCDs in MHz, [1] = min, [2] = max, [3] = XCDs that reported (0: no such launch
- * ran, or it was a single round of workgroups: nothing to difference).  Diagnostic, like demc_timing_read: the chip lowers its
+ * reference) and its CU as it ends; per CU the clock is the shader cycles over the reference ticks between the first and the last
+ * workgroup to finish there.  out[0] = median over the CUs in MHz, [1] = min, [2] = max, [3] = CUs that reported (0: no such
+ * launch ran, or it was a single round of workgroups: nothing to difference).  Diagnostic, like demc_timing_read: the chip lowers its
  * clock under load and devices differ, so a measured TFLOP/s is quoted with the clock it was measured at (replaces nothing in
  * the reference). */
 int32_t demc_timing_clock(demc_handle* h, double* out4);

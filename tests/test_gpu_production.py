@@ -662,3 +662,60 @@ def test_snooker_lean_instances_match_the_oracle(demc, orc, shape):
     ran = free_run(demc, orc, w, 8, [kern], G, Np, theta_exact=False, theta_snooker=snk,
                    lp_rtol=1e-5 if shape == "cfg5_chain" else 1e-9, **kw)
     assert "k_res_mvn" not in ran
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# k_res_obs (demc_resobs.hpp, round 6): the lean resident kernel of the DEFAULT sampler on the per-observation families -- what the
+# reference's own gates run (test/gaussian_tests.jl:39-41, test/binomial_tests.jl, test/lognormal_race_tests.jl:40-42,
+# Examples/Gaussian_Example.jl = BASELINE cfg1)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("family,G,Np,kw,beta", [
+    ("cfg1", 4, 10, {}, 0.0),                       # BASELINE cfg1 as benchmarked: 4 x 10, D = 2, 50 observations; crossover only: theta bit for bit
+    ("cfg1", 4, 10, {}, 0.1),                       # ... with mutation sweeps (device log / sincospi: 1e-10)
+    ("gaussian", 4, 6, dict(N=50), 0.1),            # test/gaussian_tests.jl:39-41: Np = 6 (three movers a phase: most lanes of the pass idle)
+    ("gaussian", 3, 40, dict(N=300), 0.1),          # 20 movers: two passes of 16 particles per colour phase, 19 observations a lane
+    ("gaussian", 5, 9, dict(N=7), 0.3),             # odd group (4 / 5 movers), fewer observations than lanes
+    ("binomial", 6, 12, dict(N=5), 0.1),            # test/binomial_tests.jl's model: D = 1, Beta prior, bounds [0, 1]
+    ("binomial", 2, 64, dict(N=33), 0.5),           # 32 movers, mutation in half of the sweeps
+    ("lnr", 4, 24, dict(N=100, na=3), 0.1),         # test/lognormal_race_tests.jl:40-42's shape: four groups of 24, the table in LDS
+    ("lnr", 3, 8, dict(N=60, na=8), 0.1),           # eight accumulators: D = 9 -- three NOISE blocks, a Uniform prior on the last scalar
+])
+def test_lean_resident_kernel_of_the_per_observation_families(demc, orc, family, G, Np, kw, beta):
+    """the default sampler on Gaussian / Binomial / LNR runs in k_res_obs<256> (sixteen lanes per particle, the whole update of a
+    group resident over the iterations between two migrations): free-running against the oracle, migrations on, in and past burn-in
+    -- every accept decision and particle id equal, theta bit for bit without mutation sweeps, log-posteriors to 1e-9 -- the
+    kernel by name"""
+    from demc_amd import workloads as W
+    from conftest import make_problem
+    if family == "cfg1":
+        w = dict(W.cfg1(), G=G, Np=Np)
+    else:
+        prob = make_problem(family, np.random.default_rng(311), **kw)
+        w = dict(prob, G=G, Np=Np, masks=None, engine={}, init=lambda P, rng_: prob["init"](P))
+    ran = free_run(demc, orc, w, 24, [], G, Np, theta_exact=beta == 0.0, exact_kernels="k_res_obs<256>", beta=beta, alpha=0.3)
+    assert ran == "k_res_obs<256>"
+
+
+def test_lean_per_observation_kernel_equals_the_general_kernel(demc):
+    """k_res_obs makes the proposals and decisions of the general kernel (trace = 1 selects k_propose): state, ids, accept flags and
+    theta history bit for bit on Gaussian, Binomial and LNR across burn-in, mutation sweeps and migrations; log-densities to rounding
+    (the sums over observations and prior terms run in another lane order)"""
+    from conftest import make_problem, setup_engine
+    for family, G, Np, kw in (("gaussian", 4, 10, dict(N=50)), ("binomial", 3, 20, dict(N=9)), ("lnr", 4, 24, dict(N=80, na=3))):
+        prob = make_problem(family, np.random.default_rng(312), **kw)
+        th0 = prob["init"](G * Np)
+        outs, names = [], []
+        for tr in (0, 1):
+            e = demc.HipEngine(n_groups=G, Np=Np, D=prob["D"], n_rows=30, schedule=2, seed=11, alpha=0.3, burnin=12, trace=tr)
+            setup_engine(e, prob)
+            e.set_state(th0)
+            e.step(1, 30)
+            names.append(e.last_kernels())
+            outs.append(e.get_history(0, 30) + e.get_state())
+            e.close()
+        assert names[0] == "k_res_obs<256>" and "k_propose" in names[1], names
+        for i, (x, y) in enumerate(zip(*outs)):
+            if x.dtype.kind == "f" and i in (2, 5):  # lp history, weights
+                np.testing.assert_allclose(x, y, rtol=1e-11, err_msg=f"{family} array {i}")
+            else:
+                assert np.array_equal(x, y), f"{family} array {i}"
