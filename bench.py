@@ -562,7 +562,7 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
         n_launch = max(1, tm["propose"]["launches"])
         byts = (24.0 * D + 17.0) * P * k_iters
         ach = byts / t_s / 1e9
-        rf = dict(bound="hbm", kernel="k_propose<..., TAIL_OBS, RES, PLAIN>: the whole update of a group by one workgroup, resident "
+        rf = dict(bound="hbm", kernel="k_res_obs<256>: the whole update of a group by one workgroup, sixteen lanes per particle, resident "
                                       "over the iterations between two migrations",
                   achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
                   bytes_counted="24*D+17 per particle-update (SURVEY 8d); four workgroups on a 256-CU chip: the number says how little "

@@ -32,14 +32,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def dominant_pattern(over):
     """kernel-name pattern of the kernel the row's roofline is about (the default sampler on MvNormal-full runs in the lean
     resident kernel k_res_mvn; other samplers in k_propose<..., RES>)"""
-    cfg, mode = over.get("config", "cfg3"), over.get("mode", "streaming")
+    cfg, mode = over.get("config", "cfg3"), over.get("mode", "direct")  # (bench.py's default mode: the headline is DIRECT since round 6)
     if cfg == "cfg3" and mode == "streaming":
         return "k_cross_mfma"
-    if cfg == "cfg3" and mode == "direct":
+    if cfg in ("cfg2", "cfg3") and mode == "direct":
         return "k_direct_mvn"
     if cfg in ("cfg2", "cfg3"):
         return "k_res_mvn|k_propose<"  # (history partners: the lean body past burn-in, k_propose<256,false,...> inside it)
-    return {"cfg4": "k_longrow|k_frozen_sweep", "cfg5": "k_lba_wave|k_lba_loglike|k_obs_loglike", "cfg1": "k_propose<", "mvn30": "k_res_mvn|k_propose<"}[cfg]
+    return {"cfg4": "k_longrow|k_frozen_sweep", "cfg5": "k_lba_wave|k_lba_loglike|k_obs_loglike", "cfg1": "k_res_obs|k_propose<", "mvn30": "k_res_mvn|k_propose<"}[cfg]
 
 
 MFMA_CTRS = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_F64", "SQ_INSTS_VALU_MFMA_MOPS_F64", "GRBM_GUI_ACTIVE",
@@ -120,7 +120,7 @@ def main():
     os.makedirs(out_dir, exist_ok=True)
     for tag in (opt.rows or list(rows)):
         over = rows[tag]
-        cfg, mode = over.get("config", "cfg3"), over.get("mode", "streaming")
+        cfg, mode = over.get("config", "cfg3"), over.get("mode", "direct")
         n_iters = over.get("steps", 20) + over.get("warmup", 5)
         pattern = dominant_pattern(over)
         print(f"{tag}: {over}", flush=True)
@@ -148,7 +148,7 @@ def main():
         dom = dominant_kernel(totals, pattern, resident=True)
         if dom:
             e = res[dom]
-            resident = "k_propose<" in pattern and over.get("partners") != "history"
+            resident = ("k_propose<" in pattern or "k_res_obs" in pattern) and over.get("partners") != "history"
             rec = {"kernel": dom, "note": "HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 half-count of wide streaming reads)"}
             if resident:  # a launch covers several iterations: reduce to bytes per iteration over the whole run
                 rec["bytes_per_iteration"] = totals[dom] / n_iters
@@ -175,7 +175,7 @@ def main():
         json.dump(res, open(os.path.join(out_dir, f"bench_{tag}_pmc.json"), "w"), indent=1)
         if not opt.no_pipe:
             # pipe counters of the dominant kernel
-            mfma = (cfg in ("cfg2", "cfg3")) and mode == "streaming"
+            mfma = (cfg in ("cfg2", "cfg3")) and mode == "streaming"  # (DIRECT is vector-pipe work: VALU counters)
             ctrs = MFMA_CTRS if mfma else VALU_CTRS
             vals, grid = counters(run(out_dir, f"{tag}_pipe", ["--pmc"] + ctrs, prof))
             m = {}
