@@ -474,8 +474,9 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
                       traffic=traffic, traffic_source=src,
                       wasted_traffic_ratio=None if traffic is None else traffic / alg_bytes)
         elif a.mode == "direct":
-            t_s = tm["loglike"]["ms"] * 1e-3
-            n_launch = max(1, tm["loglike"]["launches"])
+            in_k1 = tm["loglike"]["launches"] == 0  # small populations: the residual loop runs inside the streaming-resident lean kernel
+            t_s = (fused_ms if in_k1 else tm["loglike"]["ms"]) * 1e-3
+            n_launch = max(1, tm["propose"]["launches"] if in_k1 else tm["loglike"]["launches"])
             dp = 8 if d <= 8 else 16 if d <= 16 else 32 if d <= 32 else 64
             # SURVEY 8(d)'s unit: 3*N*D per (proposal, observation, dimension) -- one subtraction, one fused multiply-add -- and 2*D^2
             # for m = L^-1 mu~ (K1's preparation on the matrix cores: it runs in k_propose, outside this kernel's time, and is 0.02 %
@@ -489,7 +490,9 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
             # what one launch must read and write: the whitened rows once (they are shared by every proposal: L2 / MALL serve the re-reads),
             # the proposals' m rows, the per-chunk partial sums
             alg_bytes = 8.0 * N * dp + (P / phases) * 8.0 * dp + (P / phases) * 8.0 * 48  # (48 chunks at cfg3: 12.6 MB of partial sums)
-            rf = dict(bound="valu", kernel=f"k_direct_mvn<{dp}> (thread per proposal, m = L^-1 mu~ in registers, wave-uniform z rows)",
+            rf = dict(bound="valu", kernel=(f"k_res_mvn<256,true,{dp},direct> (streaming-resident lean kernel: the residual loop out of an LDS copy of the "
+                                            "workgroup's chunk of whitened rows, every iteration up to the next migration in one launch)" if in_k1 else
+                                            f"k_direct_mvn<{dp}> (thread per proposal, m = L^-1 mu~ in registers, wave-uniform z rows)"),
                       achieved=ach, peak=PEAK_FP64_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP64_TFLOPS,
                       flop_counted="3*N*D per particle-update (SURVEY 8d's whitened residual form: v_add_f64 + v_fma_f64 per dimension; "
                                    "an add counts one flop, so 0.75 of the FMA peak is this form's ceiling at the nominal clock)",

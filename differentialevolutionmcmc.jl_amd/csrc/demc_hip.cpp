@@ -135,6 +135,8 @@ struct demc_handle {
     int ainv_lds = 1;
     // lean resident kernel of the default sampler on MvNormal-full (demc_resmvn.hpp): geometry for SUFFSTAT / STREAMING
     bool lean_ok = false, lean_stream_ok = false, lean_hist_ok = false;  // (lean_hist: DE-MC_Z past burn-in, k_res_mvn<..., HIST>)
+    bool st_dir_geo = false;   // plan_stream's geometry is valid for the DIRECT likelihood (k_res_mvn<..., DIR>; st_ok stays false)
+    bool lean_direct_ok = false;  // ... and the lean kernel's DIRECT streaming-resident instance serves this model
     bool lean_obs_ok = false;  // lean resident kernel of the default sampler on the per-observation families (demc_resobs.hpp)
     size_t lean_obs_lds = 0;
     int lean_wg = 0;
@@ -1026,7 +1028,7 @@ int launch_resident(demc_handle* h, long long iter0, int n_iters) {
 // ---- lean resident kernel (demc_resmvn.hpp): default sampler, MvNormal full Sigma, D = d <= 32, one pass per phase ----
 void plan_lean(demc_handle* h) {
     const demc_config& c = h->c;
-    h->lean_ok = h->lean_stream_ok = h->lean_hist_ok = false;
+    h->lean_ok = h->lean_stream_ok = h->lean_hist_ok = h->lean_direct_ok = false;
     // The per-observation families under the default sampler (demc_resobs.hpp): Gaussian, Binomial and the LNR with a handful of
     // parameters (a lane per scalar of a sixteen-lane particle) and few enough observations for sixteen lanes to walk them; the
     // group, its scratch rows and -- LNR -- the log Phi(-z) table in LDS.  Whether the SAMPLER is the default one is asked per step
@@ -1075,7 +1077,10 @@ void plan_lean(demc_handle* h) {
         if (t.kind == PR_NORMAL_REF) return;  // (hierarchical scale priors: the general kernel)
     const int nact_max = c.Np - c.Np / 2;
     if (nact_max * 4 > 512) return;
-    const int wg = nact_max * 4 > 256 ? 512 : 256;
+    // (DIRECT at D = 8: 512 threads whatever the group's size -- two waves per SIMD for the residual loop, which one wave per SIMD runs
+    // at half the vector pipe's rate: nothing else hides its LDS reads and dependent FP64 pairs)
+    const bool dir8 = c.loglike_mode == DEMC_LOGLIKE_DIRECT && c.D == 8 && nact_max * 4 <= 256;
+    const int wg = (nact_max * 4 > 256 || dir8) ? 512 : 256;
     const size_t D = (size_t)c.D, Np = (size_t)c.Np;
     const size_t base = (Np * D + Np + (size_t)nact_max + 16 + (size_t)(wg / 4) * (D + 2)) * sizeof(double);
     if (c.loglike_mode == DEMC_LOGLIKE_SUFFSTAT) {
@@ -1085,8 +1090,11 @@ void plan_lean(demc_handle* h) {
     }
     // STREAMING: only where the streaming-resident form applies (plan_stream: small populations), and only with one wave per
     // SIMD (256 threads: what the observation stage needs beyond 256 VGPRs then lives in AGPRs, not scratch)
-    if (!h->st_ok || wg != 256) return;
-    size_t bytes = base + ((size_t)(wg / 4) * h->dpad + (size_t)(wg / 64) * nact_max) * sizeof(double) + 16;
+    const bool dir = c.loglike_mode == DEMC_LOGLIKE_DIRECT;
+    if (!(dir ? h->st_dir_geo : h->st_ok) || (wg != 256 && !dir8)) return;
+    // (DIRECT: the instances with the row length compiled in, the chunk of whitened rows in LDS, MvNormal-full)
+    if (dir && !(h->family == FAM_MVN_FULL && h->n_seg == 1 && (c.D == 8 || c.D == 32) && h->dp_direct == c.D && h->dpad == c.D && h->st_x_lds)) return;
+    size_t bytes = base + ((size_t)(wg / 4) * h->dpad + (size_t)(dir ? wg / 16 : wg / 64) * nact_max) * sizeof(double) + 16;  // (DIRECT: a partial sum per 16-lane row)
     if (bytes > kMaxDynLds) return;
     const size_t xbytes = (size_t)(h->st_chunk_tiles + 1) * (h->dpad / 4) * 64 * sizeof(double);
     // (the X chunk rides in LDS exactly when plan_stream found room for it; this kernel's other buffers are no larger)
@@ -1094,8 +1102,9 @@ void plan_lean(demc_handle* h) {
         if (bytes + xbytes > kMaxDynLds) return;
         bytes += xbytes;
     }
-    h->lean_stream_ok = true; h->lean_wg = wg; h->lean_stream_lds = bytes;
+    h->lean_stream_ok = !dir; h->lean_direct_ok = dir; h->lean_wg = wg; h->lean_stream_lds = bytes;
     h->lean_st_C = h->st_C; h->lean_st_chunk_tiles = h->st_chunk_tiles; h->lean_st_x_lds = h->st_x_lds; h->lean_st_occ = 1;
+    if (dir) return;
 #ifdef DEMC_EXPERIMENTS
     // A/B builds only (DEMC_LEAN_OCC2=1) -- TWO workgroups per CU (D = 8, the instance compiled for it): twice the chunks, so that
     // the grid is twice the CU count and a CU holds workgroups of two different groups ("two latency chains on a
@@ -1130,6 +1139,8 @@ int launch_lean(demc_handle* h, long long iter0, int n_iters, bool stream) {
     if (stream) {
         k.st_C = h->lean_st_C; k.st_nact_max = h->st_nact_max; k.st_x_lds = h->lean_st_x_lds; k.st_chunk_tiles = h->lean_st_chunk_tiles;
         k.n_tiles = h->n_tiles; k.Xf = h->Xf; k.st_gran = h->st_gran; k.st_err = h->st_err;
+        k.st_rows = 0;
+        if (const char* e = experiment("DEMC_OCC2_DELAY")) k.st_rows = std::atoi(e);  // A/B experiments (k_res_mvn<...,OCC 2>: start offset in cycles)
         if (k.n_groups * h->lean_st_C > h->n_cus * h->lean_st_occ) return fail(h, DEMC_EINVAL, "streaming-resident grid exceeds what is resident at once");
         HIPCHK(hipMemsetAsync(h->st_gran, 0, 2 * (size_t)c.n_groups * h->lean_st_C * h->st_nact_max * 2 * sizeof(unsigned long long), h->stream));
     }
@@ -1140,12 +1151,14 @@ int launch_lean(demc_handle* h, long long iter0, int n_iters, bool stream) {
     const int dt = (h->n_seg == 1 && (c.D == 32 || c.D == 8)) ? c.D : 0;
     h->last = demc_handle::LastPlan();
     h->last.k1 = 4; h->last.wg = h->lean_wg; h->last.stream = stream; h->last.dt = dt;
+    h->last.big = stream && h->lean_direct_ok;  // (the DIRECT instance: named below)
     void (*fn)(KParams) = nullptr;
 #ifdef DEMC_EXPERIMENTS
     if (stream && h->lean_st_occ == 2) fn = k_res_mvn<256, true, 8, 0, 2>;  // (plan_lean: D = 8 only)
     else
 #endif
-    if (stream) fn = dt == 8 ? k_res_mvn<256, true, 8> : dt == 32 ? k_res_mvn<256, true, 32> : k_res_mvn<256, true, 0>;
+    if (stream && h->lean_direct_ok) fn = dt == 8 ? k_res_mvn<512, true, 8, 0, 1, false, true> : k_res_mvn<256, true, 32, 0, 1, false, true>;
+    else if (stream) fn = dt == 8 ? k_res_mvn<256, true, 8> : dt == 32 ? k_res_mvn<256, true, 32> : k_res_mvn<256, true, 0>;
     else if (h->lean_wg == 512) fn = dt == 8 ? k_res_mvn<512, false, 8> : dt == 32 ? k_res_mvn<512, false, 32> : k_res_mvn<512, false, 0>;
     else fn = dt == 8 ? k_res_mvn<256, false, 8> : dt == 32 ? k_res_mvn<256, false, 32> : k_res_mvn<256, false, 0>;
     LAUNCH_T(h, fn, dim3(grid), dim3(h->lean_wg), lds, k);
@@ -1233,7 +1246,11 @@ K1Fn k1_stream_instance(int wg, int tail, int lean) {
 void plan_stream(demc_handle* h) {
     const demc_config& c = h->c;
     h->st_ok = false;
-    if (!is_mvn(h->family) || c.loglike_mode != DEMC_LOGLIKE_STREAMING || c.fuse != 0 || c.schedule != DEMC_SCHED_TWO_COLOUR ||
+    h->st_dir_geo = false;
+    // (DIRECT: the same geometry -- chunks of the observations per workgroup, hand-over granules -- serves the lean kernel's DIRECT
+    // instance only, plan_lean; the general streaming-resident kernel has no such form, so st_ok stays false)
+    const bool direct = c.loglike_mode == DEMC_LOGLIKE_DIRECT;
+    if (!is_mvn(h->family) || (c.loglike_mode != DEMC_LOGLIKE_STREAMING && !direct) || c.fuse != 0 || c.schedule != DEMC_SCHED_TWO_COLOUR ||
         c.partner_kind != DEMC_PARTNER_CURRENT || c.Np < 4 || h->n_cus < 1 || h->geo_groups > h->n_cus || c.n_groups > h->n_cus ||
         h->dpad > 64 || h->n_kpass != 1)
         return;
@@ -1275,7 +1292,8 @@ void plan_stream(demc_handle* h) {
         if (hipHostMalloc((void**)&h->st_err, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) return;
         *h->st_err = 0u;
     }
-    h->st_ok = true; h->st_C = C; h->st_nact_max = nact_max; h->st_rows = rows; h->st_x_lds = x_lds; h->st_chunk_tiles = chunk;
+    h->st_ok = !direct; h->st_dir_geo = direct;
+    h->st_C = C; h->st_nact_max = nact_max; h->st_rows = rows; h->st_x_lds = x_lds; h->st_chunk_tiles = chunk;
     h->st_lpp = lpp; h->st_scr_doubles = (int)scr_doubles; h->st_lds = bytes; h->st_wg = wg;
 }
 
@@ -1453,6 +1471,7 @@ int size_k1_lds(demc_handle* h) {
         void (*lean[])(KParams) = {k_res_mvn<256, false, 0>, k_res_mvn<256, false, 8>, k_res_mvn<256, false, 32>,
                                    k_res_mvn<512, false, 0>, k_res_mvn<512, false, 8>, k_res_mvn<512, false, 32>,
                                    k_res_mvn<256, true, 0>,  k_res_mvn<256, true, 8>,  k_res_mvn<256, true, 32>,
+                                   k_res_mvn<512, true, 8, 0, 1, false, true>, k_res_mvn<256, true, 32, 0, 1, false, true>,
 #ifdef DEMC_EXPERIMENTS
                                    k_res_mvn<256, true, 8, 0, 2>,
 #endif
@@ -2337,12 +2356,14 @@ static int step_body(demc_handle* h, int64_t iter0, int32_t n_iters, bool with_m
         kp0.mode = MODE_STEP;
         const bool plain = is_plain(h, kp0);
         const bool obs_lean = h->lean_obs_ok && plain;
-        if ((h->res_ok || st_ok || obs_lean) && !h->rp_active) {  // every iteration up to the next migration in one launch
+        const bool dir_lean = h->lean_direct_ok && plain && !h->cur_glist;  // (its workgroups wait on each other: never on a subset)
+        if ((h->res_ok || st_ok || obs_lean || dir_lean) && !h->rp_active) {  // every iteration up to the next migration in one launch
             int run = 1;  // capped so that a single launch stays in the millisecond range whatever the caller asks for
-            const int cap = st_ok ? 64 : 1024;
+            const int cap = (st_ok || dir_lean) ? 64 : 1024;
             while (run < cap && iter + run < iter0 + n_iters && !(with_migration && migration_due_h(h, iter + run))) ++run;
             int rc;
-            if (st_ok && plain && h->lean_stream_ok) rc = launch_lean(h, iter, run, true);
+            if (dir_lean) rc = launch_lean(h, iter, run, true);
+            else if (st_ok && plain && h->lean_stream_ok) rc = launch_lean(h, iter, run, true);
             else if (!st_ok && plain && h->lean_ok) rc = launch_lean(h, iter, run, false);
             else if (obs_lean) rc = launch_lean_obs(h, iter, run);
             else rc = st_ok ? launch_stream(h, iter, run) : launch_resident(h, iter, run);
@@ -2993,6 +3014,7 @@ int32_t demc_last_kernels(demc_handle* h, char* out, int32_t nbytes) {
         case 4:
             if (L.hist && L.iso) std::snprintf(buf, sizeof buf, "k_res_mvn<%d,%s,%d,%d,iso>", L.wg, tf[L.stream != 0], L.dt, L.hist);
             else if (L.hist) std::snprintf(buf, sizeof buf, "k_res_mvn<%d,%s,%d,%d>", L.wg, tf[L.stream != 0], L.dt, L.hist);
+            else if (L.big) std::snprintf(buf, sizeof buf, "k_res_mvn<%d,%s,%d,direct>", L.wg, tf[L.stream != 0], L.dt);
             else std::snprintf(buf, sizeof buf, "k_res_mvn<%d,%s,%d>", L.wg, tf[L.stream != 0], L.dt);
             break;
         default: break;

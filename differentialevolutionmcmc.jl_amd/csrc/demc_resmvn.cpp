@@ -7,6 +7,7 @@
 namespace demc {
 #define DEMC_X_(...) template __global__ void k_res_mvn<__VA_ARGS__>(KParams);
 DEMC_RESMVN_INSTANCES(DEMC_X_)
+DEMC_RESMVN_INSTANCES_DIR(DEMC_X_)
 DEMC_RESMVN_INSTANCES_EXP(DEMC_X_)
 #undef DEMC_X_
 }  // namespace demc

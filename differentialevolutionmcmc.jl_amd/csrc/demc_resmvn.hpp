@@ -53,9 +53,18 @@ namespace demc {
 // the quad -- aux = |mu - xbar|^2 and S = (mu - xbar) . sum_i x~_i are eight products per lane and one quad sum each, sigma comes
 // from the lane that holds scalar d -- no A^-1, no LDS transposition, no matrix stage; the prior table has two segments (Normal on
 // mu, Cauchy+ on sigma).  HIST instances only: with current-population partners the general kernel's lean instances serve it.
-template <int WG, bool STREAM, int DT = 0, int HIST_ = 0, int OCC = 1, bool ISO = false>
+// DIR (round 6; STREAM instances with the row length compiled in): the streaming-resident form in DIRECT mode -- the likelihood in
+// the residual form the reference writes (test/multivariate_normal_tests.jl:31-33), sum_i |z_i - m|^2 term by term with z_i = L^-1 x~_i
+// whitened once and m = L^-1 (theta' - xbar) per proposal (SURVEY 8d's 3 N D per update: the work that does not collapse), on the
+// FP64 vector pipe: the workgroup's chunk of whitened rows rides in LDS where the MFMA form keeps its fragment-ordered tiles, the
+// proposal stage leaves m where it left y (the host hands (L^-1)' over in place of Sigma^-1), and a thread walks every n-th row of
+// the chunk for ONE proposal with m in registers (rows are LDS broadcasts: the lanes of a slice read the same address).  Hand-over,
+// decisions and stores are the streaming form's.  For populations too small to fill the chip with the K1 -> k_direct_mvn -> K3
+// chain (BASELINE cfg2: six dependent launches per iteration for 4.9e8 flop).
+template <int WG, bool STREAM, int DT = 0, int HIST_ = 0, int OCC = 1, bool ISO = false, bool DIR = false>
 __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) void k_res_mvn(KParams p) {
     constexpr bool HIST = HIST_ != 0;
+    static_assert(!DIR || (STREAM && DT > 0 && (DT & 1) == 0), "the DIRECT form: streaming-resident instances with an even row length compiled in");
     static_assert(!(HIST && STREAM), "history partners: the SUFFSTAT form only");
     static_assert(!ISO || (HIST && (DT == 0 || DT == 31)), "the isotropic form: DE-MC_Z instances, general row length or D = 31 (the reference's test)");
     // (one iteration per launch: launch_lean_hist never asks for more, and checks it; the kernel's own guard is the trip count of
@@ -102,7 +111,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
     double* scr = coff + 16;
     double* ybuf = scr + (size_t)(WG / 4) * scr_stride;
     double* part_l = ybuf + (STREAM ? (size_t)(WG / 4) * p.dpad : 0);
-    double* xs = reinterpret_cast<double*>((reinterpret_cast<size_t>(part_l + (STREAM ? (size_t)(WG / 64) * nact_max : 0)) + 15) & ~(size_t)15);
+    double* xs = reinterpret_cast<double*>((reinterpret_cast<size_t>(part_l + (STREAM ? (size_t)(DIR ? WG / 16 : WG / 64) * nact_max : 0)) + 15) & ~(size_t)15);
     const int xt_lo = STREAM ? c_idx * p.st_chunk_tiles : 0;
     const int xt_hi = STREAM ? (xt_lo + p.st_chunk_tiles < p.n_tiles ? xt_lo + p.st_chunk_tiles : p.n_tiles) : 0;
 
@@ -122,13 +131,19 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
     }
     if (STREAM) {
         for (int i = tid; i < (WG / 4) * p.dpad; i += WG) ybuf[i] = 0.0;
-        if (p.st_x_lds && xt_lo < xt_hi) {
+        if (DIR && xt_lo < xt_hi) {  // the chunk's whitened rows z_i [obs][DT], row-major (demc_set_model, DIRECT)
+            const long long o_hi = (long long)xt_hi * 16 < p.N ? (long long)xt_hi * 16 : p.N;
+            const double* src = p.data + (size_t)xt_lo * 16 * DT;
+            const int n16 = (int)(((o_hi - (long long)xt_lo * 16) * DT) >> 1);
+            for (int c0 = wave * 64; c0 < n16; c0 += WG)
+                if (c0 + lane < n16) lds_dma16(src + 2 * (size_t)(c0 + lane), xs + 2 * (size_t)c0);
+        } else if (p.st_x_lds && xt_lo < xt_hi) {
             const double* src = p.Xf + (size_t)xt_lo * (p.dpad >> 2) * 64;
             const int n16 = ((xt_hi - xt_lo) * (p.dpad >> 2) * 64) >> 1;
             for (int c0 = wave * 64; c0 < n16; c0 += WG)
                 if (c0 + lane < n16) lds_dma16(src + 2 * (size_t)(c0 + lane), xs + 2 * (size_t)c0);
         }
-        if (p.st_x_lds)
+        if (!DIR && p.st_x_lds)
             for (int i = tid; i < (p.dpad >> 2) * 64; i += WG) xs[(size_t)p.st_chunk_tiles * (p.dpad >> 2) * 64 + i] = 0.0;
     }
     // lane geometry: particle slot q = tid / 4 of the pass, lane sl of the particle owns noise blocks m = sl and sl + 4,
@@ -324,6 +339,16 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
     // the three-round cumulative weights or the two-level base pick move the phase: it is a chain of dependent latencies at two
     // waves per SIMD with the vector pipe 0.39 busy, not a count of instructions.)
     if (STREAM) draw_phase(0, pre_mine, pre_nzA, pre_nzB);
+#ifdef DEMC_EXPERIMENTS
+    if constexpr (STREAM && OCC == 2) {
+        // A/B only: the second workgroup of every CU (the upper half of the grid: other groups) starts p.st_rows shader cycles late,
+        // so that the two workgroups of a CU run OUT of step -- one's matrix stage under the other's proposal / hand-over stages
+        if (p.st_rows > 0 && blockIdx.x >= gridDim.x / 2) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)p.st_rows) __builtin_amdgcn_s_sleep(8);
+        }
+    }
+#endif
     for (long long step = 0; step < n_steps; ++step) {
         DEMC_STAMP_RESET();
         const int ph = (int)(step & 1);
@@ -703,7 +728,84 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
             // ---- the observation stream: cross terms of the phase's proposals against this workgroup's chunk of tiles ----
             lds_barrier();  // (LDS only: see the end of the phase)
             DEMC_STAMP(16);  // every proposal of the phase prepared
-            {
+            if constexpr (DIR) {
+                // sum_i |z_i - m|^2 over the chunk's rows for every proposal of the phase.  A thread holds HALF a row's worth of m for PB
+                // proposals in registers and walks every n-th row of the chunk: what it reads of a row from LDS serves PB proposals,
+                // and the two halves of a row are read by neighbouring lane groups -- a wave's eight groups then touch FOUR consecutive
+                // rows (64 bytes apart: all 64 banks once) instead of eight (rows r and r + 4 on the same banks: every read a 2-way
+                // conflict, the LDS pipe as busy as the vector pipe and the two serialised).  One proposal per thread and whole rows
+                // (the first form) left the LDS pipe four times as busy: 17 us of a 21 us phase at BASELINE cfg2.
+                constexpr int PB = 4, HD = DT / 2;                                           // proposals per thread, dims per half row
+                const int n_pg = (n_act + PB - 1) / PB;                                      // groups of PB proposals
+                const int pg_pad = n_pg <= 4 ? 4 : n_pg <= 8 ? 8 : 16;                       // (wave-uniform; n_act <= 64)
+                const int pgi = tid & (pg_pad - 1), hs = (tid / pg_pad) & 1, slice = tid / (2 * pg_pad), n_slices = WG / (2 * pg_pad);
+                double m[PB][HD];
+#pragma unroll
+                for (int j = 0; j < PB; ++j)
+#pragma unroll
+                    for (int k = 0; k < HD; ++k)  // (proposals pgi, pgi + pg_pad, ...: neighbouring lanes read neighbouring m rows -- with
+                                                  // proposals pgi PB .. pgi PB + PB - 1 the rows of a wave's lanes sat PB x 64 bytes apart, all on the same banks)
+                        m[j][k] = pgi + j * pg_pad < n_act ? ybuf[(size_t)(pgi + j * pg_pad) * DT + hs * HD + k] : 0.0;  // (dpad == DT)
+                DEMC_STAMP(20);  // m in registers
+                const long long o_hi = (long long)xt_hi * 16 < p.N ? (long long)xt_hi * 16 : p.N;
+                const int n_obs = xt_lo < xt_hi ? (int)(o_hi - (long long)xt_lo * 16) : 0;
+                double a2[PB][2];
+#pragma unroll
+                for (int j = 0; j < PB; ++j) a2[j][0] = a2[j][1] = 0.0;
+                const lds_cptr zs = (lds_cptr)xs + hs * HD;  // (xs went through an integer round-up: without the cast the row reads are FLAT loads)
+                // UR rows per trip, all of them read before the first is used: the compiler puts a trip's reads at its top and waits for
+                // each where it is consumed, so the LDS round trip is paid once per UR rows (with one row per trip the younger of a
+                // SIMD's two waves ended 4.5 k cycles after the older one: a 10 k-cycle loop, 15 k until the barrier let go)
+                constexpr int UR = HD <= 4 ? 4 : 1;  // (D = 32: a row half is sixteen doubles -- one row per trip keeps the instance off scratch)
+                auto accumulate = [&](const double (&zc)[HD]) {
+#pragma unroll
+                    for (int k = 0; k < HD; k += 2) {
+                        double r[PB][2];  // (the 2 x PB residuals of a dim pair before the 2 x PB FMAs that consume them)
+#pragma unroll
+                        for (int j = 0; j < PB; ++j) {
+                            r[j][0] = zc[k] - m[j][k];
+                            r[j][1] = zc[k + 1] - m[j][k + 1];
+                        }
+#pragma unroll
+                        for (int j = 0; j < PB; ++j) {
+                            a2[j][0] = fma(r[j][0], r[j][0], a2[j][0]);
+                            a2[j][1] = fma(r[j][1], r[j][1], a2[j][1]);
+                        }
+                    }
+                };
+                int o = slice;
+                for (; o + (UR - 1) * n_slices < n_obs; o += UR * n_slices) {
+                    double zr[UR][HD];
+#pragma unroll
+                    for (int u = 0; u < UR; ++u) {
+                        const lds_cptr z = zs + (size_t)(o + u * n_slices) * DT;
+#pragma unroll
+                        for (int k = 0; k < HD; ++k) zr[u][k] = z[k];
+                    }
+#pragma unroll
+                    for (int u = 0; u < UR; ++u) accumulate(zr[u]);
+                }
+                for (; o < n_obs; o += n_slices) {  // (the last rows of the slice)
+                    const lds_cptr z = zs + (size_t)o * DT;
+                    double zc[HD];
+#pragma unroll
+                    for (int k = 0; k < HD; ++k) zc[k] = z[k];
+                    accumulate(zc);
+                }
+                DEMC_STAMP(21);  // residual loop done
+                // The lanes of a 16-lane row that hold the same proposals (the two halves of the rows, the row's slices) are added on
+                // the DPP network; every ROW then leaves its partial sums in LDS and the hand-over below adds the WG / 16 of them in a
+                // fixed order.  (Summed across the wave with __shfl_xor -- sixteen dependent ds_bpermute round trips a thread -- this
+                // step took 6 k cycles of a 25 k-cycle phase.)
+#pragma unroll
+                for (int j = 0; j < PB; ++j) {
+                    double v = a2[j][0] + a2[j][1];
+                    if (pg_pad <= 8) v += dpp_mov<0x128>(v);  // row_ror:8
+                    if (pg_pad <= 4) v += dpp_mov<0x124>(v);  // row_ror:4
+                    if ((lane & 15) < pg_pad && pgi + j * pg_pad < n_act) part_l[(size_t)(tid >> 4) * nact_max + pgi + j * pg_pad] = v;
+                }
+                DEMC_STAMP(15);  // row partials in LDS
+            } else {
                 const int nw_ = WG / 64;
                 const int nt = xt_hi - xt_lo, per_w = (nt + nw_ - 1) / nw_;
                 const int t_lo = wave * per_w < nt ? wave * per_w : nt, t_hi = t_lo + per_w < nt ? t_lo + per_w : nt;
@@ -726,7 +828,13 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
             unsigned long long* gran = p.st_gran + (((size_t)(step & 1) * p.n_groups + gi) * p.st_C) * nact_max * 2;
             if (tid < n_act) {
                 double v = 0.0;
-                for (int wv = 0; wv < WG / 64; ++wv) v += part_l[(size_t)wv * nact_max + tid];
+                if constexpr (DIR) {  // a partial per 16-lane row: four chains, then a fixed tree (32 dependent FP64 additions were 2 k cycles)
+                    double v4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int wv = 0; wv < WG / 16; ++wv) v4[wv & 3] += part_l[(size_t)wv * nact_max + tid];
+                    v = (v4[0] + v4[1]) + (v4[2] + v4[3]);
+                } else
+                    for (int wv = 0; wv < WG / 64; ++wv) v += part_l[(size_t)wv * nact_max + tid];
                 unsigned long long* mine_g = gran + ((size_t)c_idx * nact_max + tid) * 2;
                 store_granule(mine_g, epoch, (unsigned)__double2loint(v));
                 store_granule(mine_g + 1, epoch, (unsigned)__double2hiint(v));
@@ -783,7 +891,9 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
         if constexpr (ISO) {  // loglike_from_stats' MVN_ISO form (c1 = sum_i |x~_i|^2)
             const double nd = (double)p.N * (double)d;
             wp = oob ? -INFINITY : prior + (-0.5 * nd * kLog2Pi - nd * log(sg_iso) - 0.5 * (p.c1 - 2.0 * S + (double)p.N * aux) / (sg_iso * sg_iso));
-        } else
+        } else if constexpr (DIR)
+            wp = oob ? -INFINITY : prior + (p.c0 - 0.5 * S);  // loglike_from_stats' DIRECT form: S = sum_i |L^-1 (x_i - mu)|^2
+        else
             wp = oob ? -INFINITY : prior + (p.c0 - 0.5 * (p.c1 - 2.0 * S + (double)p.N * aux));
         double adj = 0.0;
         if constexpr (HSNK) {
@@ -907,6 +1017,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
     X(256, true, 0, 0, 1, false) \
     X(256, true, 8, 0, 1, false) \
     X(256, true, 32, 0, 1, false)
+#define DEMC_RESMVN_INSTANCES_DIR(X) X(512, true, 8, 0, 1, false, true) X(256, true, 32, 0, 1, false, true)  // the DIRECT streaming-resident form
 #ifdef DEMC_EXPERIMENTS
 #define DEMC_RESMVN_INSTANCES_EXP(X) X(256, true, 8, 0, 2, false)  // A/B only: two streaming workgroups per CU
 #else
@@ -915,6 +1026,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
 #ifdef DEMC_RESMVN_EXTERN
 #define DEMC_X_(...) extern template __global__ void k_res_mvn<__VA_ARGS__>(KParams);
 DEMC_RESMVN_INSTANCES(DEMC_X_)
+DEMC_RESMVN_INSTANCES_DIR(DEMC_X_)
 DEMC_RESMVN_INSTANCES_EXP(DEMC_X_)
 #undef DEMC_X_
 #endif

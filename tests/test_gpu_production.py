@@ -609,6 +609,26 @@ def test_cfg3_geometry_direct_chain(demc, orc, beta):
              theta_exact=beta == 0.0, beta=beta, loglike_mode=2, geometry_groups=256)
 
 
+@pytest.mark.parametrize("shape,beta", [("cfg2", 0.0), ("cfg2", 0.1), ("cfg2_ragged", 0.1), ("d32", 0.1), ("d32_small_groups", 0.0)])
+def test_direct_likelihood_in_the_streaming_resident_lean_kernel(demc, orc, shape, beta):
+    """DIRECT mode on a population too small to fill the chip with the K1 -> k_direct_mvn -> K3 chain (BASELINE cfg2: 32 x 64, D = 8,
+    N = 1e4 -- six dependent launches an iteration): the streaming-resident lean kernel's DIRECT instance, the residual form
+    sum_i |z_i - m|^2 term by term on the vector pipe out of an LDS copy of the workgroup's chunk of whitened rows, C workgroups
+    per group handing their sums over.  Free-running against the oracle (whose MvNormal likelihood IS the whitened residual form,
+    oracle/demc_oracle.c:490-505): cfg2 as benchmarked; an observation count that leaves the last chunk short and ragged; D = 32
+    (the proposal's m through the matrix-core preparation) with 32 and with 9 / 10 moving particles (slices of 32 and of 16 lanes)."""
+    from demc_amd import workloads as W
+    if shape == "cfg2":
+        w, kern = W.cfg2(), "k_res_mvn<512,true,8,direct>"
+    elif shape == "cfg2_ragged":
+        w, kern = W.cfg2(N=2050), "k_res_mvn<512,true,8,direct>"
+    elif shape == "d32":
+        w, kern = W.cfg3(N=3000, G=16, Np=64), "k_res_mvn<256,true,32,direct>"
+    else:
+        w, kern = W.cfg3(N=1500, G=12, Np=19), "k_res_mvn<256,true,32,direct>"
+    free_run(demc, orc, w, 10, [], w["G"], w["Np"], theta_exact=beta == 0.0, exact_kernels=kern, beta=beta, loglike_mode=2, alpha=0.3)
+
+
 def test_the_three_likelihood_modes_make_the_same_decisions(demc):
     """STREAMING (expanded form on the matrix cores), SUFFSTAT and DIRECT are three evaluation orders of one log-density:
     same proposals, same accept decisions, log-posteriors to rounding -- cfg2's shape, 40 iterations"""
@@ -625,7 +645,8 @@ def test_the_three_likelihood_modes_make_the_same_decisions(demc):
         outs.append(e.get_history(0, n_it))
         names.append(e.last_kernels())
         e.close()
-    assert "k_res_mvn<256,true,8>" in names[0] and "k_res_mvn<256,false,8>" in names[1] and "k_direct_mvn<8>" in names[2], names
+    # (round 6: a population this small takes the DIRECT likelihood inside the streaming-resident lean kernel too)
+    assert "k_res_mvn<256,true,8>" in names[0] and "k_res_mvn<256,false,8>" in names[1] and names[2] == "k_res_mvn<512,true,8,direct>", names
     for other in outs[1:]:
         assert np.array_equal(outs[0][1], other[1]) and np.array_equal(outs[0][3], other[3])
         assert np.array_equal(outs[0][0], other[0])

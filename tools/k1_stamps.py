@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, "differentialevolutionmcmc.jl_amd", "csrc")
 if os.environ.get("STAMPS_PREBUILT") != "1":  # (build here and ship the library to the GPU box: STAMPS_PREBUILT=1 skips the make)
-  subprocess.check_call(["make", "-B", "-j2", "-C", csrc, "-s", "STAMPS=1", "OUT=../libdemc_hip_stamps.so"] +
+  subprocess.check_call(["make", "-B", "-j8", "-C", csrc, "-s", "STAMPS=1", "OUT=../libdemc_hip_stamps.so"] +
                         (["STAMP_PASS=" + os.environ["STAMP_PASS"]] if "STAMP_PASS" in os.environ else []) +
                         (["EXTRA=" + os.environ["STAMP_EXTRA"]] if "STAMP_EXTRA" in os.environ else []))  # e.g. -DDEMC_X_...=1 experiments
 import demc_amd  # noqa: E402
@@ -53,7 +53,7 @@ else:
     prob = W.cfg3(N=a.nobs, d=a.dim, G=a.n_groups, Np=a.Np)
     hist = a.partners == "history"
     eng = demc_amd.HipEngine(n_groups=a.n_groups, Np=a.Np, D=a.dim, n_rows=60 if hist else 40, schedule=1 if hist else 2, seed=1,
-                             loglike_mode=1 if a.mode == "suffstat" else 0, trace=0,
+                             loglike_mode=1 if a.mode == "suffstat" else 2 if a.mode == "direct" else 0, trace=0,
                              **(dict(partner_kind=1, n_initial=16, burnin=0) if hist else {}))
     W.configure(eng, prob)
     rng0 = np.random.default_rng(20260003)
@@ -84,7 +84,7 @@ if os.environ.get("STAMP_TIMELINE") == "1":  # STAMP_EXTRA=-DDEMC_STAMPS_TIMELIN
     print("  mutation particles take %.1f us (median), the others %.1f" % (np.median((en - st)[mut]) if mut.any() else float("nan"),
                                                                           np.median((en - st)[~mut])))
     sys.exit(0)
-if a.mode == "streaming":
+if a.mode in ("streaming", "direct"):
     n_wg = len(w_prop) // 24  # streaming-resident form: several workgroups per group
 n_wg = min(n_wg, len(w_prop) // 24)  # the stamps live in the P-long trace array, 24 per workgroup
 full = w_prop[: n_wg * 24].reshape(n_wg, 24)
@@ -123,7 +123,7 @@ if ran.startswith("k_res_mvn"):
                         ("accept + row moves", 9), ("end of the phase (after its barrier)", 10)):
         print(f"  {label:80s} {med[slot]:9.0f}  (+{med[slot] - prev:7.0f})")
         prev = med[slot]
-    if a.mode != "streaming":
+    if a.mode not in ("streaming", "direct"):
         sys.exit(0)
     prev = 0.0
 print(f"{len(t)} workgroups; cycles since kernel start (median), and the step")
@@ -134,10 +134,12 @@ ex = np.median(full[:, [11, 13]], 0)
 print(f"  also: plan written (before the tile wait) {ex[0]:.0f}; A^-1 fragments in registers (before pass 0) {ex[1]:.0f}")
 pro = np.median(full[:, [12, 14, 15]], 0)
 print(f"  inside the prologue: group coin {pro[0]:.0f}; weights / A^-1 parked {pro[1]:.0f}; tile copy issued {pro[2]:.0f}")
-if a.mode == "streaming" and (full[:, 16] > 0).any():
+if a.mode in ("streaming", "direct") and (full[:, 16] > 0).any():
     st = np.median(full[full[:, 16] > 0][:, 16:21], 0)
     print("  streaming-resident: all proposals prepared %.0f; chunk cross terms %.0f; granules stored %.0f; collected %.0f; "
           "accept + moves done %.0f" % tuple(st))
+    if a.mode == "direct":  # (the DIRECT instance: its residual stage from the inside -- slots 20, 21)
+        print("  DIRECT stage: m in registers %.0f; residual loop done %.0f; row partials in LDS %.0f" % (tuple(np.median(full[full[:, 16] > 0][:, 20:22], 0)) + (np.median(full[full[:, 16] > 0][:, 15]),)))
     if (full[:, 23] > 0).any():  # k_res_mvn: store / collect times of the workgroups of a group on one clock (slots 22, 23)
         # (blockIdx = j * 8 + xcd; workgroup c of group g = 8 * (j / C) + xcd sits at j = (g / 8) * C + c; the trace holds the first P / 24 blocks)
         C = 8
