@@ -216,6 +216,10 @@ class HipEngine:
                     self.L.demc_destroy(self.h)
                     self.h = C.c_void_p()
                 raise DemcError(rc, msg)
+            note = self.L.demc_last_error(self.h)
+            if note and note.decode().startswith("note:"):  # a documented deviation in force on this handle (e.g. shard-local DE-MC_Z)
+                import warnings
+                warnings.warn(note.decode()[6:], stacklevel=2)
         self.P = self.cfg.n_groups * self.cfg.Np
         self.D = self.cfg.D
 

@@ -1643,6 +1643,13 @@ int32_t demc_create(const demc_config* cfg, demc_handle** out) {
     int rc_lds = size_k1_lds(h);
     if (rc_lds != DEMC_OK) return rc_lds;
     if (2 * (size_t)c.n_groups_total * sizeof(int) > 48 * 1024) return fail(h, DEMC_EINVAL, "n_groups_total too large");
+    // A documented deviation says so at run time: `resample` draws its partner cells from the history of ALL
+    // particles (crossover.jl:116-124); a shard holds the history of its own groups only.  Not an error -- SURVEY 8(e) allows the
+    // shard-local pool -- but the caller is told: demc_last_error() carries the note after a successful demc_create.
+    if (c.partner_kind == DEMC_PARTNER_HISTORY && c.n_groups_total > c.n_groups)
+        h->err = "note: sharded handle (" + std::to_string(c.n_groups) + " of " + std::to_string(c.n_groups_total) +
+                 " groups) with history partners: DE-MC_Z draws its partner cells from THIS shard's history only "
+                 "(the reference draws from all particles, crossover.jl:116-124)";
     return DEMC_OK;
     });
 }

@@ -151,6 +151,9 @@ typedef struct demc_handle demc_handle;
 int32_t demc_version(void);
 int32_t demc_create(const demc_config* cfg, demc_handle** out);
 int32_t demc_destroy(demc_handle* h);
+/* The message of the last failed call on the handle -- or, after a SUCCESSFUL call, a line that starts with "note:" when a
+ * documented deviation is in force (demc_create on a shard with history partners: the partner pool is the shard's own history;
+ * demc_set_model / demc_set_blocks: a scratch buffer that could not be allocated and the slower path taken instead). */
 const char* demc_last_error(demc_handle* h);
 /* Enqueue on an existing HIP stream (hipStream_t passed as void*; NULL -> the handle's own stream). */
 int32_t demc_set_stream(demc_handle* h, void* hip_stream);

@@ -392,3 +392,20 @@ def test_bench_sharded_rows_of_the_8_gpu_configs_at_world_one():
     assert [c["name"] for c in line["rows"]] == ["cfg4_sharded", "cfg5_sharded"] and line["rows"][0]["all_gathers_per_rank"] == rows["cfg4_sharded"]["all_gathers_per_rank"]
     rec = json.load(open(os.path.join(ROOT, "gpurun_out", "rank0.json")))
     assert [x["name"] for x in rec["rows"]] == ["cfg4_sharded", "cfg5_sharded"] and rec["rows"][0]["all_gathers"] == rows["cfg4_sharded"]["all_gathers_per_rank"][0]
+
+
+def test_a_shard_with_history_partners_says_that_its_pool_is_local(D):
+    """DE-MC_Z under sharding is a documented deviation: `resample` (crossover.jl:116-124) draws from the
+    history of all particles, a shard from its own groups' history.  The one-process-per-GPU road says so at run time: demc_create
+    leaves a note in demc_last_error and the Python host turns it into a warning; an unsharded handle, or a sharded one with
+    partners from the current population, says nothing."""
+    import warnings
+    cfg = dict(Np=8, D=3, n_rows=12, n_initial=2, schedule=1, seed=5)
+    with pytest.warns(UserWarning, match="THIS shard's history only"):
+        e = D.HipEngine(n_groups=4, n_groups_total=8, group_offset=4, partner_kind=1, **cfg)
+    assert e.L.demc_last_error(e.h).decode().startswith("note: sharded handle (4 of 8 groups)")
+    e.close()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        D.HipEngine(n_groups=4, partner_kind=1, **cfg).close()
+        D.HipEngine(n_groups=4, n_groups_total=8, group_offset=4, partner_kind=0, **cfg).close()

@@ -35,8 +35,10 @@ def dominant_pattern(over):
     cfg, mode = over.get("config", "cfg3"), over.get("mode", "direct")  # (bench.py's default mode: the headline is DIRECT since round 6)
     if cfg == "cfg3" and mode == "streaming":
         return "k_cross_mfma"
-    if cfg in ("cfg2", "cfg3") and mode == "direct":
+    if cfg == "cfg3" and mode == "direct":
         return "k_direct_mvn"
+    if cfg == "cfg2" and mode == "direct":
+        return "k_res_mvn|k_propose<|k_direct_mvn"  # (a population this small: the residual loop inside the streaming-resident lean kernel)
     if cfg in ("cfg2", "cfg3"):
         return "k_res_mvn|k_propose<"  # (history partners: the lean body past burn-in, k_propose<256,false,...> inside it)
     return {"cfg4": "k_longrow|k_frozen_sweep", "cfg5": "k_lba_wave|k_lba_loglike|k_obs_loglike", "cfg1": "k_res_obs|k_propose<", "mvn30": "k_res_mvn|k_propose<"}[cfg]
