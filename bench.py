@@ -508,7 +508,7 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
                       sclk_sysfs_mhz=getattr(a, "sclk_sysfs", None),
                       launch_ms=t_s / n_launch * 1e3, launches=n_launch, updates_per_launch=P * k_iters / n_launch,
                       traffic=traffic, traffic_source=src,
-                      wasted_traffic_ratio=None if traffic is None else traffic / alg_bytes,
+                      wasted_traffic_ratio=None if (traffic is None or in_k1) else traffic / alg_bytes,  # (the resident form: a launch spans iterations)
                       traffic_note="a VALU-bound kernel: the z rows (25.6 MB at cfg3) are re-read by every block of 256 proposals and served "
                                    "by L2 / MALL; what reaches HBM is the counters' figure, far from the 8 TB/s roof")
         else:
