@@ -509,8 +509,13 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
                       launch_ms=t_s / n_launch * 1e3, launches=n_launch, updates_per_launch=P * k_iters / n_launch,
                       traffic=traffic, traffic_source=src,
                       wasted_traffic_ratio=None if (traffic is None or in_k1) else traffic / alg_bytes,  # (the resident form: a launch spans iterations)
-                      traffic_note="a VALU-bound kernel: the z rows (25.6 MB at cfg3) are re-read by every block of 256 proposals and served "
-                                   "by L2 / MALL; what reaches HBM is the counters' figure, far from the 8 TB/s roof")
+                      # what the counters' bytes are: every (block of 256 proposals, observation chunk) workgroup reads its proposals' m rows
+                      # (64 KB) -- the m rows are read once per CHUNK, by the decomposition that fills the chip (cfg3: 48 chunks x 8.4 MB)
+                      implied_m_rereads=None if (traffic is None or in_k1) else (traffic - 8.0 * N * dp - (P / phases) * 8.0 * 48) / ((P / phases) * 8.0 * dp),
+                      traffic_note="a VALU-bound kernel (the vector pipe issues on 0.94 of its cycles): what the counters see is mostly the proposals' m "
+                                   "rows, read once per observation chunk by every block of 256 proposals (cfg3: 48 chunks x 8.4 MB = 403 MB per launch, "
+                                   "65 GB/s -- far from the 8 TB/s roof); the whitened rows themselves (25.6 MB) stay with one XCD's L2 per chunk since "
+                                   "round 6's workgroup -> (block, chunk) mapping")
         else:
             t_s = fused_ms * 1e-3
             n_launch = max(1, tm["propose"]["launches"])

@@ -2078,9 +2078,19 @@ __global__ __launch_bounds__(256, 2) void k_cross_mfma(KParams p, const double* 
 // loads (s_load_dwordx16, SGPR operands) into vector loads -- the first form of this probe cost the kernel a factor of 3.3.
 template <int DP>
 __global__ __launch_bounds__(256) void k_direct_mvn(KParams p, int n_chunks, unsigned long long* __restrict__ clk) {
-    const int q = blockIdx.x * 256 + threadIdx.x;
+    // workgroup -> (block of 256 proposals, observation chunk).  Workgroups are dealt to the eight XCDs in turn (linear id mod 8) and
+    // every XCD has an L2 of its own: with the chunk count a multiple of 8, XCD x takes the chunks x, x + 8, ... and all proposal
+    // blocks of one chunk before the next, so a chunk of whitened rows is fetched by ONE XCD, once (k_cross_mfma's rule).  With
+    // (block, chunk) = (blockIdx.x, blockIdx.y) every XCD held a share of twelve chunks at a time -- 6.4 MB of rows behind a 4 MB
+    // L2 -- and the counters saw the data sixteen times per launch (443 MB where the rows are 25.6).
+    int pblock = blockIdx.x, chunk = blockIdx.y;
+    if ((n_chunks & 7) == 0) {
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7u, j = lin >> 3;
+        chunk = (int)((j / gridDim.x) * 8u + xcd);
+        pblock = (int)(j % gridDim.x);
+    }
+    const int q = pblock * 256 + threadIdx.x;
     const int n_prop = p.n_groups * p.n_act;
-    const int chunk = blockIdx.y;
     const bool ok = q < n_prop;
     const size_t slot = ok ? (size_t)slot_of(p, q) : 0;
     double m[DP];
@@ -2101,6 +2111,9 @@ __global__ __launch_bounds__(256) void k_direct_mvn(KParams p, int n_chunks, uns
             }
         }
     }
+    // (The four s_load_dwordx16 of a row sit at the top of the trip with s_waitcnt lgkmcnt(0) right behind them: the wait is exposed
+    // per wave and six waves per SIMD cover most of it.  A half-row pipeline written in the source -- each half of the NEXT row asked
+    // for as soon as the current half is consumed -- is folded back by the compiler into exactly this shape; profiles/r06/NOTES.md.)
     if (ok) p.partial[(size_t)chunk * p.P + slot] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     if (clk) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
