@@ -3,7 +3,7 @@
 each run free on the GPU and on the CPU oracle from the same start, compared as the tests compare them (every accept decision
 and particle id equal, theta to 1e-10, log-posteriors to 1e-9).  Prints the failures and which kernel instances the cases ran.
 
-    python3 tests/free_run_sweep.py {de_mc_z | two_colour | long_row | de_mc_z_families | row_streaming} [n_cases] [seed]
+    python3 tests/free_run_sweep.py {de_mc_z | two_colour | long_row | de_mc_z_families | row_streaming | per_observation | direct_resident} [n_cases] [seed]
 
 It lives under tests/ because it runs the CPU oracle, which is test infrastructure: nothing outside tests/, the smoke check and
 bench.py's cpu_baseline leg may use it.
@@ -25,7 +25,8 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 O.build()
 gen = {"de_mc_z": T._de_mc_z_cases, "two_colour": T._two_colour_cases, "long_row": T._long_row_cases,
-       "de_mc_z_families": T._de_mc_z_family_cases, "row_streaming": T._row_streaming_cases}[which]
+       "de_mc_z_families": T._de_mc_z_family_cases, "row_streaming": T._row_streaming_cases,
+       "per_observation": T._per_observation_cases, "direct_resident": T._direct_resident_cases}[which]
 bad, kernels = 0, {}
 for case in gen(n, seed=seed):
     c = dict(case.values[0])
@@ -34,6 +35,10 @@ for case in gen(n, seed=seed):
             ran = T.run_de_mc_z_family_case(demc_amd, O, c)
         elif which == "row_streaming":
             ran = T.run_row_streaming_case(demc_amd, O, c)
+        elif which == "per_observation":
+            ran = T.run_per_observation_case(demc_amd, O, c)
+        elif which == "direct_resident":
+            ran = T.run_direct_resident_case(demc_amd, O, c)
         elif which == "long_row":
             S, G, Np, hist, blocks = c.pop("S"), c.pop("G"), c.pop("Np"), c.pop("hist"), c.pop("blocks")
             w = W.cfg4(S=S, G=G, Np=Np)

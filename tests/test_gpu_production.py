@@ -740,3 +740,68 @@ def test_lean_per_observation_kernel_equals_the_general_kernel(demc):
                 np.testing.assert_allclose(x, y, rtol=1e-11, err_msg=f"{family} array {i}")
             else:
                 assert np.array_equal(x, y), f"{family} array {i}"
+
+
+def _per_observation_cases(n, seed=20261009):
+    """the default sampler on the per-observation families over random shapes: Gaussian / Binomial / LNR (2 .. 8 accumulators),
+    groups of 4 .. 80 particles (one to three passes of sixteen per colour phase, odd halves), 3 .. 700 observations (fewer than
+    lanes, ragged strides), mutation-heavy runs, in / leaving / past burn-in, migrations every other iteration"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        fam = str(rng.choice(["gaussian", "gaussian", "binomial", "lnr", "lnr"]))
+        c = dict(fam=fam, Np=int(rng.integers(4, 81)), G=int(rng.integers(1, 9)), N=int(rng.choice([3, 7, 16, 17, 50, 130, 700])),
+                 na=int(rng.integers(2, 9)), beta=float(rng.choice([0.0, 0.1, 0.5])), burnin=int(rng.choice([0, 6, 100])),
+                 alpha=float(rng.choice([0.1, 0.5])), seed=int(rng.integers(1, 2**31)))
+        out.append(pytest.param(c, id=f"{i}-{fam}-Np{c['Np']}-G{c['G']}-N{c['N']}-na{c['na']}-b{c['burnin']}"))
+    return out
+
+
+def run_per_observation_case(demc, orc, c):
+    from conftest import make_problem
+    c = dict(c)
+    fam, Np, G, N, na = c.pop("fam"), c.pop("Np"), c.pop("G"), c.pop("N"), c.pop("na")
+    prob = make_problem(fam, np.random.default_rng(c["seed"] % 100000), **({"N": N, "na": na} if fam == "lnr" else {"N": N}))
+    w = dict(prob, G=G, Np=Np, masks=None, engine={}, init=lambda P, rng_: prob["init"](P))
+    if G == 1:
+        c["alpha"] = 0.0  # (structs.jl:102-105: no migration with one group)
+    return free_run(demc, orc, w, 14, [], G, Np, theta_exact=c["beta"] == 0.0, exact_kernels="k_res_obs<256>", **c)
+
+
+@pytest.mark.parametrize("c", _per_observation_cases(8))
+def test_per_observation_kernel_randomised_free_runs(demc, orc, c):
+    """the generator above against the oracle: every accept decision and particle id equal, theta bit for bit without mutation
+    sweeps (tests/free_run_sweep.py per_observation N runs the long form)"""
+    run_per_observation_case(demc, orc, c)
+
+
+def _direct_resident_cases(n, seed=20261010):
+    """DIRECT mode on small populations (the streaming-resident lean kernel's DIRECT instances): D = 8 and 32, observation counts
+    that leave ragged and empty last chunks, groups of 6 .. 128 particles (slices of 4 .. 16 proposal groups), mutation sweeps,
+    in / leaving / past burn-in"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        d = int(rng.choice([8, 8, 32]))
+        c = dict(d=d, Np=int(rng.integers(6, 129)), G=int(rng.integers(2, 33 if d == 8 else 13)),
+                 N=int(rng.choice([300, 1030, 2048, 2050, 4097] if d == 8 else [300, 1030, 2050])),
+                 beta=float(rng.choice([0.0, 0.1, 0.5])), burnin=int(rng.choice([0, 4, 100])), alpha=float(rng.choice([0.1, 0.5])),
+                 seed=int(rng.integers(1, 2**31)))
+        out.append(pytest.param(c, id=f"{i}-d{d}-Np{c['Np']}-G{c['G']}-N{c['N']}-b{c['burnin']}"))
+    return out
+
+
+def run_direct_resident_case(demc, orc, c):
+    from demc_amd import workloads as W
+    c = dict(c)
+    d, Np, G, N = c.pop("d"), c.pop("Np"), c.pop("G"), c.pop("N")
+    w = W.cfg3(N=N, d=d, G=G, Np=Np)
+    return free_run(demc, orc, w, 10, [], G, Np, theta_exact=c["beta"] == 0.0, loglike_mode=2, **c)
+
+
+@pytest.mark.parametrize("c", _direct_resident_cases(8))
+def test_direct_resident_kernel_randomised_free_runs(demc, orc, c):
+    """the generator above against the oracle (whatever kernel the shape takes: the DIRECT streaming-resident instance where the
+    observation chunk fits in LDS, else the K1 -> k_direct_mvn -> K3 chain): every accept decision and particle id equal"""
+    ran = run_direct_resident_case(demc, orc, c)
+    assert "direct" in ran, ran
