@@ -805,3 +805,25 @@ def test_direct_resident_kernel_randomised_free_runs(demc, orc, c):
     observation chunk fits in LDS, else the K1 -> k_direct_mvn -> K3 chain): every accept decision and particle id equal"""
     ran = run_direct_resident_case(demc, orc, c)
     assert "direct" in ran, ran
+
+
+def test_direct_resident_kernel_repeats_bit_for_bit(demc):
+    """every output is a pure function of (inputs, seed): BASELINE cfg2 in DIRECT mode (eight workgroups per group handing their row
+    partials over through epoch-tagged granules, 40 iterations, migrations on) three times on fresh handles -- state, weights, ids and
+    the whole history bit for bit"""
+    from demc_amd import workloads as W
+    w = W.cfg2()
+    G, Np, n_it = w["G"], w["Np"], 40
+    th0 = w["init"](G * Np, np.random.default_rng(8))
+    outs = []
+    for _ in range(3):
+        e = demc.HipEngine(n_groups=G, Np=Np, D=w["D"], n_rows=n_it, schedule=2, seed=99, burnin=20, alpha=0.3, loglike_mode=2)
+        W.configure(e, w)
+        e.set_state(th0)
+        e.step(1, n_it)
+        assert e.last_kernels() == "k_res_mvn<512,true,8,direct>"
+        outs.append(e.get_history(0, n_it) + e.get_state())
+        e.close()
+    for other in outs[1:]:
+        for x, y in zip(outs[0], other):
+            assert np.array_equal(x, y)
