@@ -63,6 +63,20 @@ function check(h, rc)
     error("libdemc_hip: status $rc: $msg")   # non-zero status -> Julia exception (SURVEY 8b)
 end
 
+"a `note:` line left by a SUCCESSFUL call -- a documented deviation in force on the handle (include/demc.h, demc_last_error) -- is a warning"
+function note(h)
+    msg = unsafe_string(@ccall LIB.demc_last_error(h::Ptr{Cvoid})::Cstring)
+    startswith(msg, "note:") && @warn "libdemc_hip: " * msg[7:end]
+    nothing
+end
+
+"shader clock (MHz: median, min, max over the CUs; CUs that reported) the DIRECT likelihood kernel held in its last timed launch"
+function timing_clock(h)
+    out = zeros(Float64, 4)
+    check(h, @ccall LIB.demc_timing_clock(h::Ptr{Cvoid}, out::Ptr{Float64})::Int32)
+    out
+end
+
 # function-valued hooks of DE (src/structs.jl:71-74) -> enums; anything else has no device implementation
 hook_code(f, table, what) = haskey(table, f) ? table[f] :
     error("DE.$what = $f cannot run on the device; use the CPU path (step!/pstep!)")
@@ -185,6 +199,7 @@ function sample(model::DEModel, de::DE, b::HIPBackend, n_iter::Int; model_spec::
     h = href[]
     try
         check(h, rc)
+        note(h)
         load_handle!(h, model_spec, de, particles)
         run_segments(de, n_iter, [h]) do first, count
             check(h, @ccall LIB.demc_step(h::Ptr{Cvoid}, Int64(first + de.n_initial)::Int64, Int32(count)::Int32)::Int32)
