@@ -16,11 +16,11 @@ from demc_amd import workloads as W  # noqa: E402
 import demc_amd  # noqa: E402
 
 G, Np, N, d, iters = 256, 256, 100000, 32, 250
-mode = sys.argv[1] if len(sys.argv) > 1 else "streaming"
+mode = sys.argv[1] if len(sys.argv) > 1 else "direct"
 P = G * Np
 prob = W.cfg3(N=N, d=d, G=G, Np=Np)
 th0 = prob["init"](P, np.random.default_rng(20260003))
-eng = demc_amd.HipEngine(n_groups=G, Np=Np, D=d, n_rows=iters, schedule=2, seed=20260001, loglike_mode=0 if mode == "streaming" else 1,
+eng = demc_amd.HipEngine(n_groups=G, Np=Np, D=d, n_rows=iters, schedule=2, seed=20260001, loglike_mode={"streaming": 0, "suffstat": 1, "direct": 2}[mode],
                          trace=0)
 t0 = time.perf_counter()
 W.configure(eng, prob)          # X upload (25.6 MB) + fragment reorder + priors
