@@ -666,7 +666,11 @@ def roofline_of(a, w, tm, k_iters, P, dt_per_iter):
                 pipes_src = f"profiles/{PROFILE_ROUND}/{os.path.basename(pj)} was collected on other kernel sources: not quoted"
         except (OSError, KeyError, ValueError, IndexError):
             pass
-        rf = dict(bound="valu", kernel="k_lba_wave (LBA: a wave per proposal, lanes across trials sorted by (choice, decision time), batches of 8 "
+        clk = getattr(a, "clock", None) or {}
+        mhz = clk.get("mhz_median")
+        rf = dict(bound="valu", shader_clock_mhz=mhz, shader_clock_mhz_min=clk.get("mhz_min"), shader_clock_mhz_max=clk.get("mhz_max"),
+                  frac_at_clock=None if (not mhz or ach is None) else ach / (PEAK_FP64_TFLOPS * mhz / 2400.0),
+                  kernel="k_lba_wave (LBA: a wave per proposal, lanes across trials sorted by (choice, decision time), batches of 8 "
                                        "trials per lane, one degree-7 Phi polynomial table on intervals of 1/32 in LDS whose derivative gives phi -- "
                                        "read as broadcasts --, one log per batch)",
                   achieved=ach, peak=PEAK_FP64_TFLOPS, unit="TFLOP/s", frac=None if ach is None else ach / PEAK_FP64_TFLOPS,
@@ -1208,6 +1212,8 @@ def compact_row(r):
         c["shape_frac"] = rf["shape_frac"]
     if (r.get("cpu_baseline") or {}).get("value") is not None:  # (rows with a CPU leg: the oracle on all cores / on one thread)
         c["cpu"], c["cpu_1thread"] = r["cpu_baseline"]["value"], r["cpu_baseline"].get("value_single_thread")
+    if rf.get("shader_clock_mhz") is not None:  # (VALU-bound rows: the in-kernel clock the fraction was measured at)
+        c["clock_mhz"] = rf["shader_clock_mhz"]
     if rf.get("frac_survey") is not None:  # (STREAMING rows: the executed MFMA flop and SURVEY 8d's unit side by side -- the latter > 1)
         c["frac_executed"], c["frac_survey"] = rf.get("frac_executed"), rf["frac_survey"]
     return sig(c)

@@ -454,7 +454,7 @@ class HipEngine:
         return {n: dict(ms=out[i], launches=int(out[5 + i])) for i, n in enumerate(names)}
 
     def timing_clock(self):
-        """shader clock (MHz) the DIRECT MvNormal likelihood kernel held in its last launch with timing enabled: median / min /
+        """shader clock (MHz) the DIRECT MvNormal likelihood kernel (or the LBA wave kernel) held in its last launch with timing enabled: median / min /
         max over the CUs (per CU: s_memtime ticks over 100 MHz s_memrealtime ticks between the first and the last workgroup to
         finish there); None if no such launch ran or it was too short to difference"""
         out = np.zeros(4)

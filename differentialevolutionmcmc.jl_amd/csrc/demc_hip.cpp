@@ -454,6 +454,23 @@ int chunks_filling_rounds(long long blocks, long long cap, double resident_wgs) 
     return (int)best;
 }
 
+// demc_timing_clock: with timing enabled the compute-bound likelihood kernels (k_direct_mvn, k_lba_wave) leave per workgroup
+// {s_memtime, s_memrealtime, CU} as they end; the buffer is zeroed on the stream ahead of the launch (a workgroup whose first wave
+// has no proposal reports nothing) and sized for the launch's grid.  Null when timing is off.
+int clock_buffer(demc_handle* h, size_t wgs, unsigned long long** out) {
+    *out = nullptr;
+    if (!h->timing) return DEMC_OK;
+    if (wgs > h->clk_cap) {
+        if (h->clk_dev) { HIPCHK(hipStreamSynchronize(h->stream)); hipFree(h->clk_dev); h->clk_dev = nullptr; h->clk_cap = 0; }
+        ALLOC(h->clk_dev, 3 * wgs);
+        h->clk_cap = wgs;
+    }
+    HIPCHK(hipMemsetAsync(h->clk_dev, 0, 3 * wgs * sizeof(unsigned long long), h->stream));
+    h->clk_n = wgs;
+    *out = h->clk_dev;
+    return DEMC_OK;
+}
+
 // K2 dispatch for the active set described by k.  Sets k.n_partials.
 int launch_loglike(demc_handle* h, KParams& k) {
     const long long n_prop = (long long)k.n_groups * k.n_act;
@@ -484,16 +501,7 @@ int launch_loglike(demc_handle* h, KParams& k) {
                 h->last.k2 = 5; h->last.ks = h->dp_direct;
                 // timing on: every workgroup also leaves its shader-clock / reference-clock ticks (demc_timing_clock)
                 unsigned long long* clk = nullptr;
-                if (h->timing) {
-                    const size_t wgs = (size_t)blocks * (size_t)n_chunks;
-                    if (wgs > h->clk_cap) {
-                        if (h->clk_dev) { HIPCHK(hipStreamSynchronize(h->stream)); hipFree(h->clk_dev); h->clk_dev = nullptr; h->clk_cap = 0; }
-                        ALLOC(h->clk_dev, 3 * wgs);
-                        h->clk_cap = wgs;
-                    }
-                    clk = h->clk_dev;
-                    h->clk_n = wgs;
-                }
+                if (int rc = clock_buffer(h, (size_t)blocks * (size_t)n_chunks, &clk)) return rc;
                 tick(h, 2, true);
                 const dim3 grid((unsigned)blocks, (unsigned)n_chunks);
                 switch (h->dp_direct) {
@@ -585,11 +593,13 @@ int launch_loglike(demc_handle* h, KParams& k) {
                     if (const char* e = experiment("DEMC_OBS_CHUNKS"))  // A/B experiments
                         if (std::atoi(e) > 0 && std::atoi(e) <= capw) nc = std::atoi(e);
                     h->last.k2 = 8;
+                    unsigned long long* clk = nullptr;  // timing on: the clock the vector pipe held (demc_timing_clock)
+                    if (int rc = clock_buffer(h, (size_t)((n_prop + 3) / 4) * (size_t)nc, &clk)) return rc;
                     tick(h, 2, true);
                     const dim3 grid((unsigned)((n_prop + 3) / 4), (unsigned)nc);
-                    if (h->n_acc == 3) LAUNCH_T(h, k_lba_wave<3>, grid, dim3(256), 0, k, nc);
-                    else if (h->n_acc == 2) LAUNCH_T(h, k_lba_wave<2>, grid, dim3(256), 0, k, nc);
-                    else LAUNCH_T(h, k_lba_wave<0>, grid, dim3(256), 0, k, nc);
+                    if (h->n_acc == 3) LAUNCH_T(h, k_lba_wave<3>, grid, dim3(256), 0, k, nc, clk);
+                    else if (h->n_acc == 2) LAUNCH_T(h, k_lba_wave<2>, grid, dim3(256), 0, k, nc, clk);
+                    else LAUNCH_T(h, k_lba_wave<0>, grid, dim3(256), 0, k, nc, clk);
                     tick(h, 2, false);
                     k.n_partials = nc;
                     break;
@@ -3081,8 +3091,10 @@ int32_t demc_timing_clock(demc_handle* h, double* out4) {
     // workgroup that finished first there and the one that finished last, by the 100 MHz reference; the shader-clock ticks between
     // the two over the reference ticks between the two is the clock the CU held over that span of the launch.  A CU whose span is
     // under 20 us (a launch of a single round of workgroups) says nothing.
-    std::vector<size_t> order(h->clk_n);
-    for (size_t i = 0; i < h->clk_n; ++i) order[i] = i;
+    std::vector<size_t> order;
+    order.reserve(h->clk_n);
+    for (size_t i = 0; i < h->clk_n; ++i)
+        if (t[3 * i + 1] != 0) order.push_back(i);  // (a workgroup that reported)
     std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return t[3 * a + 2] < t[3 * b + 2]; });
     std::vector<double> mhz;
     for (size_t a = 0; a < order.size();) {

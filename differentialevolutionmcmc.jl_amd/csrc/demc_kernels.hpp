@@ -2178,7 +2178,7 @@ __global__ __launch_bounds__(256) void k_obs_loglike(KParams p, int n_chunks) {
 // ------------------------------------------------------------------------------------------------
 #ifndef DEMC_DEVICE_HELPERS_ONLY
 template <int NA>
-__global__ __launch_bounds__(256, 2) void k_lba_wave(KParams p, int n_chunks) {
+__global__ __launch_bounds__(256, 2) void k_lba_wave(KParams p, int n_chunks, unsigned long long* __restrict__ clk) {
     __shared__ double s_tab[kPhiIntervals * kPhiRow];
     for (int i = threadIdx.x; i < kPhiIntervals * kPhiRow; i += 256) s_tab[i] = kPhiTable[i];
     __syncthreads();
@@ -2240,6 +2240,16 @@ __global__ __launch_bounds__(256, 2) void k_lba_wave(KParams p, int n_chunks) {
         acc += log(lba_trial<NA, kPhiRow, double>(s_tab, na, nu, nuS, kS, bS, tau, inv_A, inv_SA, inv_norm, p.data[i], p.data2[i]));
     acc = subgroup_sum(acc, 64);
     if (lane == 0) p.partial[(size_t)chunk * p.P + slot] = acc;
+    if (clk) {  // (demc_timing_clock: as k_direct_mvn -- end-of-life stamps only, behind every load of the kernel)
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u, hwid = __builtin_amdgcn_s_getreg(4 | (31 << 11));
+        if (threadIdx.x == 0) {
+            const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+            clk[3 * wg] = t1;
+            clk[3 * wg + 1] = r1;
+            clk[3 * wg + 2] = (xcc << 8) | ((hwid >> 8) & 0xffu);
+        }
+    }
 }
 #endif
 

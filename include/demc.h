@@ -362,8 +362,8 @@ int32_t demc_set_replay(demc_handle* h, const demc_replay* replay);
  * [3]=accept/store (K3), [4]=migration; the number of timed launch groups of each class in out[5..9]. */
 int32_t demc_timing_enable(demc_handle* h, int32_t on);
 int32_t demc_timing_read(demc_handle* h, double* out10, int32_t reset);
-/* The shader clock the DIRECT MvNormal likelihood kernel (DEMC_LOGLIKE_DIRECT: FP64 vector-pipe work, whose rate scales with the
- * clock) held during its LAST launch with timing enabled: every workgroup stamps s_memtime (shader cycles), s_memrealtime (100 MHz
+/* The shader clock a compute-bound likelihood kernel -- the DIRECT MvNormal kernel (DEMC_LOGLIKE_DIRECT) or the LBA's wave-per-proposal
+ * kernel: FP64 vector-pipe work, whose rate scales with the clock -- held during its LAST launch with timing enabled: every workgroup stamps s_memtime (shader cycles), s_memrealtime (100 MHz
  * reference) and its CU as it ends; per CU the clock is the shader cycles over the reference ticks between the first and the last
  * workgroup to finish there.  out[0] = median over the CUs in MHz, [1] = min, [2] = max, [3] = CUs that reported (0: no such
  * launch ran, or it was a single round of workgroups: nothing to difference).  Diagnostic, like demc_timing_read: the chip lowers its

@@ -371,6 +371,8 @@ def _fake_bench_result(bench, n_gpus=1, n_rows=None):
             r["roofline"]["counter_frac"] = 0.21512345678
         if r["name"].startswith("cfg4_whole"):
             r["roofline"]["shape_frac"] = 0.63123456789
+        if r["name"].startswith("cfg5") or r["name"] == "cfg2_direct":
+            r["roofline"]["shader_clock_mhz"] = 2251.123456
         if r["name"] in bench.CPU_ROWS:
             r["cpu_baseline"] = dict(value=23877.65572005412, value_single_thread=1737.3869838033977, cores=16, sample=prose)
     rows.append(dict(name="a_row_that_failed", error="RuntimeError: " + prose))
@@ -431,7 +433,7 @@ def test_bench_final_line_fits_what_a_harness_keeps(capsys):
             for r in line["rows"][:-1]:
                 assert {"name", "value", "ms_per_step", "steps", "frac", "launch_ms", "bound", "traffic"} <= set(r), r
                 assert set(r) <= {"name", "value", "ms_per_step", "steps", "frac", "launch_ms", "bound", "traffic", "counter_frac", "shape_frac",
-                                  "frac_executed", "frac_survey", "cpu", "cpu_1thread"}, r
+                                  "frac_executed", "frac_survey", "cpu", "cpu_1thread", "clock_mhz"}, r
                 assert ("frac_survey" in r) == ("streaming" in r["name"]) and ("cpu" in r) == (r["name"] in bench.CPU_ROWS)
                 assert all(not isinstance(v, str) or len(v) < 64 for v in r.values())
             assert len(line["rows"][-1]["error"]) <= 80

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BATCH = int(re.search(r"constexpr int kLbaBatch = (\d+);", open(os.path.join(ROOT, "differentialevolutionmcmc.jl_amd/csrc/demc_kernels.hpp")).read()).group(1))
 DEG = int(re.search(r"constexpr int kPhiDeg = (\d+);", open(os.path.join(ROOT, "differentialevolutionmcmc.jl_amd/csrc/demc_phi_table.hpp")).read()).group(1))
 READS = (DEG + 2) // 2  # sixteen-byte LDS reads per table look-up: deg + 1 coefficients, two per read
-src = ('#include "%s"\nnamespace demc { template __global__ void k_lba_wave<3>(KParams, int); }\n'
+src = ('#include "%s"\nnamespace demc { template __global__ void k_lba_wave<3>(KParams, int, unsigned long long*); }\n'
        % os.path.join(ROOT, "differentialevolutionmcmc.jl_amd/csrc/demc_kernels.hpp"))
 with tempfile.TemporaryDirectory() as td:
     hip, asm = os.path.join(td, "k.hip"), os.path.join(td, "k.s")
@@ -25,7 +25,7 @@ with tempfile.TemporaryDirectory() as td:
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                            "--cuda-device-only", "-S", hip, "-o", asm], stderr=subprocess.DEVNULL)
     text = open(asm).read()
-body = re.search(r"^_ZN4demc10k_lba_waveILi3EEEvNS_7KParamsEi:(.*?)s_endpgm", text, re.S | re.M).group(1)
+body = re.search(r"^_ZN4demc10k_lba_waveILi3EEEvNS_7KParamsEiPy:(.*?)s_endpgm", text, re.S | re.M).group(1)
 # the batch loop of the 3-accumulator instance: the loop (header label .. last branch back to it) whose body holds exactly
 # 3 accumulators x 2 look-ups x READS sixteen-byte table reads per trial
 lines = body.splitlines()

@@ -47,8 +47,8 @@ def main(d):
         if rf.get("frac_survey") is not None:  # STREAMING rows: the executed MFMA flop next to SURVEY 8d's unit (above 1: not the survey's work)
             ctr.append(f"`frac_executed` {g(rf.get('frac_executed'), 3)}, `frac_survey` {g(rf['frac_survey'], 3)}")
         if rf.get("shader_clock_mhz") is not None:  # DIRECT rows: the clock the vector pipe held (in-kernel) and the fraction at that clock
-            ctr.append(f"shader clock {g(rf['shader_clock_mhz'])} MHz in-kernel: {g(rf.get('frac_at_clock'), 3)} of the peak at that clock, "
-                       f"{g(rf.get('frac_of_mix_ceiling_at_clock'), 3)} of the add+fma mix's ceiling")
+            ctr.append(f"shader clock {g(rf['shader_clock_mhz'])} MHz in-kernel: {g(rf.get('frac_at_clock'), 3)} of the peak at that clock" +
+                       (f", {g(rf['frac_of_mix_ceiling_at_clock'], 3)} of the add+fma mix's ceiling" if rf.get("frac_of_mix_ceiling_at_clock") is not None else ""))
         if rf.get("traffic") is not None:
             ctr.append(f"{g(rf['traffic'] / 1e6)} MB/launch ({g(rf.get('wasted_traffic_ratio'), 3)}× algorithmic)")
         if rf.get("counter_frac") is not None:
