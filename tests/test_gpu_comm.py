@@ -362,7 +362,8 @@ def test_bench_under_the_drivers_launcher_with_the_library_collective():
     assert rec["world"] == 1 and rec["all_gathers"] == line["config"]["all_gathers_per_rank"][0] and rec["rccl_nranks"] == 1
 
 
-def test_bench_sharded_rows_of_the_8_gpu_configs_at_world_one():
+@pytest.mark.parametrize("collective", ["library", "torch"])
+def test_bench_sharded_rows_of_the_8_gpu_configs_at_world_one(collective):
     """What `bench.py --gpus N` adds at N > 1 -- BASELINE's cfg4 (128 groups) and cfg5 (512 groups) partitioned over the ranks, one
     library all-gather per migration on the row engine's own communicator -- exercised on the one GPU there is: the driver's
     launcher, DEMC_FORCE_DIST=1, world 1 (each row is then the config's whole population on this GPU).  The rows are in the compact
@@ -376,17 +377,19 @@ def test_bench_sharded_rows_of_the_8_gpu_configs_at_world_one():
     env = dict(os.environ, DEMC_FORCE_DIST="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3",
-                          "--accuracy-iters", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+                          "--accuracy-iters", "0", "--no-cpu-baseline", "--collective", collective], capture_output=True, text=True, timeout=900,
+                         env=env)  # (torch: the road the run takes when the library's communicator cannot be created -- same rows)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     det, line = json.loads(lines[0])["detail"], json.loads(lines[-1])
-    assert len(lines[-1]) < 6000 and line["config"]["rccl_nranks"] == 1
+    nranks = 1 if collective == "library" else None  # (rccl_nranks is the LIBRARY communicator's size)
+    assert len(lines[-1]) < 6000 and line["config"]["rccl_nranks"] == nranks
     rows = {r["name"]: r for r in det["rows"]}
     assert list(rows) == ["cfg4_sharded", "cfg5_sharded"], [(r["name"], r.get("error"), r.get("skipped")) for r in det["rows"]]
     for name, total, kern in (("cfg4_sharded", 128, "k_frozen_sweep"), ("cfg5_sharded", 512, "k_lba_wave")):
         r = rows[name]
         assert "error" not in r and r["value"] > 0 and r["finite_weights"] and r["scaling"] == "strong"
-        assert r["groups_total"] == total == r["groups_per_rank"] * r["n_gpus"] and r["rccl_nranks"] == 1 and r["collective"] == "library"
+        assert r["groups_total"] == total == r["groups_per_rank"] * r["n_gpus"] and r["rccl_nranks"] == nranks and r["collective"] == collective
         assert r["all_gathers_per_rank"][0] >= 1, "50 iterations at alpha = 0.1 without a migration: the row measured no exchange"
         assert kern in r["kernels"]
     assert [c["name"] for c in line["rows"]] == ["cfg4_sharded", "cfg5_sharded"] and line["rows"][0]["all_gathers_per_rank"] == rows["cfg4_sharded"]["all_gathers_per_rank"]
