@@ -100,7 +100,7 @@ def test_cfg3_geometry_suffstat_lean_kernel(demc, orc, beta):
 
 @pytest.mark.parametrize("beta", [0.0, 0.1])
 def test_cfg3_geometry_streaming_chain(demc, orc, beta):
-    """the headline's three kernels: PLAIN K1 (LDS tile, MvNormal preparation on the matrix cores) -> k_cross_mfma<8,4> ->
+    """the STREAMING chain (the headline of rounds 1-5; a labelled row since round 6), three kernels: PLAIN K1 (LDS tile, MvNormal preparation on the matrix cores) -> k_cross_mfma<8,4> ->
     k_accept_store, with cfg3's lane geometry (geometry_groups = 256 -> 4 lanes per particle) on 16 groups; fuse = 2 keeps
     the per-phase chain that the full-size population takes by itself"""
     from demc_amd import workloads as W
