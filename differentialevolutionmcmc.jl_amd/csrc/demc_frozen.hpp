@@ -149,7 +149,7 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
     const double w_cur = gw[pl];
     double* srow = (!BIG && p.snap_theta) ? p.snap_theta + slot * D : nullptr;  // the row as this sweep leaves it (by-product snapshot)
     // the history row of a sweep that is the iteration's last: the row as it stands after the decision (utilities.jl:161-180)
-    double* hrow = (p.store_row >= 0) ? p.hist + ((size_t)p.store_row * p.P + slot) * D : nullptr;
+    double* hrow = (p.store_row >= 0) ? p.hist + ((size_t)p.store_row * p.P + slot) * p.hist_ld : nullptr;
     const bool maybe_base = p.proposal_kind == 0 && p.iter <= p.burnin && wave == 0;
     double pw_r[4] = {0.0, 0.0, 0.0, 0.0};
     if (maybe_base) {
@@ -193,9 +193,9 @@ __global__ __launch_bounds__(WG, MINW) void k_frozen_sweep(KParams p) {
                 if (c >= lo) ++c;
                 if (c >= hi) ++c;
             }
-            Pa = p.hist + ((a % ub) * (uint64_t)p.P + a / ub) * (uint64_t)D;
-            Pb2 = p.hist + ((b % ub) * (uint64_t)p.P + b / ub) * (uint64_t)D;
-            Pc = p.hist + ((c % ub) * (uint64_t)p.P + c / ub) * (uint64_t)D;
+            Pa = p.hist + ((a % ub) * (uint64_t)p.P + a / ub) * (uint64_t)p.hist_ld;
+            Pb2 = p.hist + ((b % ub) * (uint64_t)p.P + b / ub) * (uint64_t)p.hist_ld;
+            Pc = p.hist + ((c % ub) * (uint64_t)p.P + c / ub) * (uint64_t)p.hist_ld;
         } else if (snooker) {
             uint32_t a, b, c;  // snooker_update! draws 3 from the whole pool (crossover.jl:241)
             pick_triple(ri0, ri1, ri2, (uint32_t)p.pool_n, a, b, c);

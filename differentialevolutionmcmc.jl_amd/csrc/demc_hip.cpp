@@ -161,6 +161,7 @@ struct demc_handle {
     bool rp_active = false, rp_has_step = false;
     double rp_u_step = 0.0;
     int geo_groups = 0;  // groups the lane geometry is sized for (demc_config.geometry_groups, else n_groups)
+    int hist_ld = 0;     // doubles between consecutive history cells (KParams::hist_ld)
     // the one collective of the path: an RCCL communicator owned by the handle (demc_comm_init), or lent by the
     // single-process multi-GPU set the handle is a shard of (demc_create_multi)
     ncclComm_t comm = nullptr;
@@ -339,7 +340,7 @@ KParams base_params(demc_handle* h) {
     k.seg_plain = h->seg_plain;
     std::memset(k.mrun_start, 0, sizeof k.mrun_start);
     k.n_mrun = 1; k.mrun_in = 1u;  // no block mask: one run, inside
-    k.hist = h->hist; k.acc_hist = h->acc_hist; k.lp_hist = h->lp_hist; k.id_hist = h->id_hist;
+    k.hist = h->hist; k.acc_hist = h->acc_hist; k.lp_hist = h->lp_hist; k.id_hist = h->id_hist; k.hist_ld = h->hist_ld;
     k.P = h->P; k.store_row = -1; k.tile_in_lds = h->tile_in_lds;
     k.family = h->family; k.N = h->N; k.d = h->d; k.n_acc = h->n_acc; k.n_partials = 1;
     k.partial = h->partial; k.aux = h->aux; k.data = h->data; k.data2 = h->data ? h->data + h->data2_off : nullptr;
@@ -1607,7 +1608,13 @@ int32_t demc_create(const demc_config* cfg, demc_handle** out) {
     ALLOC(h->mig_rows, (size_t)c.n_groups_total * (D + 3));
     ALLOC(h->scratch_theta, P * D); ALLOC(h->scratch_w, P);
     if (c.store_history && c.n_rows > 0) {
-        ALLOC(h->hist, (size_t)c.n_rows * P * D);
+        // History cells that partners are GATHERED from (DE-MC_Z: `resample`, crossover.jl:113-124) are padded to whole cache lines --
+        // rows of up to 16 scalars to the next power of two, up to 64 to the next multiple of 16 doubles: a cell of 31 doubles at an
+        // 8-byte boundary touches 2.9 lines of 128 bytes on average (376 B fetched for 248), at a 256-byte boundary exactly two.  Only
+        // then: a history that is only written (partners from the population) stays dense -- padded cells would be partial-line stores.
+        h->hist_ld = (int)D;
+        if (c.partner_kind == DEMC_PARTNER_HISTORY && D <= 64) h->hist_ld = D <= 16 ? pow2_ceil((int)D) : (int)((D + 15) & ~(size_t)15);
+        ALLOC(h->hist, (size_t)c.n_rows * P * (size_t)h->hist_ld);
         ALLOC(h->acc_hist, (size_t)c.n_rows * P);
         ALLOC(h->lp_hist, (size_t)c.n_rows * P);
         ALLOC(h->id_hist, (size_t)c.n_rows * P);
@@ -2130,10 +2137,26 @@ int32_t demc_set_history_rows(demc_handle* h, int64_t row0, int64_t nrows, const
     USE_DEVICE(h);
     if (!h->hist) return fail(h, DEMC_EINVAL, "history is not stored on this handle");
     if (row0 < 0 || nrows < 0 || row0 + nrows > h->c.n_rows) return fail(h, DEMC_EINVAL, "history rows out of range");
-    const size_t PD = (size_t)h->P * h->c.D;
+    const size_t D = (size_t)h->c.D, ld = (size_t)h->hist_ld, P = (size_t)h->P;
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(h->hist + (size_t)row0 * PD, rows, (size_t)nrows * PD * sizeof(double), hipMemcpyHostToDevice));
-    return DEMC_OK;
+    if (ld == D) {
+        HIPCHK(hipMemcpy(h->hist + (size_t)row0 * P * D, rows, (size_t)nrows * P * D * sizeof(double), hipMemcpyHostToDevice));
+        return DEMC_OK;
+    }
+    // padded cells: the caller's dense rows go through a device staging buffer, a few rows at a time
+    const size_t chunk = std::max<size_t>(1, ((size_t)64 << 20) / (P * D * sizeof(double)));
+    double* stage = nullptr;
+    ALLOC(stage, std::min<size_t>(chunk, (size_t)nrows) * P * D);
+    int rc = DEMC_OK;
+    for (size_t r = 0; r < (size_t)nrows && rc == DEMC_OK; r += chunk) {
+        const size_t n = std::min(chunk, (size_t)nrows - r);
+        if (hipMemcpy(stage, rows + r * P * D, n * P * D * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(h, DEMC_EHIP, "history upload"); break; }
+        hipLaunchKernelGGL(k_hist_repack, dim3(1024), dim3(256), 0, h->stream, h->hist + ((size_t)row0 + r) * P * ld, stage, (long long)(n * P), (int)D,
+                           (int)ld, (int)D);
+        if (hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, DEMC_EHIP, "history repack");
+    }
+    hipFree(stage);
+    return rc;
     });
 }
 
@@ -2145,7 +2168,23 @@ int32_t demc_get_history(demc_handle* h, int64_t row0, int64_t row1, double* th,
     if (row0 < 0 || row1 < row0 || row1 > h->c.n_rows) return fail(h, DEMC_EINVAL, "history rows out of range");
     const size_t P = (size_t)h->P, D = (size_t)h->c.D, n = (size_t)(row1 - row0);
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (th) HIPCHK(hipMemcpy(th, h->hist + (size_t)row0 * P * D, n * P * D * sizeof(double), hipMemcpyDeviceToHost));
+    const size_t ld = (size_t)h->hist_ld;
+    if (th && ld == D) HIPCHK(hipMemcpy(th, h->hist + (size_t)row0 * P * D, n * P * D * sizeof(double), hipMemcpyDeviceToHost));
+    else if (th && n > 0) {  // padded cells: packed into a dense staging buffer on the device, a few rows at a time
+        const size_t chunk = std::max<size_t>(1, ((size_t)64 << 20) / (P * D * sizeof(double)));
+        double* stage = nullptr;
+        ALLOC(stage, std::min(chunk, n) * P * D);
+        int rc = DEMC_OK;
+        for (size_t r = 0; r < n && rc == DEMC_OK; r += chunk) {
+            const size_t m = std::min(chunk, n - r);
+            hipLaunchKernelGGL(k_hist_repack, dim3(1024), dim3(256), 0, h->stream, stage, h->hist + ((size_t)row0 + r) * P * ld, (long long)(m * P), (int)D,
+                               (int)D, (int)ld);
+            if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(h, DEMC_EHIP, "history repack"); break; }
+            if (hipMemcpy(th + r * P * D, stage, m * P * D * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(h, DEMC_EHIP, "history download");
+        }
+        hipFree(stage);
+        if (rc != DEMC_OK) return rc;
+    }
     if (acc) HIPCHK(hipMemcpy(acc, h->acc_hist + (size_t)row0 * P, n * P, hipMemcpyDeviceToHost));
     if (lp) HIPCHK(hipMemcpy(lp, h->lp_hist + (size_t)row0 * P, n * P * sizeof(double), hipMemcpyDeviceToHost));
     if (idh) {

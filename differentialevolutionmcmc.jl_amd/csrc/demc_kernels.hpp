@@ -85,10 +85,11 @@ struct KParams {
                                 // group glist[i], n_groups counts the subset; null: all groups, in order
     const unsigned char* mask;  // [D] or null
     // history (slot keyed)
-    double* hist;             // [rows][P][D]
+    double* hist;             // [rows][P][hist_ld]: a cell holds the D scalars of a row, cells hist_ld >= D doubles apart
     unsigned char* acc_hist;  // [rows][P]
     double* lp_hist;          // [rows][P]
     int* id_hist;             // [rows][P]
+    int hist_ld;              // doubles between consecutive history cells (D, or D padded to whole cache lines: demc_create)
     long long P;              // local particles
     long long store_row;      // >= 0: K3 stores this history row
     int tile_in_lds;          // K1: stage the group tile in LDS
@@ -1320,7 +1321,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
         if (valid) {
             double* trow = p.theta + slot * D;
             double* lrow = tile + (size_t)pl * D;  // RES: the group's copy in LDS moves with it
-            double* hrow = (p.store_row >= 0 && wr_hbm) ? p.hist + ((size_t)p.store_row * p.P + slot) * D : nullptr;
+            double* hrow = (p.store_row >= 0 && wr_hbm) ? p.hist + ((size_t)p.store_row * p.P + slot) * p.hist_ld : nullptr;
             const double* th = scr + srow * scr_stride;
             if (acc || hrow)
                 for (int k = sl; 2 * k < D; k += lpp) {
@@ -1458,7 +1459,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !STREAM) ? 2 : 1) void k_propose(
                         } else {
                             sl_ = x / ub; row = x - sl_ * ub;
                         }
-                        return p.hist + (row * (uint64_t)p.P + sl_) * (uint64_t)D;
+                        return p.hist + (row * (uint64_t)p.P + sl_) * (uint64_t)p.hist_ld;
                     };
                     Pa = cell(a);
                     Pb2 = cell(b);
@@ -2409,7 +2410,7 @@ __global__ __launch_bounds__(256) void k_accept_store(KParams p) {
     if (!valid) return;
     double* trow = p.theta + slot * D;
     const double* prow = p.prop + slot * D;
-    double* hrow = (p.store_row >= 0) ? p.hist + ((size_t)p.store_row * p.P + slot) * D : nullptr;
+    double* hrow = (p.store_row >= 0) ? p.hist + ((size_t)p.store_row * p.P + slot) * p.hist_ld : nullptr;
     if (!acc && !hrow) return;
     for (int k = sl; 2 * k < D; k += lpp)
         for (int e = 0; e < 2; ++e) {
@@ -2597,6 +2598,20 @@ __global__ __launch_bounds__(256) void k_mig_apply(KParams p, const double* __re
 }
 #endif
 
+// History cells between their padded device layout (cells hist_ld doubles apart) and the dense [rows][P][D] layout of the C-ABI
+// (demc_set_history_rows / demc_get_history): dst[c][j] = src[c][j] for the D scalars of every cell.
+#ifndef DEMC_DEVICE_HELPERS_ONLY
+__global__ __launch_bounds__(256) void k_hist_repack(double* __restrict__ dst, const double* __restrict__ src, long long cells, int D, int ld_dst,
+                                                    int ld_src) {
+    const long long total = cells * D;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const long long c = t / D;
+        const int j = (int)(t - c * D);
+        dst[c * ld_dst + j] = src[c * ld_src + j];
+    }
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // Chains export (bundle_samples, main.jl:222-250): re-key the slot-keyed history by particle id and lay it out as the
 // value array (parameters, acceptance, lp).  One thread per (row, slot, j); reads are contiguous in j.
@@ -2611,7 +2626,7 @@ __global__ __launch_bounds__(256) void k_export_chains(KParams p, long long row0
         const long long slot = rs % p.P, r = rs / p.P;
         const size_t hrow = (size_t)(row0 + r) * p.P + slot;
         const long long id = (long long)p.id_hist[hrow] - id0;
-        const double v = j < p.D ? p.hist[hrow * p.D + j] : (j == p.D ? (double)p.acc_hist[hrow] : p.lp_hist[hrow]);
+        const double v = j < p.D ? p.hist[hrow * p.hist_ld + j] : (j == p.D ? (double)p.acc_hist[hrow] : p.lp_hist[hrow]);
         if (layout == 0)
             out[(size_t)((id * D2 + j) * n + r)] = v;
         else

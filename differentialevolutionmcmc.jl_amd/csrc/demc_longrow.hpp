@@ -211,9 +211,9 @@ __global__ __launch_bounds__(WG, (WG / 64 * PER_CU + 3) / 4) void k_longrow(KPar
                     if (c >= lo) ++c;
                     if (c >= hi) ++c;
                 }
-                Pa = p.hist + ((a % ub) * (uint64_t)p.P + a / ub) * (uint64_t)D;
-                Pb2 = p.hist + ((b % ub) * (uint64_t)p.P + b / ub) * (uint64_t)D;
-                Pc = p.hist + ((c % ub) * (uint64_t)p.P + c / ub) * (uint64_t)D;
+                Pa = p.hist + ((a % ub) * (uint64_t)p.P + a / ub) * (uint64_t)p.hist_ld;
+                Pb2 = p.hist + ((b % ub) * (uint64_t)p.P + b / ub) * (uint64_t)p.hist_ld;
+                Pc = p.hist + ((c % ub) * (uint64_t)p.P + c / ub) * (uint64_t)p.hist_ld;
                 i0 = (int)(a & 0x7fffffff); i1 = (int)(b & 0x7fffffff); i2 = snooker ? (int)(c & 0x7fffffff) : -1;
             } else if (snooker) {
                 uint32_t a, b, c;  // snooker_update! draws 3 from the whole pool (crossover.jl:241)
@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(WG, (WG / 64 * PER_CU + 3) / 4) void k_longrow(KPar
     }
     DEMC_LR_NEXT(5);
     double* trow = p.theta + slot * D;
-    double* hrow = (p.store_row >= 0) ? p.hist + ((size_t)p.store_row * p.P + slot) * D : nullptr;
+    double* hrow = (p.store_row >= 0) ? p.hist + ((size_t)p.store_row * p.P + slot) * p.hist_ld : nullptr;
     // in a block sweep an accepted crossover proposal differs from the row only inside the block: write only those
     const bool masked = acc && p.mask && kind != 2 && kind != 3;
     // A whole row to move and another particle to follow in this workgroup: its span loops do it (see `pend` at the top).

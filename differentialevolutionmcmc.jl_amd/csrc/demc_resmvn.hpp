@@ -265,7 +265,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
             } else {
                 sl_ = x / ub; row = x - sl_ * ub;
             }
-            return p.hist + (row * (uint64_t)p.P + sl_) * (uint64_t)D;
+            return p.hist + (row * (uint64_t)p.P + sl_) * (uint64_t)p.hist_ld;
         };
         a_o = cell(a);
         b_o = cell(b);
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
             }
         }
         double* trow = p.theta + slot_ * D;
-        double* hrow = store_row_ >= 0 ? p.hist + ((size_t)store_row_ * p.P + slot_) * D : nullptr;
+        double* hrow = store_row_ >= 0 ? p.hist + ((size_t)store_row_ * p.P + slot_) * p.hist_ld : nullptr;
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             const int j = blk ? jB : jA;
@@ -933,7 +933,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
             }
             double* trow = p.theta + slot * D;
             double* lrow = tile + (size_t)pl * D;
-            double* hrow = (store_row >= 0 && wr_hbm) ? p.hist + ((size_t)store_row * p.P + slot) * D : nullptr;
+            double* hrow = (store_row >= 0 && wr_hbm) ? p.hist + ((size_t)store_row * p.P + slot) * p.hist_ld : nullptr;
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
                 const int j = blk ? jB : jA;

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(WG, 2) void k_res_obs(KParams p) {
                         tile[(size_t)pl * D + sl] = x;
                         p.theta[slot * D + sl] = x;
                     }
-                    if (store_row >= 0) p.hist[((size_t)store_row * p.P + slot) * D + sl] = x;
+                    if (store_row >= 0) p.hist[((size_t)store_row * p.P + slot) * p.hist_ld + sl] = x;
                 }
             }
         }
