@@ -891,3 +891,23 @@ def test_user_row_model_through_sample():
     assert abs(d["sigma"]["mean"] - 0.5) < 0.06
     got = np.array([d[f"b0[{s + 1}]"]["mean"] + d["mu_b0"]["mean"] for s in range(S)])
     np.testing.assert_allclose(got, Y.mean(1), atol=0.08)   # subject means are well identified (30 observations each)
+
+
+def test_padded_history_cells_round_trip_through_the_abi():
+    """With history partners the device pads a history cell to whole cache lines (KParams::hist_ld: D = 31 -> 32 doubles); the C-ABI
+    keeps its dense [rows][P][D] layout: rows written with demc_set_history_rows come back from demc_get_history bit for bit, also
+    when the transfer takes several chunks of the staging buffer (40 rows of 16 384 x 31 doubles = 162 MB through 64 MB), at an offset,
+    and the chain export reads the padded cells."""
+    from conftest import make_problem, setup_engine
+    G, Np, d, n_rows = 256, 64, 30, 48
+    prob = make_problem("mvn_iso", np.random.default_rng(5), N=50, d=d)
+    e = D.HipEngine(n_groups=G, Np=Np, D=d + 1, n_rows=n_rows, n_initial=4, schedule=1, partner_kind=1, seed=3, loglike_mode=1)
+    setup_engine(e, prob)
+    rows = np.random.default_rng(6).normal(0, 1, (40, G * Np, d + 1))
+    e.set_history_rows(3, rows)
+    back = e.get_history(3, 43)[0]
+    assert np.array_equal(back, rows)
+    assert np.array_equal(e.get_history(10, 12)[0], rows[7:9])
+    e.set_history_rows(0, rows[:4] * 2.0)
+    assert np.array_equal(e.get_history(0, 5)[0], np.concatenate([rows[:3] * 2.0, rows[3:4] * 2.0, rows[1:2]]))
+    e.close()
