@@ -826,15 +826,26 @@ __global__ __launch_bounds__(WG, (WG == 256 && (!STREAM || OCC == 2)) ? 2 : 1) v
             DEMC_STAMP(17);  // cross terms of this workgroup's chunk done
             const unsigned epoch = (unsigned)(step + 1);
             unsigned long long* gran = p.st_gran + (((size_t)(step & 1) * p.n_groups + gi) * p.st_C) * nact_max * 2;
-            if (tid < n_act) {
+            if constexpr (DIR) {
+                // a partial per 16-lane row (WG / 16 of them): LPS lanes per proposal add LPS-strided shares of them, the shares meet on
+                // the DPP network -- a fixed tree, the same bits in every workgroup of the group -- and the proposal's first lane stores
+                // the granules.  (One lane per proposal adding all 32 in turn was 2.3 k cycles of the phase.)
+                constexpr int LPS = WG / 64;  // 8 lanes per proposal at 512 threads, 4 at 256: 64 proposals at most
+                const int pq8 = tid / LPS, r8 = tid % LPS;
                 double v = 0.0;
-                if constexpr (DIR) {  // a partial per 16-lane row: four chains, then a fixed tree (32 dependent FP64 additions were 2 k cycles)
-                    double v4[4] = {0.0, 0.0, 0.0, 0.0};
+                if (pq8 < n_act) {
 #pragma unroll
-                    for (int wv = 0; wv < WG / 16; ++wv) v4[wv & 3] += part_l[(size_t)wv * nact_max + tid];
-                    v = (v4[0] + v4[1]) + (v4[2] + v4[3]);
-                } else
-                    for (int wv = 0; wv < WG / 64; ++wv) v += part_l[(size_t)wv * nact_max + tid];
+                    for (int wv = 0; wv < WG / 16; wv += LPS) v += part_l[(size_t)(wv + r8) * nact_max + pq8];
+                }
+                v = subgroup_sum(v, LPS);
+                if (pq8 < n_act && r8 == 0) {
+                    unsigned long long* mine_g = gran + ((size_t)c_idx * nact_max + pq8) * 2;
+                    store_granule(mine_g, epoch, (unsigned)__double2loint(v));
+                    store_granule(mine_g + 1, epoch, (unsigned)__double2hiint(v));
+                }
+            } else if (tid < n_act) {
+                double v = 0.0;
+                for (int wv = 0; wv < WG / 64; ++wv) v += part_l[(size_t)wv * nact_max + tid];
                 unsigned long long* mine_g = gran + ((size_t)c_idx * nact_max + tid) * 2;
                 store_granule(mine_g, epoch, (unsigned)__double2loint(v));
                 store_granule(mine_g + 1, epoch, (unsigned)__double2hiint(v));
