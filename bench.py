@@ -1239,9 +1239,8 @@ def compact_line(out):
                                 "device_ms_per_iter", "counter_frac", "shader_clock_mhz", "frac_at_clock", "frac_of_mix_ceiling_at_clock")},
         kernel=short(rf.get("kernel"), 60), sclk_sysfs_mhz=(rf.get("sclk_sysfs_mhz") or {}).get("median"),
         # (what a wasted_traffic_ratio far from 1 is made of, where the detail line explains it: one clause here)
-        **({"traffic_is": "the proposals' m rows, read once per observation chunk (x%.0f): the decomposition that fills the chip; VALU-bound"
-                          % rf["implied_m_rereads"]}
-           if rf.get("traffic_note") and rf.get("wasted_traffic_ratio") and rf.get("implied_m_rereads") else {}))
+        **({"traffic_is": "the proposals' m rows, read once per observation chunk: the decomposition that fills the chip; VALU-bound"}
+           if rf.get("traffic_note") and rf.get("wasted_traffic_ratio") else {}))
     line["cpu_baseline"] = None if cpu is None else dict(
         {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "value_single_thread", "cpu_model")}, sample=short(cpu.get("sample"), 160))
     line["headline_context"] = None if ctx is None else {k: ctx.get(k) for k in ("streaming_value", "streaming_frac_executed", "streaming_frac_survey",
